@@ -1,0 +1,334 @@
+#!/usr/bin/env python3
+"""
+Golden-vector generator (runs ONLY in the build container, where /root/reference exists).
+
+Imports the reference implementation (SherbyRobotics/pyro, pure Python) and records inputs and
+expected outputs of its grid value-iteration path as small .npz fixtures next to this file.
+The fixtures are DATA (arrays + scalars); no reference source text is stored.
+
+    MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_goldens.py [case ...]
+
+Cases follow SURVEY.md section 8(c).  Environment used for the committed fixtures:
+Python 3.10.12, NumPy 2.2.6, SciPy 1.15.3.
+"""
+import contextlib
+import io
+import os
+import sys
+import time
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+REF = os.environ.get("PYRO_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+with quiet():
+    from pyro.dynamic import pendulum, cartpole, manipulator, system  # noqa: E402
+    from pyro.analysis import costfunction  # noqa: E402
+    from pyro.planning import discretizer, dynamicprogramming  # noqa: E402
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %-40s %8.1f KiB" % (name + ".npz", os.path.getsize(path) / 1024.0))
+
+
+# ---------------------------------------------------------------------------------------------
+def case_f_kat():
+    """64 uniform-random (x,u) in bounds per system -> dx  (SURVEY 8c.1)."""
+    out = {}
+    for key, cls in [("pendulum", pendulum.SinglePendulum), ("inverted", pendulum.InvertedPendulum),
+                     ("cartpole", cartpole.CartPole), ("twolink", manipulator.TwoLinkManipulator),
+                     ("doublependulum", pendulum.DoublePendulum)]:
+        with quiet():
+            s = cls()
+        rng = np.random.default_rng(0)
+        X = rng.uniform(s.x_lb, s.x_ub, size=(64, s.n))
+        U = rng.uniform(s.u_lb, s.u_ub, size=(64, s.m))
+        dX = np.array([s.f(X[i], U[i]) for i in range(64)])
+        out[key + "_X"], out[key + "_U"], out[key + "_dX"] = X, U, dX
+        out[key + "_bounds"] = np.concatenate([s.x_lb, s.x_ub, s.u_lb, s.u_ub])
+    # the spot values quoted in SURVEY A.1
+    with quiet():
+        out["spot_pendulum"] = pendulum.SinglePendulum().f(np.array([0.3, 1.2]), np.array([0.7]))
+        out["spot_cartpole"] = cartpole.CartPole().f(np.linspace(0.3, 1.2, 4), np.array([0.7]))
+        out["spot_twolink"] = manipulator.TwoLinkManipulator().f(np.linspace(0.3, 1.2, 4), np.array([0.7, -0.4]))
+    save("f_kat", **out)
+
+
+def case_cost_kat():
+    """Quadratic g/h incl. on-target zeroing and non-diagonal weights; Time; Reachability."""
+    rng = np.random.default_rng(1)
+    n, m = 4, 2
+    q = costfunction.QuadraticCostFunction(n, m)
+    A = rng.normal(size=(n, n)); q.Q = A @ A.T
+    B = rng.normal(size=(m, m)); q.R = B @ B.T
+    C = rng.normal(size=(n, n)); q.S = C @ C.T
+    q.xbar = rng.normal(size=n); q.ubar = rng.normal(size=m)
+    q.EPS = 0.25
+    X = rng.normal(size=(48, n)); U = rng.normal(size=(48, m))
+    X[:8] = q.xbar + 0.05 * rng.normal(size=(8, n))          # inside the on-target ball
+    X[8] = q.xbar
+    g = np.array([q.g(X[i], U[i], 0.0) for i in range(48)], dtype=float)
+    h = np.array([q.h(X[i], 0.0) for i in range(48)], dtype=float)
+    t = costfunction.TimeCostFunction(q.xbar.copy()); t.EPS = 0.25
+    tg = np.array([t.g(X[i], U[i], 0.0) for i in range(48)], dtype=float)
+    r = costfunction.Reachability(lambda x: bool(np.all(np.abs(x) < 1.5)), xbar=q.xbar.copy())
+    rg = np.array([r.g(X[i], U[i], 0.0) for i in range(48)], dtype=float)
+    rh = np.array([r.h(X[i], 0.0) for i in range(48)], dtype=float)
+    save("cost_kat", Q=q.Q, R=q.R, S=q.S, xbar=q.xbar, ubar=q.ubar, EPS=q.EPS, INF=q.INF, X=X, U=U,
+         g=g, h=h, time_g=tg, reach_g=rg, reach_h=rh, reach_INF=r.INF, reach_EPS=r.EPS)
+
+
+def case_grid_kat():
+    """x_level, node/action enumeration maps for n=2,3,4 and m=1,2."""
+    out = {}
+    for dims in [(5, 4), (3, 4, 5), (3, 4, 5, 6)]:
+        for udims in [(3,), (2, 3)]:
+            n, m = len(dims), len(udims)
+            with quiet():
+                s = system.ContinuousDynamicSystem(n, m, n)
+            rng = np.random.default_rng(n * 10 + m)
+            s.x_lb = -rng.uniform(1, 3, n); s.x_ub = rng.uniform(1, 3, n)
+            s.u_lb = -rng.uniform(1, 3, m); s.u_ub = rng.uniform(1, 3, m)
+            with quiet():
+                g = discretizer.GridDynamicSystem(s, list(dims), list(udims), dt=0.1, lookup=False)
+            k = "n%dm%d_" % (n, m)
+            out[k + "bounds"] = np.concatenate([s.x_lb, s.x_ub, s.u_lb, s.u_ub])
+            out[k + "dims"] = np.array(dims); out[k + "udims"] = np.array(udims)
+            for d in range(n):
+                out[k + "x_level%d" % d] = g.x_level[d]
+            for d in range(m):
+                out[k + "u_level%d" % d] = g.u_level[d]
+            out[k + "state_from_node_id"] = g.state_from_node_id
+            out[k + "index_from_node_id"] = g.index_from_node_id
+            out[k + "node_id_from_index"] = g.node_id_from_index
+            out[k + "input_from_action_id"] = g.input_from_action_id
+            out[k + "index_from_action_id"] = g.index_from_action_id
+            out[k + "action_id_from_index"] = g.action_id_from_index
+            out[k + "x_step_size"] = g.x_step_size
+            out[k + "u_step_size"] = g.u_step_size
+            # index helpers on a few probe points (discretizer.py:453-537)
+            P = rng.uniform(s.x_lb * 1.2, s.x_ub * 1.2, size=(16, n))
+            out[k + "probe_x"] = P
+            out[k + "probe_index"] = np.array([g.get_index_from_state(x) for x in P])
+            out[k + "probe_nearest"] = np.array([g.get_nearest_index_from_state(x) for x in P])
+            out[k + "probe_node"] = np.array([g.get_nearest_node_id_from_state(x) for x in P])
+            PU = rng.uniform(s.u_lb * 1.2, s.u_ub * 1.2, size=(16, m))
+            out[k + "probe_u"] = PU
+            out[k + "probe_action"] = np.array([g.get_nearest_action_id_from_input(u) for u in PU])
+    save("grid_kat", **out)
+
+
+def _pendulum_problem(xdims, udims, dt=0.05, INF=300.0, xbar=(-3.14, 0.0), bounds=None, EPS=None, S=None, R=None):
+    with quiet():
+        s = pendulum.SinglePendulum()
+        if bounds is not None:
+            s.x_lb = np.array(bounds[0], dtype=float); s.x_ub = np.array(bounds[1], dtype=float)
+        g = discretizer.GridDynamicSystem(s, list(xdims), list(udims), dt=dt)
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+        q.xbar = np.array(xbar, dtype=float); q.INF = INF
+        if EPS is not None:
+            q.EPS = EPS
+        if S is not None:
+            q.S = np.array(S, dtype=float)
+        if R is not None:
+            q.R = np.array(R, dtype=float)
+    return s, g, q
+
+
+def _meta(s, g, q):
+    return dict(x_lb=s.x_lb, x_ub=s.x_ub, u_lb=s.u_lb, u_ub=s.u_ub, dims=g.x_grid_dim, udims=g.u_grid_dim,
+                dt=g.dt, Q=q.Q, R=q.R, S=q.S, xbar=q.xbar, ubar=q.ubar, INF=q.INF, EPS=q.EPS)
+
+
+def case_pendulum_small():
+    """Pendulum 21x21x5: tables, G, J0 and J/pi after 1, 2, 10 sweeps, LUT and base class (8c.4)."""
+    s, g, q = _pendulum_problem((21, 21), (5,))
+    out = _meta(s, g, q)
+    with quiet():
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, q)
+        dp.save_time_history = False
+        out.update(x_next_table=g.x_next_table, x_next_isok=g.x_next_isok, action_isok=g.action_isok,
+                   G=dp.G, J0=dp.J.copy())
+        stats = []
+        for k in range(1, 11):
+            dp.initialize_backward_step(); dp.compute_backward_step()
+            delta = dp.finalize_backward_step()
+            d = dp.J - dp.J_next
+            stats.append([dp.J.max(), d.max(), d.min(), delta])
+            if k in (1, 2, 10):
+                out["J_%d" % k] = dp.J.copy(); out["pi_%d" % k] = dp.pi.copy()
+        out["stats"] = np.array(stats)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            db = dynamicprogramming.DynamicProgramming(g, q)
+            db.save_time_history = False
+            for k in range(1, 11):
+                db.initialize_backward_step(); db.compute_backward_step(); db.finalize_backward_step()
+                if k in (1, 2, 10):
+                    out["Jbase_%d" % k] = db.J.copy(); out["pibase_%d" % k] = db.pi.copy()
+        # clean_infeasible_set + controller samples (8c.9)
+        dp.clean_infeasible_set()
+        out["J_clean"] = dp.J.copy(); out["pi_clean"] = dp.pi.copy()
+        ctl = dp.get_lookup_table_controller()
+        rng = np.random.default_rng(9)
+        P = rng.uniform(s.x_lb * 1.15, s.x_ub * 1.15, size=(32, 2))
+        P[0] = s.x_lb; P[1] = s.x_ub; P[2] = [g.x_level[0][3], g.x_level[1][7]]
+        out["ctl_x"] = P
+        out["ctl_u"] = np.array([ctl.c(x, 0) for x in P])
+        out["u0_from_policy"] = g.get_input_from_policy(dp.pi, 0)
+    save("pendulum_21x21x5", **out)
+
+
+def case_config1():
+    """Config 1: pendulum 101x101x11 solved to tol 0.1 (8c.5)."""
+    with quiet():
+        s = pendulum.SinglePendulum()
+        s.xbar = np.array([-3.14, 0.0])
+        q = costfunction.QuadraticCostFunction.from_sys(s); q.INF = 300
+        g = discretizer.GridDynamicSystem(s, [101, 101], [11])
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, q)
+        dp.save_time_history = False
+        t0 = time.time()
+        dp.solve_bellman_equation()
+        el = time.time() - t0
+    out = _meta(s, g, q)
+    out.update(J=dp.J, pi=dp.pi.astype(np.int16), sweeps=dp.k, J_prev=dp.J_next, ref_solve_seconds=el)
+    save("config1_pendulum_101x101x11", **out)
+
+
+def case_lowdef():
+    """Pendulum 41x21x3, dt 0.2, EPS 1.0 to tol 1.0 (8c.6)."""
+    s, g, q = _pendulum_problem((41, 21), (3,), dt=0.2, bounds=([-4.0, -5.0], [4.0, 5.0]), EPS=1.0)
+    with quiet():
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, q)
+        dp.save_time_history = False
+        dp.solve_bellman_equation(tol=1.0)
+    out = _meta(s, g, q)
+    out.update(J=dp.J, pi=dp.pi.astype(np.int16), sweeps=dp.k, G=dp.G)
+    save("pendulum_lowdef_41x21x3", **out)
+
+
+def case_pendulum_demo():
+    """Pendulum 51x51x9 with the swing-up demo's bounds/weights (S=10 I, INF 500): non-zero J0."""
+    s, g, q = _pendulum_problem((51, 51), (9,), INF=500.0, bounds=([-10, -10], [10, 10]),
+                                S=[[10.0, 0], [0, 10.0]])
+    with quiet():
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, q)
+        dp.save_time_history = False
+        J0 = dp.J.copy()
+        dp.compute_steps(30)
+    out = _meta(s, g, q)
+    out.update(J0=J0, J=dp.J, pi=dp.pi.astype(np.int16), sweeps=dp.k)
+    save("pendulum_demo_51x51x9", **out)
+
+
+def _run_4d(s, xdims, udims, dt, q, sweeps, keep=(), f32=False, alpha=1.0):
+    with quiet():
+        g = discretizer.GridDynamicSystem(s, list(xdims), list(udims), dt=dt)
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, q)
+        dp.save_time_history = False
+        dp.alpha = alpha
+        out = _meta(s, g, q)
+        out["alpha"] = alpha
+        out["isok_frac"] = g.x_next_isok.mean()
+        out["J0"] = dp.J.copy()
+        for k in range(1, sweeps + 1):
+            dp.initialize_backward_step(); dp.compute_backward_step(); dp.finalize_backward_step()
+            if k in keep:
+                out["J_%d" % k] = dp.J.copy(); out["pi_%d" % k] = dp.pi.astype(np.int16)
+        out["J"] = dp.J.astype(np.float32) if f32 else dp.J
+        out["pi"] = dp.pi.astype(np.int16)
+        out["J_prev"] = dp.J_next.astype(np.float32) if f32 else dp.J_next
+        out["sweeps"] = dp.k
+    return g, dp, out
+
+
+def case_cartpole_small():
+    """Cart-pole 11^4 x 5, 5 sweeps, with a slice of the x_next table (8c.7)."""
+    with quiet():
+        s = cartpole.CartPole(); s.xbar = np.array([0, np.pi, 0, 0.0])
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+    g, dp, out = _run_4d(s, (11,) * 4, (5,), 0.05, q, 5, keep=(1,))
+    ids = np.arange(0, g.nodes_n, 37)
+    out.update(sample_ids=ids, x_next_sample=g.x_next_table[ids], x_next_isok_sample=g.x_next_isok[ids],
+               G_sample=dp.G[ids])
+    save("cartpole_11p4x5", **out)
+
+
+def case_cartpole_mid():
+    """Cart-pole 21^4 x 7, 20 sweeps; J stored rounded to f32, full pi (8c.7)."""
+    with quiet():
+        s = cartpole.CartPole(); s.xbar = np.array([0, np.pi, 0, 0.0])
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+    _, _, out = _run_4d(s, (21,) * 4, (7,), 0.05, q, 20, f32=True)
+    out["J0"] = out["J0"].astype(np.float32)
+    save("cartpole_21p4x7", **out)
+
+
+def case_twolink_small():
+    """Two-link manipulator 11^4 x 3x3, 5 sweeps (8c.7)."""
+    with quiet():
+        s = manipulator.TwoLinkManipulator()
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+    g, dp, out = _run_4d(s, (11,) * 4, (3, 3), 0.05, q, 5, keep=(1,))
+    ids = np.arange(0, g.nodes_n, 37)
+    out.update(sample_ids=ids, x_next_sample=g.x_next_table[ids], x_next_isok_sample=g.x_next_isok[ids],
+               G_sample=dp.G[ids])
+    save("twolink_11p4x3x3", **out)
+
+
+def case_twolink_dt():
+    """Two-link 11^4 x 3x3 with dt = 0.01 (better-conditioned variant suggested by SURVEY 8d)."""
+    with quiet():
+        s = manipulator.TwoLinkManipulator()
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+    g, _, out = _run_4d(s, (11,) * 4, (3, 3), 0.01, q, 5)
+    # full validity mask (bit-packed): this case has cells whose x_next lands within an ulp of a
+    # bound, where LAPACK's 2x2 inverse decides the classification (see test_twolink_dt01)
+    out["x_next_isok_packed"] = np.packbits(g.x_next_isok.ravel())
+    save("twolink_11p4x3x3_dt01", **out)
+
+
+def case_doublependulum():
+    """DoublePendulum 13x11x13x11 x 3x3 with the demo's bounds/weights, dt 0.1, EPS 1, alpha<1."""
+    with quiet():
+        s = pendulum.DoublePendulum()
+        s.x_ub[0] = +0.5; s.x_lb[0] = -5.0; s.x_ub[1] = +4.0; s.x_lb[1] = -1.5
+        s.x_ub[2] = +5.5; s.x_lb[2] = -4.0; s.x_ub[3] = +7.0; s.x_lb[3] = -4.0
+        s.u_ub[0] = +12.0; s.u_lb[0] = -12.0; s.u_ub[1] = +12.0; s.u_lb[1] = -12.0
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+        q.xbar = np.array([0, 0, 0, 0.0])
+        q.Q[0, 0] = 1.0; q.Q[1, 1] = 0.5; q.Q[2, 2] = 0.1; q.Q[3, 3] = 0.05
+        q.R[0, 0] = 0.05; q.R[1, 1] = 0.05
+        q.INF = 1000; q.EPS = 1.0
+    _, _, out = _run_4d(s, (13, 11, 13, 11), (3, 3), 0.1, q, 8, alpha=0.98)
+    save("doublependulum_13x11x13x11x3x3", **out)
+
+
+CASES = dict(f_kat=case_f_kat, cost_kat=case_cost_kat, grid_kat=case_grid_kat,
+             pendulum_small=case_pendulum_small, config1=case_config1, lowdef=case_lowdef,
+             pendulum_demo=case_pendulum_demo, cartpole_small=case_cartpole_small,
+             cartpole_mid=case_cartpole_mid, twolink_small=case_twolink_small,
+             twolink_dt=case_twolink_dt, doublependulum=case_doublependulum)
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(CASES)
+    for nm in names:
+        t0 = time.time()
+        CASES[nm]()
+        print("  %s done in %.1f s" % (nm, time.time() - t0))
