@@ -1,0 +1,168 @@
+/*
+ * pyrovi.h -- C ABI of libpyrovi.so: MI355X (gfx950) grid value-iteration sweeps.
+ *
+ * The reference (SherbyRobotics/pyro) is pure Python and has no FFI boundary of its own; its
+ * boundary is the Python class surface.  This header is the C boundary placed BEHIND that
+ * surface: each entry point replaces one reference method (cited as file:line, relative to the
+ * reference repo root).  The host-side mirror in pyro_amd/ binds these through ctypes
+ * (pyro_amd/_native.py); INTEGRATION.md shows the equivalent stub a pyro maintainer would add.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a negative
+ * PVI_E* code (never throws across the ABI); pvi_last_error() returns a thread-local message.
+ * Host buffers are borrowed for the duration of the call.  A handle owns its device memory and
+ * one HIP stream and must be used from one host thread at a time.  Arrays follow the reference's
+ * layout: node id / action id are C-order (last axis fastest) over x_dim / u_dim
+ * (pyro/planning/discretizer.py:167-310); J is float64[nodes], pi is int64[nodes] on the host.
+ */
+#ifndef PYROVI_H
+#define PYROVI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PVI_ABI_VERSION 1
+#define PVI_MAX_N 4 /* state dimensions supported by the reference grid: 2, 3, 4 (discretizer.py:183-245) */
+#define PVI_MAX_M 2 /* input dimensions: 1, 2 (discretizer.py:271-306) */
+#define PVI_MAX_TRIG 4
+
+/* error codes */
+#define PVI_OK 0
+#define PVI_EINVAL -1   /* bad argument / unsupported shape (reference: ValueError / NotImplementedError) */
+#define PVI_EHIP -2     /* HIP runtime error, see pvi_last_error() */
+#define PVI_ENOMEM -3
+#define PVI_ESTATE -4   /* call not valid in the handle's current state */
+#define PVI_EHALO -5    /* a gather left the stored slab: halo too small for this dynamics */
+
+/* storage / interpolation arithmetic type of J on the device */
+#define PVI_F32 0
+#define PVI_F64 1
+
+/* dynamics evaluated in-kernel (dx = f(x,u), pyro/dynamic/mechanical.py:238-263) */
+#define PVI_DYN_TABLE 0     /* none: x_next / G tables supplied by the host (pvi_set_tables) */
+#define PVI_DYN_PENDULUM 1  /* pyro/dynamic/pendulum.py:16 SinglePendulum, :283 InvertedPendulum */
+#define PVI_DYN_CARTPOLE 2  /* pyro/dynamic/cartpole.py:322 CartPole */
+#define PVI_DYN_TWOLINK 3   /* pyro/dynamic/manipulator.py:795 TwoLinkManipulator, pendulum.py:340 DoublePendulum */
+
+/* cost evaluated in-kernel */
+#define PVI_COST_TABLE 0      /* G supplied by the host */
+#define PVI_COST_QUADRATIC 1  /* pyro/analysis/costfunction.py:101 QuadraticCostFunction */
+
+typedef struct pvi_problem* pvi_handle;
+
+/*
+ * Problem description = the constructor arguments of
+ *   GridDynamicSystem(sys, x_grid_dim, u_grid_dim, dt)        pyro/planning/discretizer.py:27
+ *   DynamicProgramming(grid_sys, cost_function)               pyro/planning/dynamicprogramming.py:119
+ * flattened to plain data.
+ */
+typedef struct pvi_desc {
+    uint32_t struct_size;            /* sizeof(pvi_desc), ABI guard */
+    int32_t n;                       /* sys.n */
+    int32_t m;                       /* sys.m */
+    int32_t x_dim[PVI_MAX_N];        /* x_grid_dim */
+    int32_t u_dim[PVI_MAX_M];        /* u_grid_dim */
+    const double* x_level[PVI_MAX_N];/* np.linspace arrays, discretizer.py:142 (x_dim[d] doubles each) */
+    const double* u_level[PVI_MAX_M];/* discretizer.py:158 */
+    double x_lb[PVI_MAX_N];          /* sys.x_lb / x_ub: isavalidstate box, pyro/dynamic/system.py:198 */
+    double x_ub[PVI_MAX_N];
+    double u_lb[PVI_MAX_M];          /* sys.u_lb / u_ub: isavalidinput box, system.py:208 */
+    double u_ub[PVI_MAX_M];
+    double dt;                       /* grid_sys.dt */
+    int32_t dtype;                   /* PVI_F32 | PVI_F64 */
+    int32_t dynamics_id;             /* PVI_DYN_* */
+    double dyn_params[16];           /* derived constants, see pyro_amd/dynamic/<system>.device_dynamics() */
+    const double* trig[PVI_MAX_TRIG];/* host-computed sin/cos tables over the angle levels (dynamics
+                                        specific, see pyrovi.hip); NULL -> computed with libm */
+    int32_t cost_id;                 /* PVI_COST_* */
+    int32_t ontarget_check;          /* cf.ontarget_check, costfunction.py:137 */
+    double Q[PVI_MAX_N * PVI_MAX_N]; /* row-major n x n */
+    double R[PVI_MAX_M * PVI_MAX_M];
+    double S[PVI_MAX_N * PVI_MAX_N];
+    double xbar[PVI_MAX_N];
+    double ubar[PVI_MAX_M];
+    double EPS;                      /* cf.EPS */
+    double INF;                      /* cf.INF */
+    /* slab of axis 0 handled by this handle (multi-GPU: one handle per rank); whole grid: 0..x_dim[0] */
+    int32_t row_begin, row_end;      /* rows updated by a sweep */
+    int32_t halo_lo, halo_hi;        /* extra rows of J kept below / above for the gathers */
+    int32_t device;                  /* HIP device ordinal */
+    int32_t flags;                   /* reserved, 0 */
+    /* optional caller-owned device buffers (e.g. torch tensors used for the RCCL halo exchange):
+       two J buffers of stored_rows*plane elements of `dtype`, one pi buffer of owned_rows*plane
+       bytes (A<=256) or uint16 (A<=65536).  NULL -> allocated by the library. */
+    void* ext_J[2];
+    void* ext_pi;
+} pvi_desc;
+
+/* ---- library ------------------------------------------------------------------------------ */
+int pvi_abi_version(void);
+const char* pvi_last_error(void);
+int pvi_device_count(int* count);
+
+/* ---- problem life cycle ------------------------------------------------------------------- */
+/* GridDynamicSystem.__init__ + DynamicProgramming.__init__ (discretizer.py:27, dynamicprogramming.py:119) */
+int pvi_create(const pvi_desc* desc, pvi_handle* out);
+void pvi_destroy(pvi_handle h);
+
+/* geometry helpers */
+int64_t pvi_plane_size(pvi_handle h);   /* nodes per axis-0 row */
+int64_t pvi_stored_nodes(pvi_handle h); /* (row_end+halo_hi - (row_begin-halo_lo)) * plane */
+int64_t pvi_owned_nodes(pvi_handle h);
+int pvi_pi_itemsize(pvi_handle h);      /* bytes per policy entry on the device */
+
+/* ---- cost-to-go ---------------------------------------------------------------------------- */
+/* evaluate_terminal_cost: J[s] = cf.h(x_s), pi = 0 on all stored rows (dynamicprogramming.py:159-171) */
+int pvi_terminal_cost(pvi_handle h);
+/* upload / download rows [row0, row0+nrows) of the CURRENT cost-to-go (host float64, converted) */
+int pvi_set_J(pvi_handle h, const double* J_rows, int32_t row0, int32_t nrows);
+int pvi_get_J(pvi_handle h, double* J_rows, int32_t row0, int32_t nrows);
+/* the cost-to-go of the previous sweep (dp.J_next, dynamicprogramming.py:181) */
+int pvi_get_J_prev(pvi_handle h, double* J_rows, int32_t row0, int32_t nrows);
+/* policy of the last sweep as int64 action ids, owned rows only (dynamicprogramming.py:570) */
+int pvi_get_pi(pvi_handle h, int64_t* pi_rows, int32_t row0, int32_t nrows);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+/*
+ * initialize_backward_step + compute_backward_step + finalize_backward_step, `max_sweeps` times
+ * (dynamicprogramming.py:175-261, :557-570; drivers :265-314).  One fused kernel per sweep:
+ *   x_next = f(x,u)*dt + x ; validity ; G = g*dt | INF ; J_interp(x_next) ; min / first argmin.
+ * tol >= 0: stop after the first sweep whose delta = max(|dmax|,|dmin|) <= tol (the stop is
+ * decided on the device, later launches of the batch turn into no-ops).  tol < 0: never stop.
+ * stats: [max_sweeps][4] doubles = (max J, max(J-J_prev), min(J-J_prev), delta) per executed sweep.
+ * Only valid when the handle stores the rows its gathers need (single GPU: whole grid).
+ */
+int pvi_sweep(pvi_handle h, int32_t max_sweeps, double alpha, double tol, double* stats, int32_t* sweeps_done);
+/* GPU time of the sweep kernels of the last pvi_sweep call, from HIP events on the handle's stream */
+int pvi_last_sweep_ms(pvi_handle h, float* ms);
+
+/* multi-GPU building blocks: one sweep of the owned rows enqueued on `stream` (NULL: the
+   handle's stream), no host synchronisation; the caller exchanges halo rows of the new current
+   buffer (pvi_device_J) before the next call and reduces the stats across ranks. */
+int pvi_sweep_async(pvi_handle h, double alpha, void* stream);
+int pvi_sweep_stats(pvi_handle h, double stats3[3], void* stream); /* synchronises `stream` */
+int pvi_device_J(pvi_handle h, int which /*0 current, 1 previous*/, void** dev_ptr);
+int pvi_device_pi(pvi_handle h, void** dev_ptr);
+int pvi_synchronize(pvi_handle h);
+
+/* ---- tables (tier B and reference attributes) ---------------------------------------------- */
+/* compute_xnext_table / compute_action_set_table / compute_cost_lookuptable for rows
+   [row0,row0+nrows) (discretizer.py:342-376, :314-338; dynamicprogramming.py:517-553).
+   Any output pointer may be NULL.  Shapes: x_next [nodes][A][n], masks [nodes][A], G [nodes][A]. */
+int pvi_build_tables(pvi_handle h, int32_t row0, int32_t nrows, double* x_next, uint8_t* x_next_isok,
+                     uint8_t* action_isok, double* G);
+/* tier B: host-built tables for arbitrary sys.f / cf.g (dynamics_id == PVI_DYN_TABLE); `ok` is
+   unused by the sweep (G already carries INF) and may be NULL. */
+int pvi_set_tables(pvi_handle h, const double* x_next, const double* G);
+
+/* ---- batched dynamics ------------------------------------------------------------------------ */
+/* dX[b] = f(X[b], U[b]) for B states (mechanical.py:238-263); host pointers, float64 */
+int pvi_eval_f(int32_t dynamics_id, const double* dyn_params, int32_t n, int32_t m, int64_t B, const double* X,
+               const double* U, double* dX);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYROVI_H */

@@ -1,0 +1,283 @@
+"""
+ctypes binding of libpyrovi.so (C ABI: include/pyrovi.h).
+
+There is NO CPU fallback: if the shared library is missing, or a call fails, a RuntimeError is
+raised.  The library itself loads on a machine without a GPU (so symbol checks work there);
+creating a problem needs a HIP device.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PVI_MAX_N, PVI_MAX_M, PVI_MAX_TRIG = 4, 2, 4
+PVI_F32, PVI_F64 = 0, 1
+DYN_TABLE, DYN_PENDULUM, DYN_CARTPOLE, DYN_TWOLINK = 0, 1, 2, 3
+COST_TABLE, COST_QUADRATIC = 0, 1
+PVI_EHALO = -5
+ABI_VERSION = 1
+
+_dp = C.POINTER(C.c_double)
+
+
+class pvi_desc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("n", C.c_int32), ("m", C.c_int32),
+        ("x_dim", C.c_int32 * PVI_MAX_N), ("u_dim", C.c_int32 * PVI_MAX_M),
+        ("x_level", _dp * PVI_MAX_N), ("u_level", _dp * PVI_MAX_M),
+        ("x_lb", C.c_double * PVI_MAX_N), ("x_ub", C.c_double * PVI_MAX_N),
+        ("u_lb", C.c_double * PVI_MAX_M), ("u_ub", C.c_double * PVI_MAX_M),
+        ("dt", C.c_double), ("dtype", C.c_int32), ("dynamics_id", C.c_int32),
+        ("dyn_params", C.c_double * 16), ("trig", _dp * PVI_MAX_TRIG),
+        ("cost_id", C.c_int32), ("ontarget_check", C.c_int32),
+        ("Q", C.c_double * 16), ("R", C.c_double * 4), ("S", C.c_double * 16),
+        ("xbar", C.c_double * PVI_MAX_N), ("ubar", C.c_double * PVI_MAX_M),
+        ("EPS", C.c_double), ("INF", C.c_double),
+        ("row_begin", C.c_int32), ("row_end", C.c_int32), ("halo_lo", C.c_int32), ("halo_hi", C.c_int32),
+        ("device", C.c_int32), ("flags", C.c_int32),
+        ("ext_J", C.c_void_p * 2), ("ext_pi", C.c_void_p),
+    ]
+
+
+# every symbol include/pyrovi.h declares: name -> (restype, argtypes)
+_h = C.c_void_p
+SYMBOLS = {
+    "pvi_abi_version": (C.c_int, []),
+    "pvi_last_error": (C.c_char_p, []),
+    "pvi_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "pvi_create": (C.c_int, [C.POINTER(pvi_desc), C.POINTER(_h)]),
+    "pvi_destroy": (None, [_h]),
+    "pvi_plane_size": (C.c_int64, [_h]),
+    "pvi_stored_nodes": (C.c_int64, [_h]),
+    "pvi_owned_nodes": (C.c_int64, [_h]),
+    "pvi_pi_itemsize": (C.c_int, [_h]),
+    "pvi_terminal_cost": (C.c_int, [_h]),
+    "pvi_set_J": (C.c_int, [_h, _dp, C.c_int32, C.c_int32]),
+    "pvi_get_J": (C.c_int, [_h, _dp, C.c_int32, C.c_int32]),
+    "pvi_get_J_prev": (C.c_int, [_h, _dp, C.c_int32, C.c_int32]),
+    "pvi_get_pi": (C.c_int, [_h, C.POINTER(C.c_int64), C.c_int32, C.c_int32]),
+    "pvi_sweep": (C.c_int, [_h, C.c_int32, C.c_double, C.c_double, _dp, C.POINTER(C.c_int32)]),
+    "pvi_last_sweep_ms": (C.c_int, [_h, C.POINTER(C.c_float)]),
+    "pvi_sweep_async": (C.c_int, [_h, C.c_double, C.c_void_p]),
+    "pvi_sweep_stats": (C.c_int, [_h, _dp, C.c_void_p]),
+    "pvi_device_J": (C.c_int, [_h, C.c_int, C.POINTER(C.c_void_p)]),
+    "pvi_device_pi": (C.c_int, [_h, C.POINTER(C.c_void_p)]),
+    "pvi_synchronize": (C.c_int, [_h]),
+    "pvi_build_tables": (C.c_int, [_h, C.c_int32, C.c_int32, _dp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), _dp]),
+    "pvi_set_tables": (C.c_int, [_h, _dp, _dp]),
+    "pvi_eval_f": (C.c_int, [C.c_int32, _dp, C.c_int32, C.c_int32, C.c_int64, _dp, _dp, _dp]),
+}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpyrovi.so")
+_lib = None
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libpyrovi error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Load libpyrovi.so (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "pyro_amd: %s is missing -- build it with `python -m pyro_amd._build` "
+                "(hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)            # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if L.pvi_abi_version() != ABI_VERSION:
+            raise RuntimeError("libpyrovi ABI %d != binding ABI %d" % (L.pvi_abi_version(), ABI_VERSION))
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise NativeError(rc, lib().pvi_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().pvi_device_count(C.byref(n)))
+    return n.value
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def eval_f(dyn_id, params16, X, U):
+    """Batched dx = f(x,u) on the GPU (pvi_eval_f)."""
+    X, U = _f64(np.atleast_2d(X)), _f64(np.atleast_2d(U))
+    p = np.zeros(16)
+    p[:len(params16)] = params16
+    out = np.empty_like(X)
+    check(lib().pvi_eval_f(dyn_id, _ptr(p), X.shape[1], U.shape[1], X.shape[0], _ptr(X), _ptr(U), _ptr(out)))
+    return out
+
+
+class Problem:
+    """Owner of one pvi_handle.  All arrays are host NumPy; see include/pyrovi.h."""
+
+    def __init__(self, x_levels, u_levels, x_lb, x_ub, u_lb, u_ub, dt, dtype="float64", dynamics_id=DYN_TABLE,
+                 dyn_params=(), trig=(), cost=None, rows=None, halo=(0, 0), device=0, ext_J=None, ext_pi=None):
+        L = lib()
+        self._keep = []                      # host buffers the descriptor points to
+        d = pvi_desc()
+        d.struct_size = C.sizeof(pvi_desc)
+        d.n, d.m = len(x_levels), len(u_levels)
+        self.n, self.m = d.n, d.m
+        self.dims = tuple(len(l) for l in x_levels)
+        self.u_dims = tuple(len(l) for l in u_levels)
+        for i, l in enumerate(x_levels):
+            a = _f64(l); self._keep.append(a)
+            d.x_dim[i], d.x_level[i] = len(a), _ptr(a)
+            d.x_lb[i], d.x_ub[i] = float(x_lb[i]), float(x_ub[i])
+        for k, l in enumerate(u_levels):
+            a = _f64(l); self._keep.append(a)
+            d.u_dim[k], d.u_level[k] = len(a), _ptr(a)
+            d.u_lb[k], d.u_ub[k] = float(u_lb[k]), float(u_ub[k])
+        d.dt = float(dt)
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype("float32"), np.dtype("float64")):
+            raise ValueError("dtype must be float32 or float64")
+        d.dtype = PVI_F64 if self.dtype == np.dtype("float64") else PVI_F32
+        d.dynamics_id = int(dynamics_id)
+        for i, v in enumerate(dyn_params):
+            d.dyn_params[i] = float(v)
+        for i, t in enumerate(trig):
+            if t is not None:
+                a = _f64(t); self._keep.append(a)
+                d.trig[i] = _ptr(a)
+        if cost is not None:
+            d.cost_id = COST_QUADRATIC
+            n, m = d.n, d.m
+            for name, k in (("Q", n), ("S", n), ("R", m)):
+                M = _f64(cost[name])
+                if M.shape != (k, k):
+                    raise ValueError("cost %s must be %dx%d" % (name, k, k))
+                getattr(d, name)[:k * k] = list(M.ravel())
+            d.xbar[:n] = [float(v) for v in cost["xbar"]]
+            d.ubar[:m] = [float(v) for v in cost["ubar"]]
+            d.EPS, d.INF = float(cost["EPS"]), float(cost["INF"])
+            d.ontarget_check = int(bool(cost.get("ontarget_check", True)))
+        else:
+            d.cost_id = COST_TABLE
+        r0, r1 = (0, self.dims[0]) if rows is None else rows
+        d.row_begin, d.row_end, d.halo_lo, d.halo_hi = int(r0), int(r1), int(halo[0]), int(halo[1])
+        d.device = int(device)
+        if ext_J is not None:
+            d.ext_J[0], d.ext_J[1] = int(ext_J[0]), int(ext_J[1])
+        if ext_pi is not None:
+            d.ext_pi = int(ext_pi)
+        self.rows = (int(r0), int(r1))
+        self.store_rows = (max(0, r0 - halo[0]), min(self.dims[0], r1 + halo[1]))
+        self._h = _h()
+        check(L.pvi_create(C.byref(d), C.byref(self._h)))
+        self.plane = L.pvi_plane_size(self._h)
+        self.owned_nodes = L.pvi_owned_nodes(self._h)
+        self.stored_nodes = L.pvi_stored_nodes(self._h)
+        self.actions_n = int(np.prod(self.u_dims))
+
+    # ------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pvi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _rows(self, row0, nrows, default):
+        if row0 is None:
+            row0, nrows = default[0], default[1] - default[0]
+        return int(row0), int(nrows)
+
+    def terminal_cost(self):
+        check(lib().pvi_terminal_cost(self._h))
+
+    def set_J(self, J, row0=None, nrows=None):
+        row0, nrows = self._rows(row0, nrows, self.store_rows)
+        J = _f64(J).ravel()
+        if J.size != nrows * self.plane:
+            raise ValueError("Grid size does not match data")
+        check(lib().pvi_set_J(self._h, _ptr(J), row0, nrows))
+
+    def get_J(self, row0=None, nrows=None, prev=False):
+        row0, nrows = self._rows(row0, nrows, self.rows)
+        out = np.empty(nrows * self.plane, dtype=np.float64)
+        fn = lib().pvi_get_J_prev if prev else lib().pvi_get_J
+        check(fn(self._h, _ptr(out), row0, nrows))
+        return out
+
+    def get_pi(self, row0=None, nrows=None):
+        row0, nrows = self._rows(row0, nrows, self.rows)
+        out = np.empty(nrows * self.plane, dtype=np.int64)
+        check(lib().pvi_get_pi(self._h, out.ctypes.data_as(C.POINTER(C.c_int64)), row0, nrows))
+        return out
+
+    def sweep(self, max_sweeps, alpha=1.0, tol=-1.0):
+        """Returns (stats[k,4] = max J, dmax, dmin, delta ; sweeps_done)."""
+        stats = np.zeros((max(int(max_sweeps), 1), 4), dtype=np.float64)
+        done = C.c_int32(0)
+        check(lib().pvi_sweep(self._h, int(max_sweeps), float(alpha), float(tol), _ptr(stats), C.byref(done)))
+        return stats[:done.value], done.value
+
+    def last_sweep_ms(self):
+        ms = C.c_float(0)
+        check(lib().pvi_last_sweep_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def sweep_async(self, alpha=1.0, stream=None):
+        check(lib().pvi_sweep_async(self._h, float(alpha), C.c_void_p(stream or 0)))
+
+    def sweep_stats(self, stream=None):
+        out = np.zeros(3)
+        check(lib().pvi_sweep_stats(self._h, _ptr(out), C.c_void_p(stream or 0)))
+        return out
+
+    def device_J(self, which=0):
+        p = C.c_void_p()
+        check(lib().pvi_device_J(self._h, int(which), C.byref(p)))
+        return p.value
+
+    def device_pi(self):
+        p = C.c_void_p()
+        check(lib().pvi_device_pi(self._h, C.byref(p)))
+        return p.value
+
+    def synchronize(self):
+        check(lib().pvi_synchronize(self._h))
+
+    def build_tables(self, row0=None, nrows=None, x_next=True, x_next_isok=True, action_isok=True, G=True):
+        row0, nrows = self._rows(row0, nrows, (0, self.dims[0]))
+        nodes, A = nrows * self.plane, self.actions_n
+        xn = np.empty((nodes, A, self.n)) if x_next else None
+        xo = np.empty((nodes, A), dtype=np.uint8) if x_next_isok else None
+        ao = np.empty((nodes, A), dtype=np.uint8) if action_isok else None
+        g = np.empty((nodes, A)) if G else None
+        u8 = C.POINTER(C.c_uint8)
+        check(lib().pvi_build_tables(
+            self._h, row0, nrows, _ptr(xn) if x_next else None,
+            xo.ctypes.data_as(u8) if x_next_isok else None, ao.ctypes.data_as(u8) if action_isok else None,
+            _ptr(g) if G else None))
+        return xn, (xo.astype(bool) if xo is not None else None), (ao.astype(bool) if ao is not None else None), g
+
+    def set_tables(self, x_next, G):
+        x_next, G = _f64(x_next), _f64(G)
+        A = self.actions_n
+        if x_next.shape != (self.owned_nodes, A, self.n) or G.shape != (self.owned_nodes, A):
+            raise ValueError("table shapes do not match the grid")
+        check(lib().pvi_set_tables(self._h, _ptr(x_next), _ptr(G)))

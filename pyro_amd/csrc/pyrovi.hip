@@ -1,0 +1,1299 @@
+// pyrovi.hip -- gfx950 (MI355X / CDNA4) kernels and C ABI for grid value-iteration sweeps.
+//
+// One fused kernel per Bellman backup (reference: pyro/planning/dynamicprogramming.py:557-570
+// driven by the tables of pyro/planning/discretizer.py:342-376):
+//     x_next = f(x,u)*dt + x  ->  box validity  ->  G = g(x,u)*dt | INF
+//            ->  n-linear interpolation of J_k at x_next (fill 0 outside the grid)
+//            ->  J_{k+1}[s] = min_a (G + alpha*J_interp),  pi[s] = first argmin
+// plus the per-sweep reductions of finalize_backward_step (:240-261).
+//
+// Arithmetic contract (DESIGN.md "numerics"): dynamics, Euler step, validity and the
+// interval/fraction of the interpolation are always float64 in the reference's operation order
+// (this file is compiled with -ffp-contract=off; every fused multiply-add below is explicit).
+// Only the storage of J and the interpolation/Bellman arithmetic follow `dtype`.
+//
+// Written for gfx950 only: 64-wide wavefronts, wave-level __shfl reductions, LDS staging.
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <vector>
+
+#include "../../include/pyrovi.h"
+
+// =================================================================================================
+// device-side problem description (kernel argument, passed by value)
+// =================================================================================================
+struct DevP {
+    int n, m, A, dof;
+    int dim[PVI_MAX_N];
+    long long strd[PVI_MAX_N];  // element strides of the stored J buffer (C order)
+    long long plane;            // nodes per axis-0 row
+    int row_begin, row_end;     // owned rows
+    int store_begin, store_end; // stored rows (owned + halo)
+    const double* lev[PVI_MAX_N];
+    const double* trig[PVI_MAX_TRIG];
+    const double* utab;         // [A][m]
+    const double* gu;           // [A]  (u-ubar)' R (u-ubar)
+    const unsigned char* aok;   // [A]  isavalidinput
+    double lb[PVI_MAX_N], ub[PVI_MAX_N];   // isavalidstate box
+    double glo[PVI_MAX_N], ghi[PVI_MAX_N]; // grid end points (interpolation fill test)
+    double inv_step[PVI_MAX_N];
+    double dt;
+    double c[16];
+    double Q[16], S[16], xbar[PVI_MAX_N];
+    double EPS, INF;
+    int ontarget;
+};
+
+struct Ctrl {
+    int done;      // set by finalize when delta <= tol
+    int k_done;    // sweeps executed in the current batch
+    int halo_err;  // a gather fell outside the stored rows
+    int pad;
+};
+
+// order-preserving encoding of doubles for integer atomicMax
+__device__ __host__ inline unsigned long long enc_f64(double d) {
+    unsigned long long u;
+    memcpy(&u, &d, 8);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __host__ inline double dec_f64(unsigned long long u) {
+    u = (u >> 63) ? (u & 0x7fffffffffffffffull) : ~u;
+    double d;
+    memcpy(&d, &u, 8);
+    return d;
+}
+
+// =================================================================================================
+// dynamics: per-state prologue + per-action acceleration, float64, reference operation order
+// (mechanical.py:222-234 ddq = inv(H) (B u - C dq - g - d); manipulator.py:197-218 adds J^T f_ext = 0)
+// =================================================================================================
+template <int DYN>
+struct Dyn;
+
+// SinglePendulum / InvertedPendulum  (pendulum.py:80-150, :301-312).  c = [1/H, m1*g*lc1 (signed), d1]
+template <>
+struct Dyn<PVI_DYN_PENDULUM> {
+    static constexpr int DOF = 1, M = 1;
+    double hinv, gq, dd;
+    __device__ void init(const double* c, const double* x, const double* tr) {
+        hinv = c[0];
+        gq = c[1] * tr[0];  // tr[0] = sin(q)
+        dd = c[2] * x[1];
+    }
+    __device__ static void trig_from_tables(const DevP& P, const int* i, double* tr) { tr[0] = P.trig[0][i[0]]; }
+    __device__ static void trig_from_state(const double* x, double* tr) { tr[0] = sin(x[0]); }
+    __device__ void accel(const double* u, double* a) const {
+        double rhs = (u[0] - gq) - dd;
+        a[0] = hinv * rhs;
+    }
+};
+
+// CartPole (cartpole.py:369-437).  c = [m1+m2, m2*lcg, m2*lcg^2, -m2*lcg, m2*g*lcg]
+template <>
+struct Dyn<PVI_DYN_CARTPOLE> {
+    static constexpr int DOF = 2, M = 1;
+    double i00, i10, t0, t1, cdq0;
+    __device__ void init(const double* c, const double* x, const double* tr) {
+        const double cth = tr[0], sth = tr[1], dth = x[3];
+        const double H00 = c[0], H01 = c[1] * cth, H11 = c[2];
+        const double C01 = (c[3] * sth) * dth;
+        cdq0 = C01 * dth;
+        const double r1 = -(c[4] * sth);
+        const double det = H00 * H11 - H01 * H01;
+        i00 = H11 / det;
+        const double i01 = -H01 / det;
+        i10 = i01;
+        const double i11 = H00 / det;
+        t0 = i01 * r1;
+        t1 = i11 * r1;
+    }
+    __device__ static void trig_from_tables(const DevP& P, const int* i, double* tr) {
+        tr[0] = P.trig[0][i[1]];  // cos(theta)
+        tr[1] = P.trig[1][i[1]];  // sin(theta)
+    }
+    __device__ static void trig_from_state(const double* x, double* tr) {
+        tr[0] = cos(x[1]);
+        tr[1] = sin(x[1]);
+    }
+    __device__ void accel(const double* u, double* a) const {
+        const double r0 = u[0] - cdq0;
+        a[0] = i00 * r0 + t0;
+        a[1] = i10 * r0 + t1;
+    }
+};
+
+// TwoLinkManipulator / DoublePendulum (manipulator.py:897-992, pendulum.py:400-493)
+// c = [k0, m2, k1, k2, I2, k3, k4, g1c, g2c, d1, d2]  (see pyro_amd/dynamic/manipulator.py)
+template <>
+struct Dyn<PVI_DYN_TWOLINK> {
+    static constexpr int DOF = 2, M = 2;
+    double i00, i01, i10, i11, cdq0, cdq1, G0, G1, D0, D1;
+    __device__ void init(const double* c, const double* x, const double* tr) {
+        const double s1 = tr[0], c2 = tr[1], s2 = tr[2], s12 = tr[3];
+        const double dq0 = x[2], dq1 = x[3];
+        const double H00 = (c[0] + c[1] * (c[2] + c[3] * c2)) + c[4];
+        const double H01 = (c[5] + c[6] * c2) + c[4];
+        const double H11 = c[5] + c[4];
+        const double h = c[6] * s2;
+        const double C00 = -h * dq1, C10 = h * dq0, C01 = -h * (dq0 + dq1);
+        cdq0 = C00 * dq0 + C01 * dq1;
+        cdq1 = C10 * dq0;
+        G0 = -c[7] * s1 - c[8] * s12;
+        G1 = -c[8] * s12;
+        D0 = c[9] * dq0;
+        D1 = c[10] * dq1;
+        const double det = H00 * H11 - H01 * H01;
+        i00 = H11 / det;
+        i01 = -H01 / det;
+        i10 = i01;
+        i11 = H00 / det;
+    }
+    __device__ static void trig_from_tables(const DevP& P, const int* i, double* tr) {
+        tr[0] = P.trig[0][i[0]];                  // sin q0
+        tr[1] = P.trig[1][i[1]];                  // cos q1
+        tr[2] = P.trig[2][i[1]];                  // sin q1
+        tr[3] = P.trig[3][i[0] * P.dim[1] + i[1]];// sin(q0+q1)
+    }
+    __device__ static void trig_from_state(const double* x, double* tr) {
+        tr[0] = sin(x[0]);
+        tr[1] = cos(x[1]);
+        tr[2] = sin(x[1]);
+        tr[3] = sin(x[0] + x[1]);
+    }
+    __device__ void accel(const double* u, double* a) const {
+        const double r0 = ((u[0] - cdq0) - G0) - D0;
+        const double r1 = ((u[1] - cdq1) - G1) - D1;
+        a[0] = i00 * r0 + i01 * r1;
+        a[1] = i10 * r0 + i11 * r1;
+    }
+};
+
+// =================================================================================================
+// cost (costfunction.py:151-204): rows of M.dx first, then the outer dot, all left to right
+// =================================================================================================
+template <int N>
+__device__ inline double quad_form(const double* M, const double* dx) {
+    double out = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double row = M[i * N] * dx[0];
+#pragma unroll
+        for (int j = 1; j < N; ++j) row = row + M[i * N + j] * dx[j];
+        const double term = dx[i] * row;
+        out = (i == 0) ? term : out + term;
+    }
+    return out;
+}
+template <int N>
+__device__ inline double l2norm(const double* dx) {
+    double s = dx[0] * dx[0];
+#pragma unroll
+    for (int j = 1; j < N; ++j) s = s + dx[j] * dx[j];
+    return sqrt(s);
+}
+
+// =================================================================================================
+// interpolation (scipy RegularGridInterpolator 'linear', bounds_error=False, fill_value=0;
+// restated in oracle/vi_oracle.py interp_nlinear)
+// =================================================================================================
+// interval i with lev[i] <= x < lev[i+1], clipped to [0, N-2]   (_rgi_cython.find_indices)
+__device__ inline int find_interval(const double* lev, int N, double lo, double inv_step, double x) {
+    double t = floor((x - lo) * inv_step);
+    int i = (t < 0.0) ? 0 : (t > (double)(N - 2) ? N - 2 : (int)t);
+    while (i > 0 && x < lev[i]) --i;
+    while (i < N - 2 && x >= lev[i + 1]) ++i;
+    return i;
+}
+
+// float64: bit-for-bit the oracle's order.  2-D follows evaluate_linear_2d, n>2 _evaluate_linear.
+template <int N>
+__device__ inline double interp_f64(const double* __restrict__ J, const long long* strd, long long base,
+                                    const double* y) {
+    if (N == 2) {
+        const double v00 = J[base], v01 = J[base + strd[1]];
+        const double v10 = J[base + strd[0]], v11 = J[base + strd[0] + strd[1]];
+        const double a0 = 1.0 - y[0], a1 = 1.0 - y[1];
+        return v00 * a0 * a1 + v01 * a0 * y[1] + v10 * y[0] * a1 + v11 * y[0] * y[1];
+    }
+    double val = 0.0;
+#pragma unroll
+    for (int corner = 0; corner < (1 << N); ++corner) {
+        double w = 1.0;
+        long long off = base;
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+            const int bit = (corner >> (N - 1 - d)) & 1;
+            w = w * (bit ? y[d] : (1.0 - y[d]));
+            off += bit ? strd[d] : 0;
+        }
+        val = val + J[off] * w;
+    }
+    return val;
+}
+
+// float32: nested lerps along the last axis first, explicit FMAs
+template <int N>
+__device__ inline float interp_f32(const float* __restrict__ J, const long long* strd, long long base,
+                                   const float* y) {
+    float v[1 << N];
+#pragma unroll
+    for (int corner = 0; corner < (1 << N); ++corner) {
+        long long off = base;
+#pragma unroll
+        for (int d = 0; d < N; ++d) off += ((corner >> (N - 1 - d)) & 1) ? strd[d] : 0;
+        v[corner] = J[off];
+    }
+#pragma unroll
+    for (int d = N - 1; d >= 0; --d) {
+        const int half = 1 << d;
+#pragma unroll
+        for (int k = 0; k < half; ++k) v[k] = fmaf(y[d], v[2 * k + 1] - v[2 * k], v[2 * k]);
+    }
+    return v[0];
+}
+
+template <typename REAL, int N>
+struct Interp;
+template <int N>
+struct Interp<double, N> {
+    __device__ static double eval(const double* J, const long long* s, long long b, const double* y) {
+        return interp_f64<N>(J, s, b, y);
+    }
+};
+template <int N>
+struct Interp<float, N> {
+    __device__ static float eval(const float* J, const long long* s, long long b, const double* y) {
+        float yf[N];
+#pragma unroll
+        for (int d = 0; d < N; ++d) yf[d] = (float)y[d];
+        return interp_f32<N>(J, s, b, yf);
+    }
+};
+
+// =================================================================================================
+// block reduction of the three sweep statistics -> encoded atomicMax
+// =================================================================================================
+__device__ inline double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+__device__ inline void block_stats(double j, double dmax, double ndmin, unsigned long long* slot) {
+    __shared__ double red[3][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    j = wave_max(j);
+    dmax = wave_max(dmax);
+    ndmin = wave_max(ndmin);
+    if (lane == 0) {
+        red[0][wave] = j;
+        red[1][wave] = dmax;
+        red[2][wave] = ndmin;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double v = red[threadIdx.x][0];
+        for (int w = 1; w < nw; ++w) v = fmax(v, red[threadIdx.x][w]);
+        atomicMax(&slot[threadIdx.x], enc_f64(v));
+    }
+}
+
+__global__ void k_reset_stats(unsigned long long* slots, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) slots[i] = enc_f64(-INFINITY);
+}
+
+__global__ void k_begin_batch(Ctrl* ctrl) {
+    ctrl->done = 0;
+    ctrl->k_done = 0;
+}
+
+// finalize_backward_step (dynamicprogramming.py:247-261): delta = max(|dmax|, |dmin|)
+__global__ void k_finalize(Ctrl* ctrl, const unsigned long long* slots, double* results, int k, double tol) {
+    if (ctrl->done) return;
+    const double mj = dec_f64(slots[3 * k]), dmax = dec_f64(slots[3 * k + 1]), dmin = -dec_f64(slots[3 * k + 2]);
+    const double delta = fmax(fabs(dmax), fabs(dmin));
+    results[4 * k] = mj;
+    results[4 * k + 1] = dmax;
+    results[4 * k + 2] = dmin;
+    results[4 * k + 3] = delta;
+    ctrl->k_done = k + 1;
+    if (tol >= 0.0 && delta <= tol) ctrl->done = 1;
+}
+
+// =================================================================================================
+// node decoding
+// =================================================================================================
+template <int N>
+__device__ inline void decode_node(const DevP& P, long long o, int* idx) {
+    long long row = o / P.plane;
+    int rem = (int)(o - row * P.plane);
+    idx[0] = P.row_begin + (int)row;
+#pragma unroll
+    for (int d = N - 1; d >= 1; --d) {
+        const int q = rem / P.dim[d];
+        idx[d] = rem - q * P.dim[d];
+        rem = q;
+    }
+}
+
+// =================================================================================================
+// terminal cost  J0[s] = h(x_s)   (dynamicprogramming.py:159-171; costfunction.py:151-165)
+// =================================================================================================
+template <typename REAL, int N>
+__global__ void k_terminal_cost(DevP P, REAL* __restrict__ J) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)(P.store_end - P.store_begin) * P.plane;
+    if (s >= total) return;
+    DevP Q = P;  // decode relative to the stored slab
+    Q.row_begin = P.store_begin;
+    int idx[N];
+    decode_node<N>(Q, s, idx);
+    double dx[N];
+#pragma unroll
+    for (int d = 0; d < N; ++d) dx[d] = P.lev[d][idx[d]] - P.xbar[d];
+    double h = quad_form<N>(P.S, dx);
+    if (P.ontarget && l2norm<N>(dx) < P.EPS) h = 0.0;
+    J[s] = (REAL)h;
+}
+
+// =================================================================================================
+// the fused sweep, tier A (in-kernel dynamics), one thread per node, actions looped in registers.
+// v0 gather path: J_k read straight through L1/L2.
+// =================================================================================================
+template <int DYN, typename REAL, typename PI_T>
+__global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ Jin, REAL* __restrict__ Jout,
+                                               PI_T* __restrict__ pi, double alpha, Ctrl* ctrl,
+                                               unsigned long long* slot) {
+    using D = Dyn<DYN>;
+    constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M;
+    if (ctrl->done) return;
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
+    double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
+    if (o < owned) {
+        int idx[N];
+        decode_node<N>(P, o, idx);
+        double x[N], dx[N];
+        long long self = (long long)(idx[0] - P.store_begin) * P.strd[0];
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+            x[d] = P.lev[d][idx[d]];
+            dx[d] = x[d] - P.xbar[d];
+            if (d > 0) self += idx[d] * P.strd[d];
+        }
+        // state part of g (costfunction.py:195) and on-target zone (:199-202)
+        const double gx = quad_form<N>(P.Q, dx);
+        const bool on_target = P.ontarget && (l2norm<N>(dx) < P.EPS);
+
+        // position rows of x_next = f*dt + x with f[0:dof] = dq: the same for every action
+        bool pos_ok = true, pos_in = true, halo_bad = false;
+        int ci[N];
+        double y[N];
+        long long base = 0;
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) {
+            const double xn = x[DOF + i] * P.dt + x[i];
+            pos_ok = pos_ok && !(xn < P.lb[i]) && !(xn > P.ub[i]);
+            pos_in = pos_in && !(xn < P.glo[i]) && !(xn > P.ghi[i]);
+            ci[i] = find_interval(P.lev[i], P.dim[i], P.glo[i], P.inv_step[i], xn);
+            y[i] = (xn - P.lev[i][ci[i]]) / (P.lev[i][ci[i] + 1] - P.lev[i][ci[i]]);
+        }
+        if (pos_in) {
+            int r0 = ci[0];
+            if (r0 < P.store_begin || r0 + 1 >= P.store_end) {
+                halo_bad = true;
+                r0 = min(max(r0, P.store_begin), P.store_end - 2);
+            }
+            base = (long long)(r0 - P.store_begin) * P.strd[0];
+#pragma unroll
+            for (int i = 1; i < DOF; ++i) base += ci[i] * P.strd[i];
+        }
+        if (halo_bad) atomicOr(&ctrl->halo_err, 1);
+
+        double tr[4];
+        D::trig_from_tables(P, idx, tr);
+        D dyn;
+        dyn.init(P.c, x, tr);
+
+        REAL best = (REAL)0;
+        int arg = 0;
+        const REAL alpha_r = (REAL)alpha;
+        for (int a = 0; a < P.A; ++a) {
+            double u[M], acc[DOF];
+#pragma unroll
+            for (int k = 0; k < M; ++k) u[k] = P.utab[a * M + k];
+            dyn.accel(u, acc);
+            bool ok = pos_ok && P.aok[a], inb = pos_in;
+            long long b = base;
+#pragma unroll
+            for (int i = 0; i < DOF; ++i) {
+                const int d = DOF + i;
+                const double xn = acc[i] * P.dt + x[d];
+                ok = ok && !(xn < P.lb[d]) && !(xn > P.ub[d]);
+                inb = inb && !(xn < P.glo[d]) && !(xn > P.ghi[d]);
+                ci[d] = find_interval(P.lev[d], P.dim[d], P.glo[d], P.inv_step[d], xn);
+                y[d] = (xn - P.lev[d][ci[d]]) / (P.lev[d][ci[d] + 1] - P.lev[d][ci[d]]);
+                b += ci[d] * P.strd[d];
+            }
+            // G (dynamicprogramming.py:534-549)
+            const double g = on_target ? 0.0 : (gx + P.gu[a]);
+            const REAL G = ok ? (REAL)(g * P.dt) : (REAL)P.INF;
+            const REAL Jn = inb ? Interp<REAL, N>::eval(Jin, P.strd, b, y) : (REAL)0;
+            REAL q;
+            if (sizeof(REAL) == 8)
+                q = G + alpha_r * Jn;  // two roundings, as numpy (:567)
+            else
+                q = fmaf(alpha_r, Jn, G);
+            if (a == 0 || q < best) {
+                best = q;
+                arg = a;
+            }
+        }
+        Jout[self] = best;
+        pi[o] = (PI_T)arg;
+        const double jn = (double)best, d = jn - (double)Jin[self];
+        st_j = jn;
+        st_dmax = d;
+        st_ndmin = -d;
+    }
+    block_stats(st_j, st_dmax, st_ndmin, slot);
+}
+
+// =================================================================================================
+// tier B: table-driven sweep for arbitrary sys.f / cf.g (dynamicprogramming.py:564-570 verbatim:
+// Q = G + alpha * J_interp(x_next_table)).  x_next [node][A][N] f64, G [node][A] f64.
+// =================================================================================================
+template <int N, typename REAL, typename PI_T>
+__global__ __launch_bounds__(256) void k_sweep_table(DevP P, const double* __restrict__ xnext,
+                                                     const double* __restrict__ Gt, const REAL* __restrict__ Jin,
+                                                     REAL* __restrict__ Jout, PI_T* __restrict__ pi, double alpha,
+                                                     Ctrl* ctrl, unsigned long long* slot) {
+    if (ctrl->done) return;
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
+    double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
+    if (o < owned) {
+        const long long self = o + (long long)(P.row_begin - P.store_begin) * P.plane;
+        REAL best = (REAL)0;
+        int arg = 0;
+        const REAL alpha_r = (REAL)alpha;
+        for (int a = 0; a < P.A; ++a) {
+            const double* xn = xnext + ((long long)o * P.A + a) * N;
+            bool inb = true;
+            int ci[N];
+            double y[N];
+            long long b = 0;
+#pragma unroll
+            for (int d = 0; d < N; ++d) {
+                const double v = xn[d];
+                inb = inb && !(v < P.glo[d]) && !(v > P.ghi[d]);
+                ci[d] = find_interval(P.lev[d], P.dim[d], P.glo[d], P.inv_step[d], v);
+                y[d] = (v - P.lev[d][ci[d]]) / (P.lev[d][ci[d] + 1] - P.lev[d][ci[d]]);
+                int c = ci[d];
+                if (d == 0) {
+                    if (inb && (c < P.store_begin || c + 1 >= P.store_end)) atomicOr(&ctrl->halo_err, 1);
+                    c = min(max(c, P.store_begin), P.store_end - 2) - P.store_begin;
+                }
+                b += c * P.strd[d];
+            }
+            const REAL G = (REAL)Gt[(long long)o * P.A + a];
+            const REAL Jn = inb ? Interp<REAL, N>::eval(Jin, P.strd, b, y) : (REAL)0;
+            REAL q;
+            if (sizeof(REAL) == 8)
+                q = G + alpha_r * Jn;
+            else
+                q = fmaf(alpha_r, Jn, G);
+            if (a == 0 || q < best) {
+                best = q;
+                arg = a;
+            }
+        }
+        Jout[self] = best;
+        pi[o] = (PI_T)arg;
+        const double jn = (double)best, d = jn - (double)Jin[self];
+        st_j = jn;
+        st_dmax = d;
+        st_ndmin = -d;
+    }
+    block_stats(st_j, st_dmax, st_ndmin, slot);
+}
+
+// =================================================================================================
+// reference tables for a block of rows: x_next_table, x_next_isok, action_isok, G
+// (discretizer.py:342-376, :314-338; dynamicprogramming.py:517-553).  One thread per (node, action).
+// =================================================================================================
+template <int DYN>
+__global__ void k_build_tables(DevP P, long long node0, long long nnodes, double* __restrict__ xnext,
+                               unsigned char* __restrict__ xok, unsigned char* __restrict__ aok,
+                               double* __restrict__ G) {
+    using D = Dyn<DYN>;
+    constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nnodes * P.A) return;
+    const long long ln = t / P.A;
+    const int a = (int)(t - ln * P.A);
+    DevP Q = P;
+    Q.row_begin = 0;
+    int idx[N];
+    decode_node<N>(Q, node0 + ln, idx);
+    double x[N], dx[N], tr[4], u[M], acc[DOF];
+#pragma unroll
+    for (int d = 0; d < N; ++d) {
+        x[d] = P.lev[d][idx[d]];
+        dx[d] = x[d] - P.xbar[d];
+    }
+    D::trig_from_tables(P, idx, tr);
+    D dyn;
+    dyn.init(P.c, x, tr);
+#pragma unroll
+    for (int k = 0; k < M; ++k) u[k] = P.utab[a * M + k];
+    dyn.accel(u, acc);
+    bool ok = true;
+    double xn[N];
+#pragma unroll
+    for (int i = 0; i < DOF; ++i) {
+        xn[i] = x[DOF + i] * P.dt + x[i];
+        xn[DOF + i] = acc[i] * P.dt + x[DOF + i];
+    }
+#pragma unroll
+    for (int d = 0; d < N; ++d) ok = ok && !(xn[d] < P.lb[d]) && !(xn[d] > P.ub[d]);
+    if (xnext) {
+#pragma unroll
+        for (int d = 0; d < N; ++d) xnext[t * N + d] = xn[d];
+    }
+    if (xok) xok[t] = ok;
+    if (aok) aok[t] = P.aok[a];
+    if (G) {
+        const bool on_target = P.ontarget && (l2norm<N>(dx) < P.EPS);
+        const double g = on_target ? 0.0 : (quad_form<N>(P.Q, dx) + P.gu[a]);
+        G[t] = (ok && P.aok[a]) ? g * P.dt : P.INF;
+    }
+}
+
+// batched f(x,u) with in-kernel trig (mechanical.py:238-263)
+template <int DYN>
+__global__ void k_eval_f(const double* __restrict__ c16, long long B, const double* __restrict__ X,
+                         const double* __restrict__ U, double* __restrict__ dX) {
+    using D = Dyn<DYN>;
+    constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M;
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double c[16], x[N], u[M], tr[4], acc[DOF];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = c16[i];
+#pragma unroll
+    for (int d = 0; d < N; ++d) x[d] = X[b * N + d];
+#pragma unroll
+    for (int k = 0; k < M; ++k) u[k] = U[b * M + k];
+    D::trig_from_state(x, tr);
+    D dyn;
+    dyn.init(c, x, tr);
+    dyn.accel(u, acc);
+#pragma unroll
+    for (int i = 0; i < DOF; ++i) {
+        dX[b * N + i] = x[DOF + i];
+        dX[b * N + DOF + i] = acc[i];
+    }
+}
+
+// dtype conversions for upload / download
+template <typename REAL>
+__global__ void k_from_f64(const double* __restrict__ src, REAL* __restrict__ dst, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (REAL)src[i];
+}
+template <typename SRC>
+__global__ void k_to_f64(const SRC* __restrict__ src, double* __restrict__ dst, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (double)src[i];
+}
+template <typename PI_T>
+__global__ void k_pi_to_i64(const PI_T* __restrict__ src, long long* __restrict__ dst, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (long long)src[i];
+}
+
+// =================================================================================================
+// host side
+// =================================================================================================
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                    \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? PVI_ENOMEM : PVI_EHIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                     \
+    } while (0)
+
+static inline unsigned grid_for(long long n, int block = 256) { return (unsigned)((n + block - 1) / block); }
+
+static const int MAX_BATCH = 1024;  // sweeps per device-side batch (stats slots)
+
+struct pvi_problem {
+    pvi_desc d;
+    DevP P;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0.f;
+    long long plane = 0, stored = 0, owned = 0;
+    int A = 0, pi_size = 1;
+    void* J[2] = {nullptr, nullptr};
+    bool own_J = true, own_pi = true;
+    void* pi = nullptr;
+    int cur = 0;  // index of the current cost-to-go buffer
+    std::vector<void*> dev_allocs;
+    Ctrl* ctrl = nullptr;
+    unsigned long long* slots = nullptr;
+    double* results = nullptr;
+    double* d_xnext = nullptr;  // tier B tables
+    double* d_G = nullptr;
+    double* stage = nullptr;  // f64 staging for up/download
+    long long stage_n = 0;
+};
+
+template <typename T>
+static int dev_upload(pvi_problem* h, const T* src, size_t n, const T** out) {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, n * sizeof(T) > 0 ? n * sizeof(T) : 8));
+    h->dev_allocs.push_back(p);
+    if (n) HIPCHK(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)p;
+    return PVI_OK;
+}
+
+// host twin of quad_form (same operation order, this TU is built with -ffp-contract=off)
+static double quad_form_host(const double* M, const double* dx, int n) {
+    double out = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double row = M[i * n] * dx[0];
+        for (int j = 1; j < n; ++j) row = row + M[i * n + j] * dx[j];
+        const double term = dx[i] * row;
+        out = (i == 0) ? term : out + term;
+    }
+    return out;
+}
+
+extern "C" int pvi_abi_version(void) { return PVI_ABI_VERSION; }
+extern "C" const char* pvi_last_error(void) { return g_err; }
+
+extern "C" int pvi_device_count(int* count) {
+    if (!count) return fail(PVI_EINVAL, "count is NULL");
+    HIPCHK(hipGetDeviceCount(count));
+    return PVI_OK;
+}
+
+static int dyn_shape(int dyn, int* n, int* m) {
+    switch (dyn) {
+        case PVI_DYN_PENDULUM: *n = 2; *m = 1; return 0;
+        case PVI_DYN_CARTPOLE: *n = 4; *m = 1; return 0;
+        case PVI_DYN_TWOLINK: *n = 4; *m = 2; return 0;
+    }
+    return -1;
+}
+
+extern "C" void pvi_destroy(pvi_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void* p : h->dev_allocs) (void)hipFree(p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
+    if (!d || !out) return fail(PVI_EINVAL, "NULL argument");
+    if (d->struct_size != sizeof(pvi_desc))
+        return fail(PVI_EINVAL, "pvi_desc size mismatch: caller %u, library %zu", d->struct_size, sizeof(pvi_desc));
+    // reference: NotImplementedError for n not in {2,3,4}, m not in {1,2} (discretizer.py:245, :306)
+    if (d->n < 2 || d->n > PVI_MAX_N) return fail(PVI_EINVAL, "state dimension n=%d not in {2,3,4}", d->n);
+    if (d->m < 1 || d->m > PVI_MAX_M) return fail(PVI_EINVAL, "input dimension m=%d not in {1,2}", d->m);
+    if (d->dtype != PVI_F32 && d->dtype != PVI_F64) return fail(PVI_EINVAL, "bad dtype %d", d->dtype);
+    if (d->dynamics_id != PVI_DYN_TABLE) {
+        int n, m;
+        if (dyn_shape(d->dynamics_id, &n, &m)) return fail(PVI_EINVAL, "unknown dynamics_id %d", d->dynamics_id);
+        if (n != d->n || m != d->m)
+            return fail(PVI_EINVAL, "dynamics %d needs n=%d m=%d, got n=%d m=%d", d->dynamics_id, n, m, d->n, d->m);
+        if (d->cost_id != PVI_COST_QUADRATIC) return fail(PVI_EINVAL, "in-kernel dynamics need cost_id QUADRATIC");
+    }
+    long long plane = 1, A = 1;
+    for (int i = 0; i < d->n; ++i) {
+        if (d->x_dim[i] < 2) return fail(PVI_EINVAL, "x_dim[%d]=%d < 2", i, d->x_dim[i]);
+        if (!d->x_level[i]) return fail(PVI_EINVAL, "x_level[%d] is NULL", i);
+        if (i > 0) plane *= d->x_dim[i];
+    }
+    for (int k = 0; k < d->m; ++k) {
+        if (d->u_dim[k] < 1) return fail(PVI_EINVAL, "u_dim[%d]=%d < 1", k, d->u_dim[k]);
+        if (!d->u_level[k]) return fail(PVI_EINVAL, "u_level[%d] is NULL", k);
+        A *= d->u_dim[k];
+    }
+    if (plane > 0x7fffffffLL) return fail(PVI_EINVAL, "plane too large");
+    if (A > 65536) return fail(PVI_EINVAL, "more than 65536 actions");
+    if (d->row_begin < 0 || d->row_end > d->x_dim[0] || d->row_begin >= d->row_end)
+        return fail(PVI_EINVAL, "bad slab rows [%d,%d) of %d", d->row_begin, d->row_end, d->x_dim[0]);
+    if (d->halo_lo < 0 || d->halo_hi < 0) return fail(PVI_EINVAL, "negative halo");
+
+    pvi_problem* h = new (std::nothrow) pvi_problem();
+    if (!h) return fail(PVI_ENOMEM, "host allocation failed");
+    h->d = *d;
+    h->device = d->device;
+    h->plane = plane;
+    h->A = (int)A;
+    h->pi_size = A <= 256 ? 1 : 2;
+    int rc = PVI_OK;
+    auto bail = [&](int code) {
+        pvi_destroy(h);
+        return code;
+    };
+#define HCHK(expr)                 \
+    do {                           \
+        rc = [&]() -> int {        \
+            HIPCHK(expr);          \
+            return PVI_OK;         \
+        }();                       \
+        if (rc) return bail(rc);   \
+    } while (0)
+
+    HCHK(hipSetDevice(h->device));
+    HCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HCHK(hipEventCreate(&h->ev0));
+    HCHK(hipEventCreate(&h->ev1));
+
+    DevP& P = h->P;
+    memset(&P, 0, sizeof(P));
+    P.n = d->n;
+    P.m = d->m;
+    P.A = (int)A;
+    P.dof = d->n / 2;
+    P.plane = plane;
+    P.row_begin = d->row_begin;
+    P.row_end = d->row_end;
+    P.store_begin = d->row_begin - d->halo_lo < 0 ? 0 : d->row_begin - d->halo_lo;
+    P.store_end = d->row_end + d->halo_hi > d->x_dim[0] ? d->x_dim[0] : d->row_end + d->halo_hi;
+    // the interpolation reads rows ci and ci+1: a slab must hold at least two rows
+    if (P.store_end - P.store_begin < 2) return bail(fail(PVI_EINVAL, "stored slab has fewer than 2 rows"));
+    h->stored = (long long)(P.store_end - P.store_begin) * plane;
+    h->owned = (long long)(P.row_end - P.row_begin) * plane;
+    long long s = 1;
+    for (int i = d->n - 1; i >= 0; --i) {
+        P.dim[i] = d->x_dim[i];
+        P.strd[i] = s;
+        s *= d->x_dim[i];
+    }
+    for (int i = 0; i < d->n; ++i) {
+        if ((rc = dev_upload(h, d->x_level[i], (size_t)d->x_dim[i], &P.lev[i]))) return bail(rc);
+        P.lb[i] = d->x_lb[i];
+        P.ub[i] = d->x_ub[i];
+        P.glo[i] = d->x_level[i][0];
+        P.ghi[i] = d->x_level[i][d->x_dim[i] - 1];
+        P.inv_step[i] = (double)(d->x_dim[i] - 1) / (P.ghi[i] - P.glo[i]);
+        P.xbar[i] = d->xbar[i];
+    }
+    P.dt = d->dt;
+    memcpy(P.c, d->dyn_params, sizeof(P.c));
+    // row-major n x n -> dense n x n at the front of the 16-slot arrays
+    memcpy(P.Q, d->Q, sizeof(double) * d->n * d->n);
+    memcpy(P.S, d->S, sizeof(double) * d->n * d->n);
+    P.EPS = d->EPS;
+    P.INF = d->INF;
+    P.ontarget = d->ontarget_check;
+
+    // action tables, C order over u_dim (discretizer.py:253-302)
+    std::vector<double> utab((size_t)A * d->m), gu((size_t)A);
+    std::vector<unsigned char> aok((size_t)A);
+    for (long long a = 0; a < A; ++a) {
+        long long r = a;
+        double du[PVI_MAX_M];
+        bool ok = true;
+        for (int k = d->m - 1; k >= 0; --k) {
+            const int ik = (int)(r % d->u_dim[k]);
+            r /= d->u_dim[k];
+            const double u = d->u_level[k][ik];
+            utab[a * d->m + k] = u;
+            du[k] = u - d->ubar[k];
+            ok = ok && !(u < d->u_lb[k]) && !(u > d->u_ub[k]);  // system.py:208-215
+        }
+        gu[a] = quad_form_host(d->R, du, d->m);
+        aok[a] = ok;
+    }
+    if ((rc = dev_upload(h, utab.data(), utab.size(), &P.utab))) return bail(rc);
+    if ((rc = dev_upload(h, gu.data(), gu.size(), &P.gu))) return bail(rc);
+    if ((rc = dev_upload(h, aok.data(), aok.size(), &P.aok))) return bail(rc);
+
+    // trig tables over the angle levels: supplied by the host (numpy) or computed here with libm
+    auto table = [&](int slot, int axis, double (*fn)(double)) -> int {
+        std::vector<double> t((size_t)d->x_dim[axis]);
+        if (d->trig[slot])
+            memcpy(t.data(), d->trig[slot], t.size() * sizeof(double));
+        else
+            for (size_t i = 0; i < t.size(); ++i) t[i] = fn(d->x_level[axis][i]);
+        return dev_upload(h, t.data(), t.size(), &P.trig[slot]);
+    };
+    double (*fsin)(double) = [](double v) { return std::sin(v); };
+    double (*fcos)(double) = [](double v) { return std::cos(v); };
+    if (d->dynamics_id == PVI_DYN_PENDULUM) {
+        if ((rc = table(0, 0, fsin))) return bail(rc);
+    } else if (d->dynamics_id == PVI_DYN_CARTPOLE) {
+        if ((rc = table(0, 1, fcos)) || (rc = table(1, 1, fsin))) return bail(rc);
+    } else if (d->dynamics_id == PVI_DYN_TWOLINK) {
+        if ((rc = table(0, 0, fsin)) || (rc = table(1, 1, fcos)) || (rc = table(2, 1, fsin))) return bail(rc);
+        std::vector<double> t((size_t)d->x_dim[0] * d->x_dim[1]);
+        if (d->trig[3])
+            memcpy(t.data(), d->trig[3], t.size() * sizeof(double));
+        else
+            for (int i = 0; i < d->x_dim[0]; ++i)
+                for (int j = 0; j < d->x_dim[1]; ++j)
+                    t[(size_t)i * d->x_dim[1] + j] = std::sin(d->x_level[0][i] + d->x_level[1][j]);
+        if ((rc = dev_upload(h, t.data(), t.size(), &P.trig[3]))) return bail(rc);
+    }
+
+    const size_t esz = d->dtype == PVI_F64 ? 8 : 4;
+    for (int b = 0; b < 2; ++b) {
+        if (d->ext_J[0] && d->ext_J[1]) {
+            h->J[b] = d->ext_J[b];
+            h->own_J = false;
+        } else {
+            HCHK(hipMalloc(&h->J[b], (size_t)h->stored * esz));
+            h->dev_allocs.push_back(h->J[b]);
+            HCHK(hipMemsetAsync(h->J[b], 0, (size_t)h->stored * esz, h->stream));
+        }
+    }
+    if (d->ext_pi) {
+        h->pi = d->ext_pi;
+        h->own_pi = false;
+    } else {
+        HCHK(hipMalloc(&h->pi, (size_t)h->owned * h->pi_size));
+        h->dev_allocs.push_back(h->pi);
+        HCHK(hipMemsetAsync(h->pi, 0, (size_t)h->owned * h->pi_size, h->stream));
+    }
+    void* p = nullptr;
+    HCHK(hipMalloc(&p, sizeof(Ctrl)));
+    h->dev_allocs.push_back(p);
+    h->ctrl = (Ctrl*)p;
+    HCHK(hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream));
+    HCHK(hipMalloc(&p, sizeof(unsigned long long) * 3 * MAX_BATCH));
+    h->dev_allocs.push_back(p);
+    h->slots = (unsigned long long*)p;
+    HCHK(hipMalloc(&p, sizeof(double) * 4 * MAX_BATCH));
+    h->dev_allocs.push_back(p);
+    h->results = (double*)p;
+    HCHK(hipStreamSynchronize(h->stream));
+#undef HCHK
+    *out = h;
+    return PVI_OK;
+}
+
+extern "C" int64_t pvi_plane_size(pvi_handle h) { return h ? h->plane : 0; }
+extern "C" int64_t pvi_stored_nodes(pvi_handle h) { return h ? h->stored : 0; }
+extern "C" int64_t pvi_owned_nodes(pvi_handle h) { return h ? h->owned : 0; }
+extern "C" int pvi_pi_itemsize(pvi_handle h) { return h ? h->pi_size : 0; }
+
+extern "C" int pvi_synchronize(pvi_handle h) {
+    if (!h) return fail(PVI_EINVAL, "NULL handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PVI_OK;
+}
+
+// ---- terminal cost ------------------------------------------------------------------------------
+template <typename REAL>
+static int terminal_cost_t(pvi_problem* h) {
+    const unsigned g = grid_for(h->stored);
+    REAL* J = (REAL*)h->J[h->cur];
+    switch (h->P.n) {
+        case 2: hipLaunchKernelGGL((k_terminal_cost<REAL, 2>), g, 256, 0, h->stream, h->P, J); break;
+        case 3: hipLaunchKernelGGL((k_terminal_cost<REAL, 3>), g, 256, 0, h->stream, h->P, J); break;
+        default: hipLaunchKernelGGL((k_terminal_cost<REAL, 4>), g, 256, 0, h->stream, h->P, J); break;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(h->pi, 0, (size_t)h->owned * h->pi_size, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PVI_OK;
+}
+
+extern "C" int pvi_terminal_cost(pvi_handle h) {
+    if (!h) return fail(PVI_EINVAL, "NULL handle");
+    if (h->d.cost_id != PVI_COST_QUADRATIC) return fail(PVI_ESTATE, "terminal cost needs cost_id QUADRATIC");
+    HIPCHK(hipSetDevice(h->device));
+    return h->d.dtype == PVI_F64 ? terminal_cost_t<double>(h) : terminal_cost_t<float>(h);
+}
+
+// ---- upload / download ----------------------------------------------------------------------------
+static int ensure_stage(pvi_problem* h, long long n) {
+    if (h->stage_n >= n) return PVI_OK;
+    if (h->stage) {
+        HIPCHK(hipFree(h->stage));
+        for (auto& p : h->dev_allocs)
+            if (p == h->stage) p = nullptr;
+    }
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, (size_t)n * 8));
+    h->dev_allocs.push_back(p);
+    h->stage = (double*)p;
+    h->stage_n = n;
+    return PVI_OK;
+}
+
+static int rows_check(pvi_problem* h, int row0, int nrows, bool owned_only) {
+    const int lo = owned_only ? h->P.row_begin : h->P.store_begin, hi = owned_only ? h->P.row_end : h->P.store_end;
+    if (nrows <= 0 || row0 < lo || row0 + nrows > hi)
+        return fail(PVI_EINVAL, "rows [%d,%d) outside [%d,%d)", row0, row0 + nrows, lo, hi);
+    return PVI_OK;
+}
+
+static const long long STAGE_CHUNK = 1ll << 24;  // elements per staged transfer (128 MiB of f64)
+
+extern "C" int pvi_set_J(pvi_handle h, const double* Jr, int32_t row0, int32_t nrows) {
+    if (!h || !Jr) return fail(PVI_EINVAL, "NULL argument");
+    int rc = rows_check(h, row0, nrows, false);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    const long long n = (long long)nrows * h->plane, off = (long long)(row0 - h->P.store_begin) * h->plane;
+    if (h->d.dtype == PVI_F64) {
+        HIPCHK(hipMemcpyAsync((double*)h->J[h->cur] + off, Jr, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    } else {
+        for (long long s = 0; s < n; s += STAGE_CHUNK) {
+            const long long c = n - s < STAGE_CHUNK ? n - s : STAGE_CHUNK;
+            if ((rc = ensure_stage(h, c))) return rc;
+            HIPCHK(hipMemcpyAsync(h->stage, Jr + s, (size_t)c * 8, hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL((k_from_f64<float>), grid_for(c), 256, 0, h->stream, h->stage,
+                               (float*)h->J[h->cur] + off + s, c);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PVI_OK;
+}
+
+static int get_J_buf(pvi_problem* h, int which, double* Jr, int row0, int nrows) {
+    if (!h || !Jr) return fail(PVI_EINVAL, "NULL argument");
+    int rc = rows_check(h, row0, nrows, false);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    const long long n = (long long)nrows * h->plane, off = (long long)(row0 - h->P.store_begin) * h->plane;
+    const void* buf = h->J[which ? h->cur ^ 1 : h->cur];
+    if (h->d.dtype == PVI_F64) {
+        HIPCHK(hipMemcpyAsync(Jr, (const double*)buf + off, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    } else {
+        for (long long s = 0; s < n; s += STAGE_CHUNK) {
+            const long long c = n - s < STAGE_CHUNK ? n - s : STAGE_CHUNK;
+            if ((rc = ensure_stage(h, c))) return rc;
+            hipLaunchKernelGGL((k_to_f64<float>), grid_for(c), 256, 0, h->stream, (const float*)buf + off + s,
+                               h->stage, c);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(Jr + s, h->stage, (size_t)c * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PVI_OK;
+}
+
+extern "C" int pvi_get_J(pvi_handle h, double* Jr, int32_t row0, int32_t nrows) { return get_J_buf(h, 0, Jr, row0, nrows); }
+extern "C" int pvi_get_J_prev(pvi_handle h, double* Jr, int32_t row0, int32_t nrows) {
+    return get_J_buf(h, 1, Jr, row0, nrows);
+}
+
+extern "C" int pvi_get_pi(pvi_handle h, int64_t* pr, int32_t row0, int32_t nrows) {
+    if (!h || !pr) return fail(PVI_EINVAL, "NULL argument");
+    int rc = rows_check(h, row0, nrows, true);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    const long long n = (long long)nrows * h->plane, off = (long long)(row0 - h->P.row_begin) * h->plane;
+    for (long long s = 0; s < n; s += STAGE_CHUNK) {
+        const long long c = n - s < STAGE_CHUNK ? n - s : STAGE_CHUNK;
+        if ((rc = ensure_stage(h, c))) return rc;
+        if (h->pi_size == 1)
+            hipLaunchKernelGGL((k_pi_to_i64<unsigned char>), grid_for(c), 256, 0, h->stream,
+                               (const unsigned char*)h->pi + off + s, (long long*)h->stage, c);
+        else
+            hipLaunchKernelGGL((k_pi_to_i64<unsigned short>), grid_for(c), 256, 0, h->stream,
+                               (const unsigned short*)h->pi + off + s, (long long*)h->stage, c);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(pr + s, h->stage, (size_t)c * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return PVI_OK;
+}
+
+extern "C" int pvi_device_J(pvi_handle h, int which, void** p) {
+    if (!h || !p) return fail(PVI_EINVAL, "NULL argument");
+    *p = h->J[which ? h->cur ^ 1 : h->cur];
+    return PVI_OK;
+}
+extern "C" int pvi_device_pi(pvi_handle h, void** p) {
+    if (!h || !p) return fail(PVI_EINVAL, "NULL argument");
+    *p = h->pi;
+    return PVI_OK;
+}
+
+// ---- sweep launch -----------------------------------------------------------------------------------
+template <typename REAL, typename PI_T>
+static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st, unsigned long long* slot) {
+    const unsigned g = grid_for(h->owned);
+    const REAL* Jin = (const REAL*)h->J[src];
+    REAL* Jout = (REAL*)h->J[src ^ 1];
+    PI_T* pi = (PI_T*)h->pi;
+    switch (h->d.dynamics_id) {
+        case PVI_DYN_PENDULUM:
+            hipLaunchKernelGGL((k_sweep<PVI_DYN_PENDULUM, REAL, PI_T>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha,
+                               h->ctrl, slot);
+            break;
+        case PVI_DYN_CARTPOLE:
+            hipLaunchKernelGGL((k_sweep<PVI_DYN_CARTPOLE, REAL, PI_T>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha,
+                               h->ctrl, slot);
+            break;
+        case PVI_DYN_TWOLINK:
+            hipLaunchKernelGGL((k_sweep<PVI_DYN_TWOLINK, REAL, PI_T>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha,
+                               h->ctrl, slot);
+            break;
+        case PVI_DYN_TABLE:
+            if (!h->d_xnext || !h->d_G) return fail(PVI_ESTATE, "tier B sweep before pvi_set_tables");
+            switch (h->P.n) {
+                case 2:
+                    hipLaunchKernelGGL((k_sweep_table<2, REAL, PI_T>), g, 256, 0, st, h->P, h->d_xnext, h->d_G, Jin,
+                                       Jout, pi, alpha, h->ctrl, slot);
+                    break;
+                case 3:
+                    hipLaunchKernelGGL((k_sweep_table<3, REAL, PI_T>), g, 256, 0, st, h->P, h->d_xnext, h->d_G, Jin,
+                                       Jout, pi, alpha, h->ctrl, slot);
+                    break;
+                default:
+                    hipLaunchKernelGGL((k_sweep_table<4, REAL, PI_T>), g, 256, 0, st, h->P, h->d_xnext, h->d_G, Jin,
+                                       Jout, pi, alpha, h->ctrl, slot);
+                    break;
+            }
+            break;
+        default:
+            return fail(PVI_EINVAL, "unknown dynamics_id");
+    }
+    HIPCHK(hipGetLastError());
+    return PVI_OK;
+}
+
+static int launch_sweep(pvi_problem* h, int src, double alpha, hipStream_t st, unsigned long long* slot) {
+    if (h->d.dtype == PVI_F64)
+        return h->pi_size == 1 ? launch_sweep_t<double, unsigned char>(h, src, alpha, st, slot)
+                               : launch_sweep_t<double, unsigned short>(h, src, alpha, st, slot);
+    return h->pi_size == 1 ? launch_sweep_t<float, unsigned char>(h, src, alpha, st, slot)
+                           : launch_sweep_t<float, unsigned short>(h, src, alpha, st, slot);
+}
+
+extern "C" int pvi_sweep(pvi_handle h, int32_t max_sweeps, double alpha, double tol, double* stats,
+                         int32_t* sweeps_done) {
+    if (!h) return fail(PVI_EINVAL, "NULL handle");
+    if (max_sweeps < 0) return fail(PVI_EINVAL, "max_sweeps < 0");
+    if (h->P.store_begin != 0 || h->P.store_end != h->P.dim[0] || h->P.row_begin != 0 || h->P.row_end != h->P.dim[0])
+        return fail(PVI_ESTATE, "pvi_sweep needs a whole-grid handle; use pvi_sweep_async + halo exchange for slabs");
+    HIPCHK(hipSetDevice(h->device));
+    int done_total = 0;
+    float ms_total = 0.f;
+    bool stopped = false;
+    while (done_total < max_sweeps && !stopped) {
+        const int nb = max_sweeps - done_total < MAX_BATCH ? max_sweeps - done_total : MAX_BATCH;
+        hipLaunchKernelGGL(k_reset_stats, grid_for(3 * nb), 256, 0, h->stream, h->slots, 3 * nb);
+        hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, h->stream, h->ctrl);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(h->ev0, h->stream));
+        int src = h->cur;
+        for (int k = 0; k < nb; ++k) {
+            int rc = launch_sweep(h, src, alpha, h->stream, h->slots + 3 * k);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_finalize, 1, 1, 0, h->stream, h->ctrl, h->slots, h->results, k, tol);
+            src ^= 1;
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
+        Ctrl c;
+        HIPCHK(hipMemcpyAsync(&c, h->ctrl, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        ms_total += ms;
+        if (c.halo_err) return fail(PVI_EHALO, "a gather left the stored rows");
+        if (stats && c.k_done)
+            HIPCHK(hipMemcpy(stats + 4 * (size_t)done_total, h->results, sizeof(double) * 4 * c.k_done,
+                             hipMemcpyDeviceToHost));
+        if (c.k_done & 1) h->cur ^= 1;
+        done_total += c.k_done;
+        stopped = c.done != 0;
+    }
+    h->last_ms = ms_total;
+    if (sweeps_done) *sweeps_done = done_total;
+    return PVI_OK;
+}
+
+extern "C" int pvi_last_sweep_ms(pvi_handle h, float* ms) {
+    if (!h || !ms) return fail(PVI_EINVAL, "NULL argument");
+    *ms = h->last_ms;
+    return PVI_OK;
+}
+
+extern "C" int pvi_sweep_async(pvi_handle h, double alpha, void* stream) {
+    if (!h) return fail(PVI_EINVAL, "NULL handle");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    hipLaunchKernelGGL(k_reset_stats, 1, 64, 0, st, h->slots, 3);
+    hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, st, h->ctrl);
+    int rc = launch_sweep(h, h->cur, alpha, st, h->slots);
+    if (rc) return rc;
+    h->cur ^= 1;
+    return PVI_OK;
+}
+
+extern "C" int pvi_sweep_stats(pvi_handle h, double stats3[3], void* stream) {
+    if (!h || !stats3) return fail(PVI_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    unsigned long long raw[3];
+    Ctrl c;
+    HIPCHK(hipMemcpyAsync(raw, h->slots, sizeof(raw), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&c, h->ctrl, sizeof(c), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (c.halo_err) return fail(PVI_EHALO, "a gather left the stored rows: halo too small");
+    stats3[0] = dec_f64(raw[0]);
+    stats3[1] = dec_f64(raw[1]);
+    stats3[2] = -dec_f64(raw[2]);
+    return PVI_OK;
+}
+
+// ---- tables --------------------------------------------------------------------------------------------
+extern "C" int pvi_build_tables(pvi_handle h, int32_t row0, int32_t nrows, double* x_next, uint8_t* x_ok,
+                                uint8_t* a_ok, double* G) {
+    if (!h) return fail(PVI_EINVAL, "NULL handle");
+    if (h->d.dynamics_id == PVI_DYN_TABLE) return fail(PVI_ESTATE, "no in-kernel dynamics to build tables from");
+    if (nrows <= 0 || row0 < 0 || row0 + nrows > h->P.dim[0]) return fail(PVI_EINVAL, "bad row range");
+    HIPCHK(hipSetDevice(h->device));
+    const int N = h->P.n, A = h->A;
+    const long long nodes = (long long)nrows * h->plane, node0 = (long long)row0 * h->plane;
+    const long long chunk_nodes = std::max<long long>(1, (1ll << 22) / A);  // ~4M cells per pass
+    double *dx = nullptr, *dG = nullptr;
+    unsigned char *dxo = nullptr, *dao = nullptr;
+    auto cleanup = [&]() {
+        if (dx) (void)hipFree(dx);
+        if (dG) (void)hipFree(dG);
+        if (dxo) (void)hipFree(dxo);
+        if (dao) (void)hipFree(dao);
+    };
+    const size_t cells = (size_t)chunk_nodes * A;
+    hipError_t e = hipSuccess;
+    if (x_next && e == hipSuccess) e = hipMalloc((void**)&dx, cells * N * 8);
+    if (G && e == hipSuccess) e = hipMalloc((void**)&dG, cells * 8);
+    if (x_ok && e == hipSuccess) e = hipMalloc((void**)&dxo, cells);
+    if (a_ok && e == hipSuccess) e = hipMalloc((void**)&dao, cells);
+    if (e != hipSuccess) {
+        cleanup();
+        return fail(PVI_ENOMEM, "table staging allocation failed: %s", hipGetErrorString(e));
+    }
+    for (long long s = 0; s < nodes; s += chunk_nodes) {
+        const long long c = nodes - s < chunk_nodes ? nodes - s : chunk_nodes;
+        const unsigned g = grid_for(c * A);
+        switch (h->d.dynamics_id) {
+            case PVI_DYN_PENDULUM:
+                hipLaunchKernelGGL((k_build_tables<PVI_DYN_PENDULUM>), g, 256, 0, h->stream, h->P, node0 + s, c, dx, dxo,
+                                   dao, dG);
+                break;
+            case PVI_DYN_CARTPOLE:
+                hipLaunchKernelGGL((k_build_tables<PVI_DYN_CARTPOLE>), g, 256, 0, h->stream, h->P, node0 + s, c, dx, dxo,
+                                   dao, dG);
+                break;
+            default:
+                hipLaunchKernelGGL((k_build_tables<PVI_DYN_TWOLINK>), g, 256, 0, h->stream, h->P, node0 + s, c, dx, dxo,
+                                   dao, dG);
+                break;
+        }
+        e = hipGetLastError();
+        const size_t cc = (size_t)c * A, so = (size_t)s * A;
+        if (e == hipSuccess && x_next) e = hipMemcpyAsync(x_next + so * N, dx, cc * N * 8, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess && G) e = hipMemcpyAsync(G + so, dG, cc * 8, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess && x_ok) e = hipMemcpyAsync(x_ok + so, dxo, cc, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess && a_ok) e = hipMemcpyAsync(a_ok + so, dao, cc, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) {
+            cleanup();
+            return fail(PVI_EHIP, "table build failed: %s", hipGetErrorString(e));
+        }
+    }
+    cleanup();
+    return PVI_OK;
+}
+
+extern "C" int pvi_set_tables(pvi_handle h, const double* x_next, const double* G) {
+    if (!h || !x_next || !G) return fail(PVI_EINVAL, "NULL argument");
+    if (h->d.dynamics_id != PVI_DYN_TABLE) return fail(PVI_ESTATE, "handle was created with in-kernel dynamics");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t cells = (size_t)h->owned * h->A;
+    if (!h->d_xnext) {
+        void* p = nullptr;
+        HIPCHK(hipMalloc(&p, cells * h->P.n * 8));
+        h->dev_allocs.push_back(p);
+        h->d_xnext = (double*)p;
+        HIPCHK(hipMalloc(&p, cells * 8));
+        h->dev_allocs.push_back(p);
+        h->d_G = (double*)p;
+    }
+    HIPCHK(hipMemcpyAsync(h->d_xnext, x_next, cells * h->P.n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_G, G, cells * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PVI_OK;
+}
+
+// ---- batched f ---------------------------------------------------------------------------------------------
+extern "C" int pvi_eval_f(int32_t dyn, const double* params, int32_t n, int32_t m, int64_t B, const double* X,
+                          const double* U, double* dX) {
+    if (!params || !X || !U || !dX) return fail(PVI_EINVAL, "NULL argument");
+    int en, em;
+    if (dyn_shape(dyn, &en, &em)) return fail(PVI_EINVAL, "unknown dynamics_id %d", dyn);
+    if (en != n || em != m) return fail(PVI_EINVAL, "dynamics %d needs n=%d m=%d", dyn, en, em);
+    if (B <= 0) return PVI_OK;
+    double *dc = nullptr, *dXd = nullptr, *dU = nullptr, *dO = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(dc);
+        (void)hipFree(dXd);
+        (void)hipFree(dU);
+        (void)hipFree(dO);
+    };
+    hipError_t e = hipMalloc((void**)&dc, 16 * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&dXd, (size_t)B * n * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&dU, (size_t)B * m * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&dO, (size_t)B * n * 8);
+    if (e == hipSuccess) e = hipMemcpy(dc, params, 16 * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dXd, X, (size_t)B * n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dU, U, (size_t)B * m * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const unsigned g = grid_for(B);
+        if (dyn == PVI_DYN_PENDULUM)
+            hipLaunchKernelGGL((k_eval_f<PVI_DYN_PENDULUM>), g, 256, 0, 0, dc, (long long)B, dXd, dU, dO);
+        else if (dyn == PVI_DYN_CARTPOLE)
+            hipLaunchKernelGGL((k_eval_f<PVI_DYN_CARTPOLE>), g, 256, 0, 0, dc, (long long)B, dXd, dU, dO);
+        else
+            hipLaunchKernelGGL((k_eval_f<PVI_DYN_TWOLINK>), g, 256, 0, 0, dc, (long long)B, dXd, dU, dO);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(dX, dO, (size_t)B * n * 8, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(PVI_EHIP, "pvi_eval_f failed: %s", hipGetErrorString(e));
+    return PVI_OK;
+}

@@ -1,0 +1,71 @@
+"""
+Host mirror of pyro/dynamic/mechanical.py:17-263 (MechanicalSystem):
+    H(q) ddq + C(q,dq) dq + d(q,dq) + g(q) = B(q) u ,   x = [q ; dq]
+"""
+import numpy as np
+
+from pyro_amd.dynamic import system
+
+
+class MechanicalSystem(system.ContinuousDynamicSystem):
+
+    def __init__(self, dof=1, actuators=None):
+        self.dof = dof
+        m = dof if actuators is None else actuators      # fully actuated unless told otherwise
+        super().__init__(2 * dof, m, 2 * dof)
+        self.name = "%dDoF Mechanical System" % dof
+        # mechanical.py:59-74: +-2pi on every state, +-5 on every input
+        self.x_ub = np.full(self.n, 2 * np.pi)
+        self.x_lb = np.full(self.n, -2 * np.pi)
+        self.u_ub = np.full(m, 5.0)
+        self.u_lb = np.full(m, -5.0)
+        for i in range(dof):
+            self.state_label[i], self.state_units[i] = "Angle %d" % i, "[rad]"
+            self.state_label[i + dof], self.state_units[i + dof] = "Velocity %d" % i, "[rad/sec]"
+        for i in range(m):
+            self.input_label[i], self.input_units[i] = "Torque %d" % i, "[Nm]"
+        self.output_label, self.output_units = self.state_label, self.state_units
+
+    # ---- model terms, defaults of mechanical.py:84-149 ----------------------------------------
+    def H(self, q):
+        return np.eye(self.dof)
+
+    def C(self, q, dq):
+        return np.zeros((self.dof, self.dof))
+
+    def B(self, q):
+        B = np.zeros((self.dof, self.m))
+        k = min(self.dof, self.m)
+        B[:k, :k] = np.eye(k)
+        return B
+
+    def g(self, q):
+        return np.zeros(self.dof)
+
+    def d(self, q, dq):
+        return np.zeros(self.dof)
+
+    # ---- state packing (mechanical.py:157-175) ------------------------------------------------
+    def x2q(self, x):
+        return [x[:self.dof], x[self.dof:self.n]]
+
+    def q2x(self, q, dq):
+        return np.concatenate([np.atleast_1d(q), np.atleast_1d(dq)]).astype(float)
+
+    def xut2q(self, x, u, t):
+        return self.x2q(x)[0]
+
+    # ---- dynamics (mechanical.py:222-263) -----------------------------------------------------
+    def generalized_forces(self, q, dq, ddq, t=0):
+        return self.H(q) @ ddq + self.C(q, dq) @ dq + self.g(q) + self.d(q, dq)
+
+    def ddq(self, q, dq, u, t=0):
+        rhs = self.B(q) @ u - self.C(q, dq) @ dq - self.g(q) - self.d(q, dq)
+        return np.linalg.inv(self.H(q)) @ rhs
+
+    def f(self, x, u, t=0):
+        q, dq = self.x2q(np.asarray(x, dtype=float))
+        return self.q2x(dq, self.ddq(q, dq, np.asarray(u, dtype=float), t))
+
+    def kinetic_energy(self, q, dq):
+        return 0.5 * dq @ (self.H(q) @ dq)

@@ -1,0 +1,122 @@
+"""
+Host mirror of the pendulum systems used by the DP path (reference pyro/dynamic/pendulum.py:
+SinglePendulum :16, InvertedPendulum :283, DoublePendulum :340).  Drawing code is out of scope.
+"""
+import numpy as np
+
+from pyro_amd import _native
+from pyro_amd.dynamic import mechanical
+
+
+class SinglePendulum(mechanical.MechanicalSystem):
+    """Point mass m1 at lc1 on a rod of inertia I1; q = 0 is hanging down (pendulum.py:52-66)."""
+
+    _gravity_sign = 1.0
+
+    def __init__(self):
+        super().__init__(1)
+        self.name = "Single Pendulum"
+        self.setparams()
+
+    def setparams(self):
+        self.l1, self.lc1 = 2.0, 1
+        self.m1, self.I1, self.gravity, self.d1 = 1, 1, 9.81, 0
+        self.l_domain = 5.0
+
+    def H(self, q):
+        return np.array([[self.m1 * self.lc1 ** 2 + self.I1]], dtype=float)
+
+    def C(self, q, dq):
+        return np.zeros((1, 1))
+
+    def B(self, q):
+        return np.eye(1)
+
+    def g(self, q):
+        return np.array([self._gravity_sign * self.m1 * self.gravity * self.lc1 * np.sin(q[0])])
+
+    def d(self, q, dq):
+        return np.array([self.d1 * dq[0]])
+
+    # device: c = [1/H, signed m1*g*lc1, d1]   (kernel: Dyn<PVI_DYN_PENDULUM>)
+    def device_dynamics(self):
+        H = self.m1 * self.lc1 ** 2 + self.I1
+        gc = self.m1 * self.gravity * self.lc1
+        return _native.DYN_PENDULUM, [1.0 / float(H), self._gravity_sign * gc, float(self.d1)]
+
+    def device_trig(self, x_level):
+        return (np.sin(x_level[0]),)
+
+
+class InvertedPendulum(SinglePendulum):
+    """Same model with gravity flipped: q = 0 is upright (pendulum.py:283-312)."""
+
+    _gravity_sign = -1.0
+
+    def __init__(self):
+        super().__init__()
+        self.name = "Inverted Pendulum"
+
+
+class _TwoLinkTerms:
+    """H, C, g, d shared by DoublePendulum (pendulum.py:400-493) and TwoLinkManipulator
+    (manipulator.py:897-992); B = I."""
+
+    def _trig(self, q):
+        return np.cos(q[1]), np.sin(q[1]), np.sin(q[0]), np.sin(q[0] + q[1])
+
+    def H(self, q):
+        c2 = np.cos(q[1])
+        H01 = self.m2 * self.lc2 ** 2 + self.m2 * self.l1 * self.lc2 * c2 + self.I2
+        H00 = (self.m1 * self.lc1 ** 2 + self.I1
+               + self.m2 * (self.l1 ** 2 + self.lc2 ** 2 + 2 * self.l1 * self.lc2 * c2) + self.I2)
+        return np.array([[H00, H01], [H01, self.m2 * self.lc2 ** 2 + self.I2]], dtype=float)
+
+    def C(self, q, dq):
+        h = self.m2 * self.l1 * self.lc2 * np.sin(q[1])
+        return np.array([[-h * dq[1], -h * (dq[0] + dq[1])], [h * dq[0], 0.0]])
+
+    def B(self, q):
+        return np.eye(2)
+
+    def g(self, q):
+        g1 = (self.m1 * self.lc1 + self.m2 * self.l1) * self.gravity
+        g2 = self.m2 * self.lc2 * self.gravity
+        s1, s12 = np.sin(q[0]), np.sin(q[0] + q[1])
+        return np.array([-g1 * s1 - g2 * s12, -g2 * s12])
+
+    def d(self, q, dq):
+        return np.array([self.d1 * dq[0], self.d2 * dq[1]])
+
+    # device: c = [k0, m2, k1, k2, I2, k3, k4, g1c, g2c, d1, d2]   (kernel: Dyn<PVI_DYN_TWOLINK>)
+    def device_dynamics(self):
+        k0 = self.m1 * self.lc1 ** 2 + self.I1
+        k1 = self.l1 ** 2 + self.lc2 ** 2
+        k2 = 2 * self.l1 * self.lc2
+        k3 = self.m2 * self.lc2 ** 2
+        k4 = self.m2 * self.l1 * self.lc2
+        g1c = (self.m1 * self.lc1 + self.m2 * self.l1) * self.gravity
+        g2c = self.m2 * self.lc2 * self.gravity
+        return _native.DYN_TWOLINK, [float(v) for v in
+                                     (k0, self.m2, k1, k2, self.I2, k3, k4, g1c, g2c, self.d1, self.d2)]
+
+    def device_trig(self, x_level):
+        q0, q1 = x_level[0], x_level[1]
+        return np.sin(q0), np.cos(q1), np.sin(q1), np.sin(q0[:, None] + q1[None, :])
+
+
+class DoublePendulum(_TwoLinkTerms, mechanical.MechanicalSystem):
+    """Two unit links, torques at both joints (pendulum.py:340-378)."""
+
+    def __init__(self):
+        mechanical.MechanicalSystem.__init__(self, 2)
+        self.name = "Double Pendulum"
+        self.setparams()
+        self.l_domain = 3
+
+    def setparams(self):
+        self.l1 = self.l2 = self.lc1 = self.lc2 = 1
+        self.m1 = self.m2 = 1
+        self.I1 = self.I2 = 0
+        self.gravity = 9.81
+        self.d1 = self.d2 = 0

@@ -1,0 +1,98 @@
+"""
+Host mirror of the part of pyro/dynamic/system.py the value-iteration path touches
+(reference: ContinuousDynamicSystem, system.py:21-333): dimensions, labels, box bounds,
+nominal point, `f` contract, box validity tests and the Euler step.
+
+Additions for the device path (not in the reference):
+  device_dynamics() -> None | (dynamics_id, params, trig_tables_fn)   in-kernel closed form
+  f_batch(X, U)     -> dX for B states at once on the GPU when device_dynamics() exists
+"""
+import numpy as np
+
+
+class ContinuousDynamicSystem:
+    """dx = f(x, u, t) with x in R^n, u in R^m, y in R^p  (reference system.py:21)."""
+
+    def __init__(self, n=1, m=1, p=1):
+        self.n, self.m, self.p = n, m, p
+        self.name = "ContinuousDynamicSystem"
+        self.state_label = ["State %d" % i for i in range(n)]
+        self.input_label = ["Input %d" % i for i in range(m)]
+        self.output_label = ["Output %d" % i for i in range(p)]
+        self.state_units = [""] * n
+        self.input_units = [""] * m
+        self.output_units = [""] * p
+        # default domain (system.py:90-93) and nominal values (:96-98)
+        self.x_ub = np.full(n, 10.0)
+        self.x_lb = np.full(n, -10.0)
+        self.u_ub = np.full(m, 1.0)
+        self.u_lb = np.full(m, -1.0)
+        self.xbar = np.zeros(n)
+        self.ubar = np.zeros(m)
+        self.tbar = 0
+        self.x0 = np.zeros(n)
+        self.traj = None
+
+    # the cost function the reference attaches in __init__ (system.py:121), built on first use
+    @property
+    def cost_function(self):
+        if getattr(self, "_cost_function", None) is None:
+            from pyro_amd.analysis import costfunction
+            self._cost_function = costfunction.QuadraticCostFunction.from_sys(self)
+        return self._cost_function
+
+    @cost_function.setter
+    def cost_function(self, cf):
+        self._cost_function = cf
+
+    # ---- to be provided by subclasses ---------------------------------------------------------
+    def f(self, x, u, t=0):
+        """State derivative (system.py:124-145)."""
+        raise NotImplementedError
+
+    def h(self, x, u, t=0):
+        """Output, default y = x (system.py:152-170)."""
+        return x
+
+    def t2u(self, t):
+        """Open-loop input signal, default constant ubar (system.py:173-191)."""
+        return self.ubar
+
+    # ---- domain tests (system.py:198-215): inclusive box; NaN compares false -> valid ---------
+    def isavalidstate(self, x):
+        x = np.asarray(x)
+        return not bool(np.any(x < self.x_lb) or np.any(x > self.x_ub))
+
+    def isavalidinput(self, x, u):
+        u = np.asarray(u)
+        return not bool(np.any(u < self.u_lb) or np.any(u > self.u_ub))
+
+    # ---- helpers ---------------------------------------------------------------------------------
+    def fsim(self, x, t=0):
+        """f with the internal input signal (system.py:295-312)."""
+        return self.f(x, self.t2u(t), t)
+
+    def x_next(self, x, u, t=0, dt=0.1, steps=1):
+        """Explicit Euler, `steps` times (system.py:315-333)."""
+        x = np.asarray(x, dtype=float)
+        for _ in range(steps):
+            x = self.f(x, u, t) * dt + x
+        return x
+
+    # ---- device path -------------------------------------------------------------------------------
+    def device_dynamics(self):
+        """(dynamics_id, params) when libpyrovi can evaluate f in-kernel, else None."""
+        return None
+
+    def device_trig(self, x_level):
+        """Host-side sin/cos tables over the grid levels consumed by the kernels."""
+        return ()
+
+    def f_batch(self, X, U):
+        """dX[b] = f(X[b], U[b]); on the GPU for systems with device_dynamics()."""
+        dd = self.device_dynamics()
+        X, U = np.atleast_2d(X), np.atleast_2d(U)
+        if dd is not None:
+            from pyro_amd import _native
+            return _native.eval_f(dd[0], dd[1], X, U)
+        return np.array([self.f(X[i], U[i]) for i in range(X.shape[0])])

@@ -1,0 +1,258 @@
+"""
+Host mirror of pyro/planning/discretizer.py:24-834 (GridDynamicSystem): regular grids over the
+state and input boxes, node/action enumeration (C order), index helpers, interpolation objects
+and the forward-dynamics look-up tables.
+
+Differences a user can see (DESIGN.md "drop-in notes"):
+  * the O(N) / O(N*A) arrays (state_from_node_id, x_next_table, ...) are built on first access
+    instead of in __init__, so a 101^4 grid does not allocate 70 GB up front;
+  * x_next_table / x_next_isok / action_isok come from the GPU (pvi_build_tables) when the
+    system has in-kernel dynamics, and from the reference's node-by-node loop over sys.f otherwise.
+"""
+import time
+
+import numpy as np
+from scipy.interpolate import RectBivariateSpline, RegularGridInterpolator
+
+from pyro_amd import _native
+
+
+def _null_cost(n, m):
+    return dict(Q=np.eye(n), R=np.eye(m), S=np.zeros((n, n)), xbar=np.zeros(n), ubar=np.zeros(m),
+                EPS=0.0, INF=0.0, ontarget_check=False)
+
+
+class GridDynamicSystem:
+
+    def __init__(self, sys, x_grid_dim=[101, 101], u_grid_dim=[11], dt=0.05, lookup=True):
+        self.sys = sys
+        self.dt = dt
+        self.x_grid_dim = np.array(x_grid_dim)
+        self.u_grid_dim = np.array(u_grid_dim)
+        self.computelookuptable = lookup
+        self.fontsize, self.figsize, self.dpi = 5, (4, 3), 300
+        self._lazy = {}
+        self.compute()
+
+    # ------------------------------------------------------------------ set-up (discretizer.py:111-163)
+    def compute(self):
+        if self.sys.n not in (2, 3, 4) or self.sys.m not in (1, 2):
+            raise NotImplementedError              # discretizer.py:245, :306
+        if len(self.x_grid_dim) != self.sys.n or len(self.u_grid_dim) != self.sys.m:
+            raise ValueError("grid dimensions do not match the system dimensions")
+        self._lazy.clear()
+        self.discretize_state_space()
+        self.discretize_input_space()
+        print("\nGenerating a mesh for:", self.sys.name)
+        print("---------------------------------------------------")
+        print("State space dimensions:", self.sys.n, " Input space dimension:", self.sys.m)
+        print("Number of nodes:", self.nodes_n, " Number of actions:", self.actions_n)
+        print("Number of node-action pairs:", self.nodes_n * self.actions_n)
+        print("---------------------------------------------------")
+
+    def discretize_state_space(self):
+        s = self.sys
+        self.x_level = [np.linspace(s.x_lb[i], s.x_ub[i], self.x_grid_dim[i]) for i in range(s.n)]
+        self.nodes_n = int(np.prod(self.x_grid_dim))
+        self.x_range = s.x_ub - s.x_lb
+        self.x_step_size = self.x_range / (self.x_grid_dim - 1)
+
+    def discretize_input_space(self):
+        s = self.sys
+        self.u_level = [np.linspace(s.u_lb[i], s.u_ub[i], self.u_grid_dim[i]) for i in range(s.m)]
+        self.actions_n = int(np.prod(self.u_grid_dim))
+        self.u_range = s.u_ub - s.u_lb
+        self.u_step_size = self.u_range / (self.u_grid_dim - 1)
+
+    # ------------------------------------------------------------------ enumeration (discretizer.py:167-310)
+    @staticmethod
+    def _enumerate(levels, dims):
+        total = int(np.prod(dims))
+        index = np.stack(np.unravel_index(np.arange(total), tuple(int(d) for d in dims)), axis=-1)
+        value = np.stack([levels[k][index[:, k]] for k in range(len(dims))], axis=-1)
+        ids = np.arange(total).reshape(tuple(int(d) for d in dims))
+        return value, index.astype(int), ids
+
+    def generate_nodes(self):
+        v, i, ids = self._enumerate(self.x_level, self.x_grid_dim)
+        self._lazy.update(state_from_node_id=v, index_from_node_id=i, node_id_from_index=ids)
+
+    def generate_actions(self):
+        v, i, ids = self._enumerate(self.u_level, self.u_grid_dim)
+        self._lazy.update(input_from_action_id=v, index_from_action_id=i, action_id_from_index=ids)
+
+    _NODE_ATTRS = ("state_from_node_id", "index_from_node_id", "node_id_from_index")
+    _ACTION_ATTRS = ("input_from_action_id", "index_from_action_id", "action_id_from_index")
+    _TABLE_ATTRS = ("x_next_table", "x_next_isok")
+
+    def __getattr__(self, name):
+        lazy = self.__dict__.get("_lazy")
+        if lazy is None:
+            raise AttributeError(name)
+        if name not in lazy:
+            if name in self._NODE_ATTRS:
+                self.generate_nodes()
+            elif name in self._ACTION_ATTRS:
+                self.generate_actions()
+            elif name in self._TABLE_ATTRS:
+                self.compute_xnext_table()
+            elif name == "action_isok":
+                self.compute_action_set_table()
+            else:
+                raise AttributeError(name)
+        return lazy[name]
+
+    def __setattr__(self, name, value):
+        if name in self._NODE_ATTRS + self._ACTION_ATTRS + self._TABLE_ATTRS + ("action_isok",):
+            self._lazy[name] = value
+        else:
+            object.__setattr__(self, name, value)
+
+    # ------------------------------------------------------------------ device handle for table builds
+    def _device_problem(self, cost=None, dtype="float64", **kw):
+        """libpyrovi problem for this grid; `cost` = dict from CostFunction.device_cost()."""
+        s = self.sys
+        dd = device_dynamics_of(s)
+        if dd is None:
+            dyn_id, params, trig = _native.DYN_TABLE, (), ()
+        else:
+            dyn_id, params = dd
+            trig = s.device_trig(self.x_level)
+        if dyn_id != _native.DYN_TABLE and cost is None:
+            cost = _null_cost(s.n, s.m)
+        return _native.Problem(self.x_level, self.u_level, s.x_lb, s.x_ub, s.u_lb, s.u_ub, self.dt, dtype=dtype,
+                               dynamics_id=dyn_id, dyn_params=params, trig=trig, cost=cost, **kw)
+
+    # ------------------------------------------------------------------ look-up tables (discretizer.py:314-376)
+    def compute_xnext_table(self):
+        """x_next_table[s,a,:] = sys.f(x_s,u_a)*dt + x_s and x_next_isok[s,a] = sys.isavalidstate(x_next)."""
+        t0 = time.time()
+        print("Computing x_next array.. ", end="")
+        if device_dynamics_of(self.sys) is not None:
+            p = self._device_problem()
+            xn, ok, _, _ = p.build_tables(action_isok=False, G=False)
+            p.close()
+        else:
+            xn, ok = self._host_xnext_table()
+        self._lazy.update(x_next_table=xn, x_next_isok=ok)
+        print("completed in %4.2f sec" % (time.time() - t0))
+
+    def _host_xnext_table(self):
+        """Generic systems: the reference's own loop over sys.f (arbitrary Python)."""
+        s, X, U = self.sys, self.state_from_node_id, self.input_from_action_id
+        xn = np.zeros((self.nodes_n, self.actions_n, s.n))
+        ok = np.zeros((self.nodes_n, self.actions_n), dtype=bool)
+        for i in range(self.nodes_n):
+            for a in range(self.actions_n):
+                x_next = s.f(X[i], U[a]) * self.dt + X[i]
+                xn[i, a] = x_next
+                ok[i, a] = s.isavalidstate(x_next)
+        return xn, ok
+
+    def compute_action_set_table(self):
+        """action_isok[s,a] = sys.isavalidinput(x_s, u_a)."""
+        s = self.sys
+        if type(s).isavalidinput is _box_isavalidinput():
+            U = self.input_from_action_id
+            row = ~(np.any(U < s.u_lb, axis=1) | np.any(U > s.u_ub, axis=1))
+            ok = np.broadcast_to(row, (self.nodes_n, self.actions_n)).copy()
+        else:
+            X, U = self.state_from_node_id, self.input_from_action_id
+            ok = np.array([[s.isavalidinput(X[i], U[a]) for a in range(self.actions_n)]
+                           for i in range(self.nodes_n)], dtype=bool)
+        self._lazy["action_isok"] = ok
+
+    def save_lookup_tables(self, name="grid"):
+        np.savez(name, x_next_table=self.x_next_table, x_next_isok=self.x_next_isok, action_isok=self.action_isok)
+
+    def load_lookup_tables(self, name="grid"):
+        try:
+            data = np.load(name + ".npz")
+        except Exception:
+            print("\n File not found ")
+        else:
+            self._lazy.update(x_next_table=data["x_next_table"], x_next_isok=data["x_next_isok"],
+                              action_isok=data["action_isok"])
+
+    # ------------------------------------------------------------------ index helpers (discretizer.py:453-537)
+    def get_index_from_state(self, x):
+        return (np.asarray(x, dtype=float) - self.sys.x_lb) / self.x_range * (self.x_grid_dim - 1)
+
+    def get_nearest_index_from_state(self, x):
+        return np.clip(np.rint(self.get_index_from_state(x)).astype(int), 0, self.x_grid_dim - 1)
+
+    def get_nearest_node_id_from_state(self, x):
+        return int(np.ravel_multi_index(tuple(self.get_nearest_index_from_state(x)), tuple(self.x_grid_dim)))
+
+    def get_index_from_input(self, u):
+        return (np.asarray(u, dtype=float) - self.sys.u_lb) / self.u_range * (self.u_grid_dim - 1)
+
+    def get_nearest_index_from_input(self, u):
+        return np.clip(np.rint(self.get_index_from_input(u)).astype(int), 0, self.u_grid_dim - 1)
+
+    def get_nearest_action_id_from_input(self, u):
+        return int(np.ravel_multi_index(tuple(self.get_nearest_index_from_input(u)), tuple(self.u_grid_dim)))
+
+    # ------------------------------------------------------------------ tools (discretizer.py:545-633)
+    def get_grid_from_array(self, J):
+        return J.reshape(self.x_grid_dim)
+
+    def compute_interpolation_function(self, J, method="linear", bounds_error=True, fill_value=None):
+        if self.nodes_n != J.size:
+            raise ValueError("Grid size does not match data")
+        return RegularGridInterpolator(tuple(self.x_level), self.get_grid_from_array(J), method, bounds_error,
+                                       fill_value)
+
+    def compute_bivariatespline_2D_interpolation_function(self, J, kx=1, ky=1):
+        if self.sys.n != 2:
+            raise NotImplementedError
+        if self.nodes_n != J.size:
+            raise ValueError("Grid size does not match data")
+        return RectBivariateSpline(self.x_level[0], self.x_level[1], self.get_grid_from_array(J),
+                                   bbox=[None, None, None, None], kx=kx, ky=ky)
+
+    def get_input_from_policy(self, pi, k):
+        if self.nodes_n != pi.size:
+            raise ValueError("Grid size does not match optimal action table size")
+        return self.input_from_action_id[np.asarray(pi, dtype=np.int64), k].astype(float)
+
+    def get_2D_slice_of_grid(self, Z, axis_1=0, axis_2=1):
+        if self.sys.n == 2:
+            return Z
+        idx = [int(i) for i in self.get_nearest_index_from_state(self.sys.xbar)]
+        idx[axis_1], idx[axis_2] = slice(None), slice(None)
+        out = np.asarray(Z[tuple(idx)], dtype=float)
+        return out if axis_1 < axis_2 else out.T
+
+    # ------------------------------------------------------------------ plots: host pass-through
+    def plot_grid_value(self, J, name="Value on the grid", x=0, y=1, jmax=np.inf, jmin=0):
+        import matplotlib.pyplot as plt
+        fig, ax = plt.subplots(figsize=self.figsize, dpi=self.dpi)
+        Z = self.get_2D_slice_of_grid(self.get_grid_from_array(J), x, y)
+        pcm = ax.pcolormesh(self.x_level[x], self.x_level[y], np.clip(Z, jmin, jmax).T, shading="gouraud")
+        ax.set_xlabel(self.sys.state_label[x] + " " + self.sys.state_units[x], fontsize=self.fontsize)
+        ax.set_ylabel(self.sys.state_label[y] + " " + self.sys.state_units[y], fontsize=self.fontsize)
+        ax.set_title(name, fontsize=self.fontsize)
+        fig.colorbar(pcm, ax=ax)
+        return fig, ax, pcm
+
+    def plot_control_input_from_policy(self, pi, k, i=0, j=1):
+        u = self.get_input_from_policy(pi, k)
+        return self.plot_grid_value(u, self.sys.input_label[k], i, j, self.sys.u_ub[k], self.sys.u_lb[k])
+
+
+def device_dynamics_of(sys):
+    """(dynamics_id, params) when `sys` can be evaluated in-kernel: it must say so itself
+    (device_dynamics()) AND keep the plain box validity tests the kernels implement."""
+    from pyro_amd.dynamic.system import ContinuousDynamicSystem as Base
+    fn = getattr(sys, "device_dynamics", None)
+    if fn is None or not isinstance(sys, Base):
+        return None
+    if type(sys).isavalidstate is not Base.isavalidstate or type(sys).isavalidinput is not Base.isavalidinput:
+        return None
+    return fn()
+
+
+def _box_isavalidinput():
+    from pyro_amd.dynamic.system import ContinuousDynamicSystem
+    return ContinuousDynamicSystem.isavalidinput

@@ -1,0 +1,281 @@
+"""
+Host mirror of pyro/planning/dynamicprogramming.py: DynamicProgramming (:115),
+DynamicProgrammingWithLookUpTable (:505), LookUpTableController (:27).  Same constructor
+arguments, attributes and method names; the Bellman backups run on the GPU through libpyrovi
+(include/pyrovi.h).  There is no CPU path: without the library / a HIP device the constructor
+raises.
+
+Two device tiers behind one API:
+  fused  : system with device_dynamics() + QuadraticCostFunction -> f, Euler, validity, cost,
+           interpolation and min/argmin in one kernel, no tables at all;
+  table  : any other sys / cf -> x_next_table and G are built on the host exactly like the
+           reference (Python loops over sys.f / cf.g), uploaded once; sweeps run on the GPU.
+
+Extra keyword arguments (not in the reference): dtype ('float64' default, 'float32'), device.
+J, pi, J_next are NumPy views of device state, fetched on access.
+"""
+import time
+
+import numpy as np
+
+from pyro_amd import _native
+from pyro_amd.control import controller
+from pyro_amd.planning.discretizer import device_dynamics_of
+
+
+class LookUpTableController(controller.StaticController):
+    """State feedback u = interp(pi)(x): per input axis a linear interpolant of the INPUT values
+    selected by pi, 0 outside the grid (dynamicprogramming.py:27-107)."""
+
+    def __init__(self, grid_sys, pi):
+        if grid_sys.nodes_n != pi.size:
+            raise ValueError("Grid size does not match optimal action table size")
+        super().__init__(1, grid_sys.sys.m, grid_sys.sys.n)
+        self.grid_sys, self.pi = grid_sys, pi
+        self.name = "Tabular Controller"
+        self.interpol_method = ["linear"] * self.m
+        self.compute_interpol_functions()
+
+    def compute_interpol_functions(self):
+        self.u_interpol = [
+            self.grid_sys.compute_interpolation_function(self.grid_sys.get_input_from_policy(self.pi, k),
+                                                         self.interpol_method[k], bounds_error=False, fill_value=0)
+            for k in range(self.m)]
+
+    def lookup_table_selection(self, x):
+        return np.array([float(np.ravel(self.u_interpol[k](x))[0]) for k in range(self.m)])
+
+    def c(self, y, r, t=0):
+        return self.lookup_table_selection(y)
+
+
+class DynamicProgramming:
+    """Value iteration on a grid (dynamicprogramming.py:115-500).
+
+    For box-only validity the reference's cell-by-cell base class and its look-up-table subclass
+    compute the same recursion; both map to the same fused kernel here."""
+
+    HISTORY_MAX_BYTES = 1 << 30     # save_time_history is dropped beyond this (J+pi per sweep)
+    BATCH = 256                     # sweeps enqueued per host round trip when no history is kept
+
+    def __init__(self, grid_sys, cost_function, final_time=0, dtype="float64", device=0):
+        self.grid_sys, self.sys = grid_sys, grid_sys.sys
+        self.cf, self.tf = cost_function, final_time
+        self.alpha = 1.0
+        self.interpol_method = "linear"
+        self.save_time_history = True
+        self.verbose = True
+        self.t, self.k = self.tf, 0
+        self.start_time = time.time()
+        self.dtype, self.device = np.dtype(dtype), device
+        self._make_engine()
+        self.evaluate_terminal_cost()
+        self.t_list, self.J_list, self.pi_list = [], [], []
+        if self._history_ok():
+            self.t_list, self.J_list, self.pi_list = [self.tf], [self.J], [self.pi]
+
+    # ------------------------------------------------------------------ device engine
+    def _make_engine(self):
+        dd = device_dynamics_of(self.sys)
+        cost = self.cf.device_cost() if hasattr(self.cf, "device_cost") else None
+        self.tier = "fused" if (dd is not None and cost is not None) else "table"
+        if self.tier == "fused":
+            self._p = self.grid_sys._device_problem(cost=cost, dtype=self.dtype, device=self.device)
+        else:
+            g, s = self.grid_sys, self.sys
+            self._p = _native.Problem(g.x_level, g.u_level, s.x_lb, s.x_ub, s.u_lb, s.u_ub, g.dt, dtype=self.dtype,
+                                      dynamics_id=_native.DYN_TABLE, cost=None, device=self.device)
+            self._p.set_tables(g.x_next_table, self._host_cost_table())
+        self._host = {}             # cached downloads: 'J', 'pi', 'J_next'
+        self._dirty = False         # host J newer than the device copy
+
+    def _host_cost_table(self):
+        """compute_cost_lookuptable for arbitrary cf.g (dynamicprogramming.py:517-553)."""
+        g = self.grid_sys
+        X, U = g.state_from_node_id, g.input_from_action_id
+        ok = g.action_isok & g.x_next_isok
+        G = np.full((g.nodes_n, g.actions_n), float(self.cf.INF))
+        for s, a in zip(*np.nonzero(ok)):
+            G[s, a] = self.cf.g(X[s], U[a], self.t) * g.dt
+        return G
+
+    # ------------------------------------------------------------------ J / pi live on the device
+    def _flush(self):
+        if self._dirty:
+            self._p.set_J(self._host["J"])
+            self._dirty = False
+
+    @property
+    def J(self):
+        if "J" not in self._host:
+            self._host["J"] = self._p.get_J()
+        return self._host["J"]
+
+    @J.setter
+    def J(self, value):
+        value = np.asarray(value, dtype=float)
+        if value.size != self.grid_sys.nodes_n:
+            raise ValueError("Grid size does not match data")
+        self._host["J"] = value
+        self._dirty = True
+
+    @property
+    def pi(self):
+        if "pi" not in self._host:
+            self._host["pi"] = self._p.get_pi()
+        return self._host["pi"]
+
+    @pi.setter
+    def pi(self, value):
+        self._host["pi"] = np.asarray(value).astype(int)
+
+    @property
+    def J_next(self):
+        if "J_next" not in self._host:
+            self._host["J_next"] = self._p.get_J(prev=True) if self.k > 0 else self.J
+        return self._host["J_next"]
+
+    @J_next.setter
+    def J_next(self, value):
+        self._host["J_next"] = np.asarray(value, dtype=float)
+
+    def _invalidate(self):
+        self._host.clear()
+        self._dirty = False
+
+    # ------------------------------------------------------------------ reference API
+    def evaluate_terminal_cost(self):
+        """J = cf.h(x, tf), pi = 0 (dynamicprogramming.py:159-171)."""
+        if self.tier == "fused":
+            self._p.terminal_cost()
+            self._invalidate()
+        else:
+            X = self.grid_sys.state_from_node_id
+            self.J = np.array([self.cf.h(X[s], self.tf) for s in range(self.grid_sys.nodes_n)], dtype=float)
+            self._flush()
+
+    def _history_ok(self):
+        if not self.save_time_history:
+            return False
+        per_sweep = self.grid_sys.nodes_n * 16
+        if per_sweep * (len(self.J_list) + 1) > self.HISTORY_MAX_BYTES:
+            if self.verbose:
+                print("save_time_history dropped: history would exceed %d bytes" % self.HISTORY_MAX_BYTES)
+            self.save_time_history = False
+            return False
+        return True
+
+    def _run(self, max_sweeps, tol):
+        """Enqueue up to max_sweeps backups (stop on delta <= tol when tol >= 0); returns delta."""
+        self._flush()
+        delta, done = None, 0
+        while done < max_sweeps:
+            nb = 1 if self._history_ok() else min(self.BATCH, max_sweeps - done)
+            stats, n = self._p.sweep(nb, self.alpha, tol)
+            self._invalidate()
+            for i in range(n):
+                self.k += 1
+                self.t -= self.grid_sys.dt
+                delta = self._report(stats[i])
+            done += n
+            if self.save_time_history and n:
+                self.J_list.append(self.J)
+                self.t_list.append(self.t)
+                self.pi_list.append(self.pi)
+            if n < nb or (tol >= 0 and delta is not None and delta <= tol):
+                break
+        return delta
+
+    def _report(self, st):
+        """finalize_backward_step (dynamicprogramming.py:240-261): print and return delta."""
+        if self.verbose:
+            print("%d t:%.2f Elasped:%.2f max: %.2f dmax:%.2f dmin:%.2f"
+                  % (self.k, self.t, time.time() - self.start_time, st[0], st[1], st[2]))
+        return float(st[3])
+
+    # the three-step form of one backup, kept for scripts that drive it by hand (:175-261)
+    def initialize_backward_step(self):
+        self._pending = True
+
+    def compute_backward_step(self):
+        self._flush()
+        self._last_stats, n = self._p.sweep(1, self.alpha, -1.0)
+        self._invalidate()
+        self.k += 1
+        self.t -= self.grid_sys.dt
+
+    def finalize_backward_step(self):
+        delta = self._report(self._last_stats[0])
+        if self._history_ok():
+            self.J_list.append(self.J)
+            self.t_list.append(self.t)
+            self.pi_list.append(self.pi)
+        return delta
+
+    def compute_steps(self, n=50, animate_cost2go=False, animate_policy=False, k=0):
+        print("\nComputing %d backward DP iterations:" % n)
+        print("-----------------------------------------")
+        self._run(n, -1.0)
+
+    def solve_bellman_equation(self, tol=0.1, animate_cost2go=False, animate_policy=False, k=0):
+        """Backups until max|J - J_next| <= tol (dynamicprogramming.py:283-314); delta starts at
+        cf.INF, so tol >= INF performs no sweep."""
+        print("\nComputing backward DP iterations until dJ<%2.2f:" % tol)
+        print("---------------------------------------------------------")
+        delta = self.cf.INF
+        while delta > tol:
+            delta = self._run(1 << 30, tol)
+        print("\nBellman equation solved!")
+
+    def clean_infeasible_set(self, tol=1):
+        """J > INF - tol  ->  J = INF, pi = action nearest to sys.ubar (:322-334)."""
+        default_action = self.grid_sys.get_nearest_action_id_from_input(self.sys.ubar)
+        J, pi = self.J.copy(), self.pi.copy()
+        bad = J > (self.cf.INF - tol)
+        J[bad] = self.cf.INF
+        pi[bad] = default_action
+        self.J, self.pi = J, pi
+
+    def get_lookup_table_controller(self):
+        return LookUpTableController(self.grid_sys, self.pi)
+
+    def save_latest(self, name="test_data"):
+        """Writes J_next (not J), as the reference does (:481-485)."""
+        np.save(name + "_J_inf", self.J_next)
+        np.save(name + "_pi_inf", self.pi.astype(int))
+
+    def load_J_next(self, name="test_data"):
+        try:
+            self.J_next = np.load(name + "_J_inf" + ".npy")
+        except Exception:
+            print("Failed to load J_next ")
+
+    # ------------------------------------------------------------------ plots: host pass-through
+    def plot_cost2go(self, jmax=None, i=0, j=1, show=True):
+        jmax = self.cf.INF if jmax is None else jmax
+        fig, ax, pcm = self.grid_sys.plot_grid_value(self.J, "Cost-to-go", i, j, jmax, 0)
+        self.cost2go_fig = [fig, ax, pcm, ax.text(0.05, 0.05, "", transform=ax.transAxes, fontsize=8), i, j]
+
+    def plot_policy(self, k=0, i=0, j=1, show=True):
+        fig, ax, pcm = self.grid_sys.plot_control_input_from_policy(self.pi, k, i, j)
+        self.policy_fig = [fig, ax, pcm, ax.text(0.05, 0.05, "", transform=ax.transAxes, fontsize=8), k, i, j]
+
+
+class DynamicProgrammingWithLookUpTable(DynamicProgramming):
+    """dynamicprogramming.py:505-570.  `G` is available as an attribute (built on the GPU for the
+    fused tier) but the fused sweep never materialises it."""
+
+    @property
+    def G(self):
+        if "_G" not in self.__dict__:
+            self.compute_cost_lookuptable()
+        return self.__dict__["_G"]
+
+    def compute_cost_lookuptable(self):
+        t0 = time.time()
+        print("Computing g(x,u,t) look-up table..  ", end="")
+        if self.tier == "fused":
+            self.__dict__["_G"] = self._p.build_tables(x_next=False, x_next_isok=False, action_isok=False)[3]
+        else:
+            self.__dict__["_G"] = self._host_cost_table()
+        print("completed in %4.2f sec" % (time.time() - t0))

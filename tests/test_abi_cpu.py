@@ -1,0 +1,145 @@
+"""CPU checks of the boundary: the shared library loads and exports every symbol include/pyrovi.h
+declares; the host classes behave like the reference where no GPU is needed."""
+import contextlib
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from pyro_amd import _build, _native
+    _build.build()
+    L = _native.lib()
+    header = open(os.path.join(ROOT, "include", "pyrovi.h")).read()
+    declared = set(re.findall(r"\b(pvi_[a-z_0-9A-Z]+)\s*\(", header))
+    assert declared, "no declarations found"
+    for name in declared:
+        assert hasattr(L, name), "libpyrovi.so does not export %s" % name
+    assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
+    assert L.pvi_abi_version() == 1
+
+
+def test_descriptor_layout_matches_header():
+    """ctypes struct vs the C struct: compile a tiny probe with gcc and compare sizeof/offsets."""
+    import ctypes
+    import subprocess
+    import tempfile
+    from pyro_amd import _native
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "pyrovi.h"
+int main(void){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(pvi_desc), offsetof(pvi_desc,x_level),
+  offsetof(pvi_desc,dyn_params), offsetof(pvi_desc,Q), offsetof(pvi_desc,row_begin), offsetof(pvi_desc,ext_J)); return 0; }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "probe.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "probe")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
+    D = _native.pvi_desc
+    mine = [ctypes.sizeof(D), D.x_level.offset, D.dyn_params.offset, D.Q.offset, D.row_begin.offset, D.ext_J.offset]
+    assert [int(v) for v in out] == mine
+
+
+def test_no_cpu_fallback_without_device():
+    """Creating a problem without a HIP device must fail loudly (no silent CPU path)."""
+    from pyro_amd import _native
+    try:
+        n = _native.device_count()
+    except _native.NativeError:
+        n = 0
+    if n > 0:
+        pytest.skip("a GPU is present")
+    lv = [np.linspace(-1, 1, 5), np.linspace(-1, 1, 5)]
+    with pytest.raises(RuntimeError):
+        _native.Problem(lv, [np.linspace(-1, 1, 3)], [-1, -1], [1, 1], [-1], [1], 0.1)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "pyro_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+@pytest.mark.parametrize("n,m", [(2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2)])
+def test_grid_matches_reference_golden(n, m):
+    from pyro_amd.dynamic import system
+    from pyro_amd.planning import discretizer
+    g = np.load(os.path.join(GOLDEN, "grid_kat.npz"))
+    k = "n%dm%d_" % (n, m)
+    b = g[k + "bounds"]
+    s = system.ContinuousDynamicSystem(n, m, n)
+    s.x_lb, s.x_ub = b[:n], b[n:2 * n]
+    s.u_lb, s.u_ub = b[2 * n:2 * n + m], b[2 * n + m:]
+    with contextlib.redirect_stdout(io.StringIO()):
+        grid = discretizer.GridDynamicSystem(s, list(g[k + "dims"]), list(g[k + "udims"]), dt=0.1, lookup=False)
+    for d in range(n):
+        assert np.array_equal(grid.x_level[d], g[k + "x_level%d" % d])
+    for name in ("state_from_node_id", "index_from_node_id", "node_id_from_index", "input_from_action_id",
+                 "index_from_action_id", "action_id_from_index", "x_step_size", "u_step_size"):
+        assert np.array_equal(getattr(grid, name), g[k + name]), name
+    P, PU = g[k + "probe_x"], g[k + "probe_u"]
+    assert np.array_equal(np.array([grid.get_index_from_state(x) for x in P]), g[k + "probe_index"])
+    assert np.array_equal(np.array([grid.get_nearest_index_from_state(x) for x in P]), g[k + "probe_nearest"])
+    assert np.array_equal(np.array([grid.get_nearest_node_id_from_state(x) for x in P]), g[k + "probe_node"])
+    assert np.array_equal(np.array([grid.get_nearest_action_id_from_input(u) for u in PU]), g[k + "probe_action"])
+    assert grid.nodes_n == int(np.prod(g[k + "dims"])) and grid.actions_n == int(np.prod(g[k + "udims"]))
+
+
+def test_grid_rejects_unsupported_dimensions():
+    from pyro_amd.dynamic import system
+    from pyro_amd.planning import discretizer
+    with contextlib.redirect_stdout(io.StringIO()):
+        with pytest.raises(NotImplementedError):
+            discretizer.GridDynamicSystem(system.ContinuousDynamicSystem(5, 1, 5), [3] * 5, [3])
+        with pytest.raises(NotImplementedError):
+            discretizer.GridDynamicSystem(system.ContinuousDynamicSystem(2, 3, 2), [3, 3], [3, 3, 3])
+        g = discretizer.GridDynamicSystem(system.ContinuousDynamicSystem(2, 1, 2), [4, 5], [3])
+        with pytest.raises(ValueError):
+            g.compute_interpolation_function(np.zeros(7))
+        with pytest.raises(ValueError):
+            g.get_input_from_policy(np.zeros(7, dtype=int), 0)
+
+
+@pytest.mark.parametrize("key,mod,cls", [
+    ("pendulum", "pendulum", "SinglePendulum"), ("inverted", "pendulum", "InvertedPendulum"),
+    ("cartpole", "cartpole", "CartPole"), ("twolink", "manipulator", "TwoLinkManipulator"),
+    ("doublependulum", "pendulum", "DoublePendulum")])
+def test_host_dynamics_match_reference_kat(key, mod, cls):
+    import importlib
+    g = np.load(os.path.join(GOLDEN, "f_kat.npz"))
+    s = getattr(importlib.import_module("pyro_amd.dynamic." + mod), cls)()
+    b = g[key + "_bounds"]
+    assert np.array_equal(np.concatenate([s.x_lb, s.x_ub, s.u_lb, s.u_ub]), b)
+    X, U, ref = g[key + "_X"], g[key + "_U"], g[key + "_dX"]
+    dX = np.array([s.f(X[i], U[i]) for i in range(len(X))])
+    assert (np.abs(dX - ref) / np.maximum(1, np.abs(ref))).max() < 1e-12
+    assert s.isavalidstate(s.x_ub) and not s.isavalidstate(s.x_ub * 1.0001)
+    assert s.isavalidinput(s.xbar, s.u_lb) and not s.isavalidinput(s.xbar, s.u_ub + 1e-9)
+
+
+def test_host_costs_match_reference_kat():
+    from pyro_amd.analysis import costfunction
+    g = np.load(os.path.join(GOLDEN, "cost_kat.npz"))
+    q = costfunction.QuadraticCostFunction(4, 2)
+    q.Q, q.R, q.S, q.xbar, q.ubar, q.EPS = g["Q"], g["R"], g["S"], g["xbar"], g["ubar"], float(g["EPS"])
+    X, U = g["X"], g["U"]
+    np.testing.assert_allclose([q.g(X[i], U[i], 0) for i in range(48)], g["g"], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose([q.h(X[i], 0) for i in range(48)], g["h"], rtol=1e-13, atol=1e-13)
+    t = costfunction.TimeCostFunction(g["xbar"].copy())
+    t.EPS = 0.25
+    assert np.array_equal([t.g(X[i], U[i], 0) for i in range(48)], g["time_g"])
+    r = costfunction.Reachability(lambda x: bool(np.all(np.abs(x) < 1.5)), xbar=g["xbar"].copy())
+    assert np.array_equal([r.g(X[i], U[i], 0) for i in range(48)], g["reach_g"])
+    assert np.array_equal([r.h(X[i], 0) for i in range(48)], g["reach_h"])
+    assert q.INF == 1e3 and r.INF == float(g["reach_INF"]) and r.EPS == float(g["reach_EPS"])

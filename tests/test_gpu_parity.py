@@ -1,0 +1,344 @@
+"""
+GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI
+(pyro_amd._native -> libpyrovi.so); the oracle and the golden fixtures are only the checkers.
+
+Tolerances
+  float64 path: the kernels mirror the oracle operation for operation (same trig tables, no
+      implicit FMA), so J is compared at 1e-12 relative and is normally bit-identical; pi exact.
+  float32 path: max|J_gpu - J_ref| / max|J_ref| <= 1e-5 (BASELINE.json north_star), pi judged
+      by Q-regret because f32 rounding legitimately flips near-ties.
+"""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import vi_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TWOLINK = dict(l1=0.5, lc1=0.2, lc2=0.1, m1=1, I1=0, m2=1, I2=0, gravity=9.81, d1=0.5, d2=0.5)
+DOUBLEP = dict(l1=1, lc1=1, lc2=1, m1=1, I1=0, m2=1, I2=0, gravity=9.81, d1=0, d2=0)
+REL_F32 = 1e-5
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def oracle_problem(g, dyn, consts):
+    lv = O.make_levels(g["x_lb"], g["x_ub"], g["dims"])
+    ul = O.make_levels(g["u_lb"], g["u_ub"], g["udims"])
+    return O.Problem(lv, ul, float(g["dt"]), dyn, consts, g["Q"], g["R"], g["S"], g["xbar"], g["ubar"],
+                     float(g["INF"]), float(g["EPS"]))
+
+
+def trig_for(p):
+    t = p.trig_tables()
+    if p.dyn_id == O.DYN_PENDULUM:
+        return (t["s0"],)
+    if p.dyn_id == O.DYN_CARTPOLE:
+        return (t["c1"], t["s1"])
+    return (t["s0"], t["c1"], t["s1"], t["s01"])
+
+
+def native_problem(p, dtype="float64", **kw):
+    from pyro_amd import _native
+    cost = dict(Q=p.Q, R=p.R, S=p.S, xbar=p.xbar, ubar=p.ubar, EPS=p.EPS, INF=p.INF, ontarget_check=p.ontarget_check)
+    return _native.Problem(p.levels, p.u_levels, p.x_lb, p.x_ub, p.u_lb, p.u_ub, p.dt, dtype=dtype,
+                           dynamics_id=p.dyn_id, dyn_params=list(p.dyn_c), trig=trig_for(p), cost=cost, **kw)
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+CASES = {
+    "pendulum_21x21x5": (O.DYN_PENDULUM, O.pendulum_consts()),
+    "pendulum_demo_51x51x9": (O.DYN_PENDULUM, O.pendulum_consts()),
+    "pendulum_lowdef_41x21x3": (O.DYN_PENDULUM, O.pendulum_consts()),
+    "cartpole_11p4x5": (O.DYN_CARTPOLE, O.cartpole_consts()),
+    "twolink_11p4x3x3": (O.DYN_TWOLINK, O.twolink_consts(**TWOLINK)),
+    "twolink_11p4x3x3_dt01": (O.DYN_TWOLINK, O.twolink_consts(**TWOLINK)),
+    "doublependulum_13x11x13x11x3x3": (O.DYN_TWOLINK, O.twolink_consts(**DOUBLEP)),
+}
+
+
+# ------------------------------------------------------------------------------------------------ f
+@pytest.mark.parametrize("key,dyn,consts", [
+    ("pendulum", O.DYN_PENDULUM, O.pendulum_consts()),
+    ("inverted", O.DYN_PENDULUM, O.pendulum_consts(inverted=True)),
+    ("cartpole", O.DYN_CARTPOLE, O.cartpole_consts()),
+    ("twolink", O.DYN_TWOLINK, O.twolink_consts(**TWOLINK)),
+    ("doublependulum", O.DYN_TWOLINK, O.twolink_consts(**DOUBLEP)),
+])
+def test_eval_f_matches_reference_kat(key, dyn, consts):
+    from pyro_amd import _native
+    g = load("f_kat")
+    dX = _native.eval_f(dyn, consts, g[key + "_X"], g[key + "_U"])
+    ref = g[key + "_dX"]
+    assert (np.abs(dX - ref) / np.maximum(1.0, np.abs(ref))).max() < 1e-11   # device sin/cos: ~1 ulp
+
+
+# ------------------------------------------------------------------------------------- tables (a3/a4/a8)
+@pytest.mark.parametrize("name", list(CASES))
+def test_tables_match_oracle_bitwise(name):
+    g = load(name)
+    p = oracle_problem(g, *CASES[name])
+    h = native_problem(p)
+    xn, xok, aok, G = h.build_tables()
+    oxn, oxok, oaok, oG = O.cells(p, np.arange(p.nodes_n))
+    assert np.array_equal(xn, oxn)
+    assert np.array_equal(xok, oxok) and np.array_equal(aok, oaok)
+    assert np.array_equal(G, oG)
+    h.close()
+
+
+def test_tables_match_reference_golden():
+    g = load("pendulum_21x21x5")
+    p = oracle_problem(g, *CASES["pendulum_21x21x5"])
+    h = native_problem(p)
+    xn, xok, aok, G = h.build_tables()
+    assert np.array_equal(xn, g["x_next_table"])
+    assert np.array_equal(xok, g["x_next_isok"]) and np.array_equal(aok, g["action_isok"])
+    np.testing.assert_allclose(G, g["G"], rtol=1e-14, atol=1e-14)
+    h.close()
+
+
+# ------------------------------------------------------------------------------------- sweeps, float64
+@pytest.mark.parametrize("name", list(CASES))
+def test_sweeps_f64_match_oracle(name):
+    g = load(name)
+    p = oracle_problem(g, *CASES[name])
+    alpha = float(g["alpha"]) if "alpha" in g.files else 1.0
+    nsw = min(int(g["sweeps"]), 10) if "sweeps" in g.files else 10
+    h = native_problem(p)
+    h.terminal_cost()
+    J = O.terminal_cost(p)
+    assert np.array_equal(h.get_J(), J)
+    for k in range(nsw):
+        Jn, pi = O.sweep(p, J, alpha)
+        st, delta = O.sweep_stats(Jn, J)
+        stats, n = h.sweep(1, alpha, -1.0)
+        assert n == 1
+        Jg, pig = h.get_J(), h.get_pi()
+        assert relerr(Jg, Jn) < 1e-12, "sweep %d" % (k + 1)
+        bad = pig != pi
+        if bad.any():
+            assert O.q_regret(p, J, pig, alpha)[bad].max() < 1e-9
+        np.testing.assert_allclose(stats[0], list(st) + [delta], rtol=1e-12, atol=1e-12)
+        assert np.array_equal(h.get_J(prev=True), J) or relerr(h.get_J(prev=True), J) < 1e-12
+        J = Jg            # continue from the device state (keeps the comparison one-step)
+    h.close()
+
+
+def test_config1_solve_f64_matches_reference():
+    """BASELINE configs[0]: 101x101x11 pendulum to tol 0.1 -> 618 sweeps, J* and pi* of the reference."""
+    g = load("config1_pendulum_101x101x11")
+    p = oracle_problem(g, O.DYN_PENDULUM, O.pendulum_consts())
+    h = native_problem(p)
+    h.terminal_cost()
+    stats, n = h.sweep(5000, 1.0, 0.1)
+    assert n == int(g["sweeps"]) == 618
+    J, pi = h.get_J(), h.get_pi()
+    assert relerr(J, g["J"]) < 1e-12
+    bad = pi != g["pi"]
+    assert bad.mean() < 1e-3
+    if bad.any():
+        assert O.q_regret(p, g["J_prev"], pi)[bad].max() < 1e-9
+    assert stats[-1, 3] <= 0.1 < stats[-2, 3]
+    h.close()
+
+
+# ------------------------------------------------------------------------------------- sweeps, float32
+def test_config1_solve_f32_within_tolerance():
+    g = load("config1_pendulum_101x101x11")
+    p = oracle_problem(g, O.DYN_PENDULUM, O.pendulum_consts())
+    h = native_problem(p, dtype="float32")
+    h.terminal_cost()
+    stats, n = h.sweep(5000, 1.0, 0.1)
+    assert abs(n - 618) <= 2
+    J, pi = h.get_J(), h.get_pi()
+    assert relerr(J, g["J"]) <= REL_F32
+    reg = O.q_regret(p, g["J_prev"], pi)
+    assert reg.max() <= 1e-3 * np.abs(g["J"]).max()
+    h.close()
+
+
+def test_cartpole_21p4_f32_golden():
+    """Cart-pole 21^4 x 7, 20 sweeps against the reference's own J (stored as f32)."""
+    g = load("cartpole_21p4x7")
+    p = oracle_problem(g, O.DYN_CARTPOLE, O.cartpole_consts())
+    for dtype, tol in (("float64", 1e-6), ("float32", REL_F32)):
+        h = native_problem(p, dtype=dtype)
+        h.terminal_cost()
+        stats, n = h.sweep(int(g["sweeps"]), 1.0, -1.0)
+        assert n == 20
+        J, pi = h.get_J(), h.get_pi()
+        assert relerr(J, g["J"].astype(np.float64)) <= tol
+        bad = pi != g["pi"]
+        assert bad.mean() < (1e-4 if dtype == "float64" else 2e-2)
+        h.close()
+
+
+@pytest.mark.parametrize("name", ["cartpole_11p4x5", "twolink_11p4x3x3", "doublependulum_13x11x13x11x3x3"])
+def test_4d_f32_within_tolerance(name):
+    g = load(name)
+    p = oracle_problem(g, *CASES[name])
+    alpha = float(g["alpha"])
+    h = native_problem(p, dtype="float32")
+    h.terminal_cost()
+    h.sweep(int(g["sweeps"]), alpha, -1.0)
+    assert relerr(h.get_J(), g["J"]) <= REL_F32
+    h.close()
+
+
+# ------------------------------------------------------------------------------------- tier B (tables)
+def test_table_tier_on_reference_tables():
+    """dynamicprogramming.py:564-570 on the reference's own x_next_table / G."""
+    from pyro_amd import _native
+    g = load("pendulum_21x21x5")
+    lv = O.make_levels(g["x_lb"], g["x_ub"], g["dims"])
+    ul = O.make_levels(g["u_lb"], g["u_ub"], g["udims"])
+    h = _native.Problem(lv, ul, g["x_lb"], g["x_ub"], g["u_lb"], g["u_ub"], float(g["dt"]),
+                        dynamics_id=_native.DYN_TABLE)
+    h.set_tables(g["x_next_table"], g["G"])
+    h.set_J(g["J0"])
+    for k in range(1, 11):
+        h.sweep(1, 1.0, -1.0)
+        if k in (1, 2, 10):
+            assert relerr(h.get_J(), g["J_%d" % k]) < 1e-14
+            assert np.array_equal(h.get_pi(), g["pi_%d" % k])
+    h.close()
+
+
+# ------------------------------------------------------------------------------------- slabs (multi-GPU building block)
+@pytest.mark.parametrize("name,dtype", [("pendulum_demo_51x51x9", "float64"), ("cartpole_11p4x5", "float32")])
+def test_slab_sweeps_equal_whole_grid(name, dtype):
+    """Two handles owning disjoint row slabs (+halo) reproduce the whole-grid sweep bit for bit."""
+    g = load(name)
+    p = oracle_problem(g, *CASES[name])
+    whole = native_problem(p, dtype=dtype)
+    whole.terminal_cost()
+    N0 = p.dims[0]
+    mid, halo = N0 // 2, 6
+    slabs = [native_problem(p, dtype=dtype, rows=(0, mid), halo=(0, halo)),
+             native_problem(p, dtype=dtype, rows=(mid, N0), halo=(halo, 0))]
+    for s in slabs:
+        s.terminal_cost()
+    for _ in range(4):
+        whole.sweep(1, 1.0, -1.0)
+        Jw = whole.get_J()
+        for s in slabs:
+            s.sweep_async(1.0)
+            s.sweep_stats()
+        parts = [s.get_J() for s in slabs]
+        assert np.array_equal(np.concatenate(parts), Jw)
+        # "halo exchange" through the host: every slab receives the rows it stores but does not own
+        full = np.concatenate(parts).reshape(N0, -1)
+        for s in slabs:
+            r0, r1 = s.store_rows
+            s.set_J(full[r0:r1].ravel(), r0, r1 - r0)
+        assert np.array_equal(np.concatenate([s.get_pi() for s in slabs]), whole.get_pi())
+    for s in slabs + [whole]:
+        s.close()
+
+
+def test_halo_too_small_is_reported():
+    from pyro_amd import _native
+    g = load("pendulum_demo_51x51x9")
+    p = oracle_problem(g, *CASES["pendulum_demo_51x51x9"])
+    s = native_problem(p, rows=(0, 25), halo=(0, 0))
+    s.terminal_cost()
+    s.sweep_async(1.0)
+    with pytest.raises(_native.NativeError) as e:
+        s.sweep_stats()
+    assert e.value.code == _native.PVI_EHALO
+    s.close()
+
+
+# ------------------------------------------------------------------------------------- class surface
+def test_class_surface_config1():
+    """The drop-in classes, driven like examples/demos_by_tool/lqr_vs_valueiteration_for_a_simple_pendulum.py."""
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import pendulum
+    from pyro_amd.planning import discretizer, dynamicprogramming
+    g = load("config1_pendulum_101x101x11")
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        sys_ = pendulum.SinglePendulum()
+        sys_.xbar = np.array([-3.14, 0])
+        qcf = costfunction.QuadraticCostFunction.from_sys(sys_)
+        qcf.INF = 300
+        grid_sys = discretizer.GridDynamicSystem(sys_, [101, 101], [11])
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(grid_sys, qcf)
+        dp.save_time_history = False
+        dp.solve_bellman_equation()
+    assert dp.k == 618
+    assert "618 t:-30.90" in buf.getvalue()
+    assert relerr(dp.J, g["J"]) < 1e-12
+    assert (dp.pi != g["pi"]).mean() < 1e-3
+    assert relerr(dp.J_next, g["J_prev"]) < 1e-12
+    assert dp.J.dtype == np.float64 and dp.pi.dtype == np.int64
+
+
+def test_class_surface_small_with_history_and_controller():
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import pendulum
+    from pyro_amd.planning import discretizer, dynamicprogramming
+    g = load("pendulum_21x21x5")
+    with contextlib.redirect_stdout(io.StringIO()):
+        sys_ = pendulum.SinglePendulum()
+        grid_sys = discretizer.GridDynamicSystem(sys_, [21, 21], [5])
+        qcf = costfunction.QuadraticCostFunction.from_sys(sys_)
+        qcf.xbar = np.array([-3.14, 0.0])
+        qcf.INF = 300
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(grid_sys, qcf)
+        assert np.array_equal(grid_sys.x_next_table, g["x_next_table"])
+        assert np.array_equal(grid_sys.x_next_isok, g["x_next_isok"])
+        assert np.array_equal(grid_sys.action_isok, g["action_isok"])
+        np.testing.assert_allclose(dp.G, g["G"], rtol=1e-14, atol=1e-14)
+        dp.compute_steps(10)
+        assert len(dp.J_list) == 11 and len(dp.pi_list) == 11
+        np.testing.assert_allclose(dp.J_list[1], g["J_1"], rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(dp.J, g["J_10"], rtol=1e-13, atol=1e-13)
+        assert np.array_equal(dp.pi, g["pi_10"])
+        dp.clean_infeasible_set()
+        np.testing.assert_allclose(dp.J, g["J_clean"], rtol=1e-13)
+        assert np.array_equal(dp.pi, g["pi_clean"])
+        ctl = dp.get_lookup_table_controller()
+        u = np.array([ctl.c(x, 0) for x in g["ctl_x"]])
+    np.testing.assert_allclose(u, g["ctl_u"], rtol=1e-12, atol=1e-12)
+
+
+def test_class_surface_generic_system_uses_table_tier():
+    """A system the kernels do not know (plain Python f) still runs: tables on the host like the
+    reference, sweeps on the GPU."""
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import system
+    from pyro_amd.planning import discretizer, dynamicprogramming
+
+    class Integrator(system.ContinuousDynamicSystem):
+        def __init__(self):
+            super().__init__(2, 1, 2)
+            self.name = "Double integrator"
+            self.x_ub, self.x_lb = np.array([2.0, 2.0]), np.array([-2.0, -2.0])
+
+        def f(self, x, u, t=0):
+            return np.array([x[1], u[0]])
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = Integrator()
+        grid = discretizer.GridDynamicSystem(s, [21, 21], [3], dt=0.1)
+        cf = costfunction.QuadraticCostFunction.from_sys(s)
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(grid, cf)
+        assert dp.tier == "table"
+        dp.compute_steps(5)
+    J = np.array([cf.h(x, 0) for x in grid.state_from_node_id], dtype=float)
+    for _ in range(5):
+        J, pi, _ = O.sweep_lut(grid.x_level, grid.x_next_table, dp.G, J)
+    assert relerr(dp.J, J) < 1e-13
+    assert np.array_equal(dp.pi, pi)
