@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""
+bench.py -- value-iteration sweep throughput on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c2p|c3|c4|c5|...]
+
+A "step" is one VI sweep (one Bellman backup of every state-action cell of the grid); J is
+resident in HBM before the timed region.  W untimed sweeps, then exactly K timed sweeps bracketed
+by a device synchronisation (plus a barrier and max over ranks for N > 1).  Rank 0 prints ONE JSON
+line: metric = state-action cell updates per second (whole job), plus sweeps/s, the roofline of the
+sweep kernel (algorithmic bytes / HIP-event kernel time) and -- at N = 1 -- a CPU baseline (the
+oracle's C/OpenMP twin timed on this box's host cores on a bounded sample) and the relative error
+of J against it.
+
+Default workload: BASELINE.json configs[1] (pendulum 1001x1001x51, f32) at N = 1; cart-pole
+101^4 x 21 (configs[2]), axis-0 slabs with a halo exchange over RCCL, at N > 1 (DESIGN.md
+"bench workloads" explains why the 2-D grid is not sharded).
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+VALU_PEAK_F32_TFLOPS = 157.3
+
+
+def oracle_problem(cfg):
+    """Oracle-side description of the same workload (checker / CPU baseline only)."""
+    from oracle import vi_oracle as O
+    s, g, cf = cfg["sys"], cfg["grid_sys"], cfg["cf"]
+    dyn_id, params = s.device_dynamics()
+    return O.Problem(g.x_level, g.u_level, g.dt, dyn_id, np.array(params), cf.Q, cf.R, cf.S, cf.xbar, cf.ubar,
+                     float(cf.INF), float(cf.EPS), x_lb=s.x_lb, x_ub=s.x_ub, u_lb=s.u_lb, u_ub=s.u_ub)
+
+
+def cpu_baseline(cfg, budget_s=20.0):
+    """Oracle C/OpenMP twin on the host cores, bounded sample: whole sweeps while they fit the
+    budget, otherwise a leading slice of nodes of one sweep."""
+    from oracle import c_oracle as CO
+    p = oracle_problem(cfg)
+    c = CO.CProblem(p)
+    cores = CO.max_threads()
+    J = c.terminal_cost()
+    cells_per_sweep = p.nodes_n * p.actions_n
+    # calibrate on a slice
+    n_probe = max(1, min(p.nodes_n, 200000 // max(1, p.actions_n // 8)))
+    t0 = time.perf_counter()
+    c.sweep(J, 1.0, 0, n_probe)
+    rate = n_probe * p.actions_n / max(time.perf_counter() - t0, 1e-9)
+    sweep_s = cells_per_sweep / rate
+    if sweep_s <= budget_s / 2:
+        nsweeps = int(max(1, min(10, budget_s // sweep_s)))
+        t0 = time.perf_counter()
+        for _ in range(nsweeps):
+            J, _ = c.sweep(J, 1.0)
+        dt = time.perf_counter() - t0
+        return dict(value=nsweeps * cells_per_sweep / dt, unit="cells/s", cores=cores, kind="port",
+                    sample="%d full sweeps of the workload in %.1f s (oracle/vi_oracle.c, OpenMP)" % (nsweeps, dt),
+                    sweeps_per_sec=nsweeps / dt), J, nsweeps
+    nodes = int(min(p.nodes_n, rate * budget_s / p.actions_n))
+    t0 = time.perf_counter()
+    c.sweep(J, 1.0, 0, nodes)
+    dt = time.perf_counter() - t0
+    v = nodes * p.actions_n / dt
+    return dict(value=v, unit="cells/s", cores=cores, kind="port",
+                sample="first %d of %d nodes of one sweep in %.1f s (oracle/vi_oracle.c, OpenMP)" % (nodes, p.nodes_n, dt),
+                sweeps_per_sec=v / cells_per_sweep), None, 0
+
+
+def load_traffic(workload):
+    """HBM bytes per sweep-kernel launch from the committed rocprofv3 PMC passes (profiles/)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(path)).get(workload, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def run_single(args):
+    from pyro_amd import configs
+    from pyro_amd.planning import dynamicprogramming
+    cfg = configs.build(args.workload)
+    g = cfg["grid_sys"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, cfg["cf"], dtype=cfg["dtype"])
+    dp.save_time_history = False
+    dp.verbose = False
+    p = dp._p
+    N, A = g.nodes_n, g.actions_n
+    w = 4 if cfg["dtype"] == "float32" else 8
+    pbytes = 1 if A <= 256 else 2
+
+    # accuracy + CPU baseline first (J0 -> n sweeps on both sides)
+    cpu, J_cpu, n_cmp = (None, None, 0)
+    if not args.no_cpu:
+        cpu, J_cpu, n_cmp = cpu_baseline(cfg, args.cpu_budget)
+    rel_err = None
+    if J_cpu is not None:
+        p.sweep(n_cmp, 1.0, -1.0)
+        Jg = p.get_J()
+        rel_err = float(np.abs(Jg - J_cpu).max() / np.abs(J_cpu).max())
+        p.terminal_cost()
+
+    p.sweep(args.warmup, 1.0, -1.0)
+    p.synchronize()
+    t0 = time.perf_counter()
+    stats, done = p.sweep(args.steps, 1.0, -1.0)
+    p.synchronize()
+    dt = time.perf_counter() - t0
+    assert done == args.steps
+    kern_ms = p.last_sweep_ms() / args.steps           # HIP events on the kernel's stream
+
+    alg_bytes = N * (2 * w + pbytes)
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    flops_cell = {2: 30, 4: 90}[g.sys.n] if g.sys.m == 1 else 120
+    out = {
+        "metric": "vi_state_action_cell_updates_per_sec", "value": N * A * args.steps / dt, "unit": "cells/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32" if w == 4 else "f64", "data": "synthetic",
+        "config": {"workload": "%s: %s" % (cfg["name"], cfg["description"]), "nodes": N, "actions": A,
+                   "cells_per_sweep": N * A, "dt": g.dt, "alpha": 1.0, "parallelism": "1 GPU"},
+        "sweeps_per_sec": args.steps / dt,
+        "jstar_rel_err_vs_cpu": rel_err, "jstar_rel_err_after_sweeps": n_cmp,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(cfg["name"]),
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
+                     "note": "VALU-bound stencil/gather: see valu_frac"},
+        "valu_frac": (N * A / (kern_ms * 1e-3)) * flops_cell / (VALU_PEAK_F32_TFLOPS * 1e12),
+        "last_stats": [float(v) for v in stats[-1]],
+    }
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+        out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
+    print(json.dumps(out))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default=None)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from pyro_amd import parallel_bench
+        return parallel_bench.run(args)
+    args.workload = args.workload or "c2"
+    big = args.workload in ("c3", "c4", "c5")
+    args.steps = args.steps if args.steps is not None else (20 if big else 200)
+    args.warmup = args.warmup if args.warmup is not None else (2 if big else 20)
+    run_single(args)
+
+
+if __name__ == "__main__":
+    main()

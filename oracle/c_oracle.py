@@ -1,0 +1,89 @@
+"""ctypes front end of oracle/vi_oracle.c (test infrastructure; see that file's header)."""
+import ctypes as C
+
+import numpy as np
+
+from oracle import build_c
+from oracle import vi_oracle as O
+
+_dp = C.POINTER(C.c_double)
+
+
+class vio_problem(C.Structure):
+    _fields_ = [("n", C.c_int32), ("m", C.c_int32), ("A", C.c_int32), ("dyn", C.c_int32),
+                ("dim", C.c_int32 * 4), ("lev", _dp * 4), ("trig", _dp * 4), ("utab", _dp),
+                ("lb", C.c_double * 4), ("ub", C.c_double * 4), ("u_lb", C.c_double * 2), ("u_ub", C.c_double * 2),
+                ("dt", C.c_double), ("c", C.c_double * 16), ("Q", C.c_double * 16), ("R", C.c_double * 4),
+                ("S", C.c_double * 16), ("xbar", C.c_double * 4), ("ubar", C.c_double * 2),
+                ("EPS", C.c_double), ("INF", C.c_double), ("ontarget", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build_c.build())
+        L.vio_sweep.restype = None
+        L.vio_sweep.argtypes = [C.POINTER(vio_problem), _dp, _dp, C.POINTER(C.c_int64), C.c_double, C.c_int64,
+                                C.c_int64, C.c_int32, C.c_int32]
+        L.vio_terminal_cost.restype = None
+        L.vio_terminal_cost.argtypes = [C.POINTER(vio_problem), _dp]
+        L.vio_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+class CProblem:
+    """Wraps an oracle Problem (vi_oracle.Problem) for the C twin."""
+
+    def __init__(self, p: O.Problem):
+        self.p = p
+        self._keep = []
+        d = vio_problem()
+        d.n, d.m, d.A, d.dyn = p.n, p.m, p.actions_n, p.dyn_id
+        for i, l in enumerate(p.levels):
+            a = np.ascontiguousarray(l, dtype=np.float64); self._keep.append(a)
+            d.dim[i], d.lev[i] = len(a), _ptr(a)
+            d.lb[i], d.ub[i] = p.x_lb[i], p.x_ub[i]
+            d.xbar[i] = p.xbar[i]
+        t = p.trig_tables()
+        order = {O.DYN_PENDULUM: ["s0"], O.DYN_CARTPOLE: ["c1", "s1"], O.DYN_TWOLINK: ["s0", "c1", "s1", "s01"]}
+        for i, k in enumerate(order[p.dyn_id]):
+            a = np.ascontiguousarray(t[k], dtype=np.float64); self._keep.append(a)
+            d.trig[i] = _ptr(a)
+        ut = np.ascontiguousarray(p.u_table, dtype=np.float64); self._keep.append(ut)
+        d.utab = _ptr(ut)
+        for k in range(p.m):
+            d.u_lb[k], d.u_ub[k], d.ubar[k] = p.u_lb[k], p.u_ub[k], p.ubar[k]
+        d.dt = p.dt
+        d.c[:len(p.dyn_c)] = list(p.dyn_c)
+        d.Q[:p.n * p.n] = list(np.asarray(p.Q, dtype=float).ravel())
+        d.S[:p.n * p.n] = list(np.asarray(p.S, dtype=float).ravel())
+        d.R[:p.m * p.m] = list(np.asarray(p.R, dtype=float).ravel())
+        d.EPS, d.INF, d.ontarget = p.EPS, p.INF, int(p.ontarget_check)
+        self.d = d
+
+    def terminal_cost(self):
+        J = np.empty(self.p.nodes_n)
+        lib().vio_terminal_cost(C.byref(self.d), _ptr(J))
+        return J
+
+    def sweep(self, J, alpha=1.0, node0=0, node1=None, f32=False, threads=0):
+        """Backup of nodes [node0,node1) -> (J_new[node1-node0], pi)."""
+        node1 = self.p.nodes_n if node1 is None else node1
+        Jin = np.ascontiguousarray(J, dtype=np.float64)
+        out = np.empty(self.p.nodes_n)
+        pi = np.empty(self.p.nodes_n, dtype=np.int64)
+        lib().vio_sweep(C.byref(self.d), _ptr(Jin), _ptr(out), pi.ctypes.data_as(C.POINTER(C.c_int64)), float(alpha),
+                        int(node0), int(node1), int(f32), int(threads))
+        return out[node0:node1], pi[node0:node1]
+
+
+def max_threads():
+    return lib().vio_max_threads()
