@@ -62,7 +62,18 @@ CONFIGS = {
 }
 
 
+def _custom(spec):
+    """'pendulum:1001,1001:51:float32' | 'cartpole:41,41,41,41:21:float32' | 'twolink:21,21,21,21:5,5:float64'"""
+    kind, xd, ud, dtype = spec.split(":")
+    xd = tuple(int(v) for v in xd.split(","))
+    ud = tuple(int(v) for v in ud.split(","))
+    fn = {"pendulum": _pendulum, "cartpole": _cartpole, "twolink": _twolink}[kind]
+    return "custom " + spec, (lambda: fn(xd, ud, dtype))
+
+
 def build(name):
+    if ":" in name:
+        CONFIGS[name] = _custom(name)
     desc, fn = CONFIGS[name]
     s, g, cf, dtype = fn()
     return dict(name=name, description=desc, sys=s, grid_sys=g, cf=cf, dtype=dtype)

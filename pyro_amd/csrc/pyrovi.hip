@@ -20,6 +20,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -32,6 +33,7 @@
 // =================================================================================================
 struct DevP {
     int n, m, A, dof;
+    int udim[PVI_MAX_M];
     int dim[PVI_MAX_N];
     long long strd[PVI_MAX_N];  // element strides of the stored J buffer (C order)
     long long plane;            // nodes per axis-0 row
@@ -57,6 +59,7 @@ struct Ctrl {
     int k_done;    // sweeps executed in the current batch
     int halo_err;  // a gather fell outside the stored rows
     int pad;
+    int dbg[12];   // PVI_CHECK_BOUNDS builds: first out-of-range gather
 };
 
 // order-preserving encoding of doubles for integer atomicMax
@@ -95,6 +98,11 @@ struct Dyn<PVI_DYN_PENDULUM> {
         double rhs = (u[0] - gq) - dd;
         a[0] = hinv * rhs;
     }
+    // acc(u) = a + B u (exact algebra; used by the f32 fast path, which re-checks near the bounds)
+    __device__ void affine(double* a, double (*B)[M]) const {
+        a[0] = hinv * ((0.0 - gq) - dd);
+        B[0][0] = hinv;
+    }
 };
 
 // CartPole (cartpole.py:369-437).  c = [m1+m2, m2*lcg, m2*lcg^2, -m2*lcg, m2*g*lcg]
@@ -128,6 +136,12 @@ struct Dyn<PVI_DYN_CARTPOLE> {
         const double r0 = u[0] - cdq0;
         a[0] = i00 * r0 + t0;
         a[1] = i10 * r0 + t1;
+    }
+    __device__ void affine(double* a, double (*B)[M]) const {
+        a[0] = t0 - i00 * cdq0;
+        a[1] = t1 - i10 * cdq0;
+        B[0][0] = i00;
+        B[1][0] = i10;
     }
 };
 
@@ -174,6 +188,15 @@ struct Dyn<PVI_DYN_TWOLINK> {
         const double r1 = ((u[1] - cdq1) - G1) - D1;
         a[0] = i00 * r0 + i01 * r1;
         a[1] = i10 * r0 + i11 * r1;
+    }
+    __device__ void affine(double* a, double (*B)[M]) const {
+        const double c0 = (cdq0 + G0) + D0, c1 = (cdq1 + G1) + D1;
+        a[0] = -(i00 * c0 + i01 * c1);
+        a[1] = -(i10 * c0 + i11 * c1);
+        B[0][0] = i00;
+        B[0][1] = i01;
+        B[1][0] = i10;
+        B[1][1] = i11;
     }
 };
 
@@ -285,6 +308,17 @@ struct Interp<float, N> {
 __device__ inline double wave_max(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+__device__ inline int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ inline int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
     return v;
 }
 
@@ -459,6 +493,579 @@ __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ 
                 arg = a;
             }
         }
+        Jout[self] = best;
+        pi[o] = (PI_T)arg;
+        const double jn = (double)best, d = jn - (double)Jin[self];
+        st_j = jn;
+        st_dmax = d;
+        st_ndmin = -d;
+    }
+    block_stats(st_j, st_dmax, st_ndmin, slot);
+}
+
+
+// =================================================================================================
+// f32 fast path ("v1").  Same recursion; the inner loop is float32 and system independent:
+//   * per state (float64, reference operation order): node coordinates, position rows of x_next
+//     (exact), dynamics prologue, and the AFFINE form of the velocity displacement measured in grid
+//     cells,  rel_d(u) = (x_next_d - x_d)/dx_d = ta_d + sum_k tB_dk u_k   (mechanical systems are
+//     affine in u), rounded once to float32;
+//   * per action (float32): rel, interval = own index + floor(rel), fraction = rel - floor(rel),
+//     2^n gathers, lerps, Bellman min.  Working relative to the node keeps |rel| small, so the
+//     fraction carries ~1e-6 cells of error instead of the 6e-5 of an absolute float32 coordinate;
+//   * validity is decided from the float32 margin to the box unless that margin is inside a guard
+//     band; then the cell is re-evaluated in float64 with the exact operation order (rare branch),
+//     so the in/out-of-bounds classification equals the float64 kernel's bit for bit.
+// Requires isavalidstate box == grid end points (always true for GridDynamicSystem grids).
+// `lsplit`: log2 of the lanes that share one state (small grids), actions interleaved over them.
+// =================================================================================================
+struct FastP {
+    const float4* act;  // [A] {u0, u1, gu*dt, isavalidinput}
+    float guard;        // guard band in cells
+    int lsplit;
+};
+
+template <int DYN, typename PI_T, bool UNIFORM>
+__global__ __launch_bounds__(256) void k_sweep_fast(DevP P, FastP F, const float* __restrict__ Jin,
+                                                    float* __restrict__ Jout, PI_T* __restrict__ pi, float alpha,
+                                                    Ctrl* ctrl, unsigned long long* slot) {
+    using D = Dyn<DYN>;
+    constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M, NP = 1 << DOF;
+    if (ctrl->done) return;
+    const int split = UNIFORM ? 1 : (1 << F.lsplit);
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long o = UNIFORM ? t : (t >> F.lsplit);
+    const int part = UNIFORM ? 0 : (int)(t & (split - 1));
+    const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
+    const bool live = o < owned;
+    const float INF_F = (float)P.INF;
+
+    int idx[N];
+    int bp[NP];
+    float wp[NP], ta[DOF], tB[DOF][M], selff[DOF], nm1f[DOF];
+    int vstr[DOF], vdim[DOF];
+    bool pos_in = false, on_target = false;
+    float gxdt = 0.f;
+    long long self = 0;
+    if (live) {
+        decode_node<N>(P, o, idx);
+        double x[N], dx[N];
+        self = (long long)(idx[0] - P.store_begin) * P.strd[0];
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+            x[d] = P.lev[d][idx[d]];
+            dx[d] = x[d] - P.xbar[d];
+            if (d > 0) self += idx[d] * P.strd[d];
+        }
+        const double gx = quad_form<N>(P.Q, dx);
+        on_target = P.ontarget && (l2norm<N>(dx) < P.EPS);
+        gxdt = (float)(gx * P.dt);
+        // position rows (exact, float64)
+        pos_in = true;
+        int ci[DOF];
+        float yp[DOF];
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) {
+            const double xn = x[DOF + i] * P.dt + x[i];
+            pos_in = pos_in && !(xn < P.glo[i]) && !(xn > P.ghi[i]);
+            ci[i] = find_interval(P.lev[i], P.dim[i], P.glo[i], P.inv_step[i], xn);
+            yp[i] = (float)((xn - P.lev[i][ci[i]]) / (P.lev[i][ci[i] + 1] - P.lev[i][ci[i]]));
+        }
+        if (pos_in) {
+            int r0 = ci[0];
+            if (r0 < P.store_begin || r0 + 1 >= P.store_end) {
+                atomicOr(&ctrl->halo_err, 1);
+                r0 = min(max(r0, P.store_begin), P.store_end - 2);
+            }
+            ci[0] = r0 - P.store_begin;
+        } else {
+#pragma unroll
+            for (int i = 0; i < DOF; ++i) ci[i] = 0;
+        }
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            int b = 0;
+            float w = 1.f;
+#pragma unroll
+            for (int i = 0; i < DOF; ++i) {
+                const int bit = (c >> (DOF - 1 - i)) & 1;
+                b += (ci[i] + bit) * (int)P.strd[i];
+                w *= bit ? yp[i] : (1.f - yp[i]);
+            }
+            bp[c] = b;
+            wp[c] = w;
+        }
+        double tr[4], a64[DOF], B64[DOF][M];
+        D::trig_from_tables(P, idx, tr);
+        D dyn;
+        dyn.init(P.c, x, tr);
+        dyn.affine(a64, B64);
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) {
+            const double sc = P.dt * P.inv_step[DOF + i];
+            ta[i] = (float)(a64[i] * sc);
+#pragma unroll
+            for (int k = 0; k < M; ++k) tB[i][k] = (float)(B64[i][k] * sc);
+            selff[i] = (float)idx[DOF + i];
+            nm1f[i] = (float)(P.dim[DOF + i] - 1 - idx[DOF + i]);
+            vstr[i] = (int)P.strd[DOF + i];
+            vdim[i] = P.dim[DOF + i];
+        }
+    }
+
+    float best = INFINITY;
+    int arg = 0x7fffffff;
+    if (live) {
+        for (int a = part; a < P.A; a += split) {
+            const float4 act = F.act[a];
+            float rel[DOF], m = INFINITY;
+#pragma unroll
+            for (int i = 0; i < DOF; ++i) {
+                float r = fmaf(tB[i][0], act.x, ta[i]);
+                if (M == 2) r = fmaf(tB[i][M - 1], act.y, r);
+                rel[i] = r;
+                m = fminf(m, fminf(r + selff[i], nm1f[i] - r));
+            }
+            const bool aok = act.w != 0.f;
+            bool inb = pos_in && (m >= 0.f);
+            if (pos_in && fabsf(m) < F.guard) {
+                // rare: within the guard band of a bound -> exact float64 classification
+                double x[N], tr[4], u[M], acc[DOF];
+#pragma unroll
+                for (int d = 0; d < N; ++d) x[d] = P.lev[d][idx[d]];
+                D::trig_from_tables(P, idx, tr);
+                D dyn;
+                dyn.init(P.c, x, tr);
+#pragma unroll
+                for (int k = 0; k < M; ++k) u[k] = P.utab[a * M + k];
+                dyn.accel(u, acc);
+                inb = true;
+#pragma unroll
+                for (int i = 0; i < DOF; ++i) {
+                    const double xn = acc[i] * P.dt + x[DOF + i];
+                    inb = inb && !(xn < P.glo[DOF + i]) && !(xn > P.ghi[DOF + i]);
+                }
+            }
+            float Jn = 0.f;
+            if (inb) {
+                int off = 0;
+                float yv[DOF];
+#pragma unroll
+                for (int i = 0; i < DOF; ++i) {
+                    const float fl = floorf(rel[i]);
+                    int di = (int)fl;
+                    const int ii = min(max(idx[DOF + i] + di, 0), vdim[i] - 2);
+                    di = ii - idx[DOF + i];
+                    yv[i] = fminf(fmaxf(rel[i] - (float)di, 0.f), 1.f);
+                    off += ii * vstr[i];
+                }
+                float sv[NP];
+#pragma unroll
+                for (int v = 0; v < NP; ++v) {
+                    int vo = off;
+#pragma unroll
+                    for (int i = 0; i < DOF; ++i) vo += ((v >> (DOF - 1 - i)) & 1) ? vstr[i] : 0;
+                    float acc = wp[0] * Jin[bp[0] + vo];
+#pragma unroll
+                    for (int c = 1; c < NP; ++c) acc = fmaf(wp[c], Jin[bp[c] + vo], acc);
+                    sv[v] = acc;
+                }
+#pragma unroll
+                for (int i = DOF - 1; i >= 0; --i) {
+#pragma unroll
+                    for (int k = 0; k < (1 << i); ++k) sv[k] = fmaf(yv[i], sv[2 * k + 1] - sv[2 * k], sv[2 * k]);
+                }
+                Jn = sv[0];
+            }
+            const float G = (inb && aok) ? (on_target ? 0.f : gxdt + act.z) : INF_F;
+            const float q = fmaf(alpha, Jn, G);
+            if (q < best) {  // strict: keeps the first (smallest a) minimum within this lane
+                best = q;
+                arg = a;
+            }
+        }
+    }
+    if (!UNIFORM) {
+        for (int off = split >> 1; off > 0; off >>= 1) {
+            const float q2 = __shfl_xor(best, off, 64);
+            const int a2 = __shfl_xor(arg, off, 64);
+            if (q2 < best || (q2 == best && a2 < arg)) {
+                best = q2;
+                arg = a2;
+            }
+        }
+    }
+    double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
+    if (live && part == 0) {
+        Jout[self] = best;
+        pi[o] = (PI_T)arg;
+        const double jn = (double)best, d = jn - (double)Jin[self];
+        st_j = jn;
+        st_dmax = d;
+        st_ndmin = -d;
+    }
+    block_stats(st_j, st_dmax, st_ndmin, slot);
+}
+
+
+// =================================================================================================
+// f32 LDS-tiled path ("v2").  Arithmetic identical to k_sweep_fast; what changes is where the 2^n
+// corner values come from.  A workgroup owns blockDim.x >> lsplit consecutive nodes.  Every thread
+// first works out the index box its gathers can touch -- position rows are exact, velocity rows
+// follow from the affine displacement evaluated at the corner actions (float rounding is monotone
+// in u, so the extremes over the action grid sit at its corners) -- the workgroup reduces the boxes
+// to one window, stages that window of J_k from HBM/L2 into LDS with coalesced row reads, and the
+// action loop then gathers from LDS only (ds_read: 2 clk per wave instruction instead of ~16 clk
+// per global gather through the texture addresser).  The loop body is branch free; lanes that came
+// within the guard band of a bound are re-run afterwards with float64 classification (EXACT pass).
+// A window that does not fit the LDS budget falls back to global gathers for that workgroup.
+// =================================================================================================
+struct TileP {
+    float guard;
+    int lsplit;
+    int lds_floats;  // capacity of the dynamic LDS window
+};
+
+template <int DOF, int M>
+struct LaneState {
+    int idxv[DOF], vmax[DOF];  // own velocity indices; dim-2 (largest interval index)
+    float ta[DOF], tB[DOF][M], selff[DOF], nm1f[DOF];
+    float wp[1 << DOF];
+    int bpw[1 << DOF];  // offsets of the position corners in the gather source
+    int vs[DOF];        // strides of the velocity axes in the gather source
+    int vorg;           // sum of window origin * stride over the velocity axes
+    int limit;          // number of elements in the gather source (debug bounds check)
+    bool pos_in, on_target;
+    float gxdt;
+};
+
+template <int DYN, bool UNIFORM, bool EXACT>
+__device__ __forceinline__ void run_actions(const DevP& P, const float4* __restrict__ actp, float guard,
+                                            const float* __restrict__ src,
+                                            const LaneState<Dyn<DYN>::DOF, Dyn<DYN>::M>& L, const int* idx, int part,
+                                            int split, float alpha, float INF_F, float& best, int& arg,
+                                            bool& need_exact, int* dbg = nullptr) {
+    using D = Dyn<DYN>;
+    constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M, NP = 1 << DOF;
+    double x[N];
+    D dyn;
+    if (EXACT) {
+        double tr[4];
+#pragma unroll
+        for (int d = 0; d < N; ++d) x[d] = P.lev[d][idx[d]];
+        D::trig_from_tables(P, idx, tr);
+        dyn.init(P.c, x, tr);
+    }
+    best = INFINITY;
+    arg = 0x7fffffff;
+    for (int a = UNIFORM ? 0 : part; a < P.A; a += UNIFORM ? 1 : split) {
+        const float4 act = actp[a];
+        float rel[DOF], m = INFINITY;
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) {
+            float r = fmaf(L.tB[i][0], act.x, L.ta[i]);
+            if (M == 2) r = fmaf(L.tB[i][M - 1], act.y, r);
+            rel[i] = r;
+            m = fminf(m, fminf(r + L.selff[i], L.nm1f[i] - r));
+        }
+        bool inb;
+        if (!EXACT) {
+            inb = L.pos_in && (m >= 0.f);
+            need_exact = need_exact || (L.pos_in && fabsf(m) < guard);
+        } else {
+            double u[M], acc[DOF];
+#pragma unroll
+            for (int k = 0; k < M; ++k) u[k] = P.utab[a * M + k];
+            dyn.accel(u, acc);
+            inb = L.pos_in;
+#pragma unroll
+            for (int i = 0; i < DOF; ++i) {
+                const double xn = acc[i] * P.dt + x[DOF + i];
+                inb = inb && !(xn < P.glo[DOF + i]) && !(xn > P.ghi[DOF + i]);
+            }
+        }
+        int off = -L.vorg;
+        float yv[DOF];
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) {
+            const int ii = min(max(L.idxv[i] + (int)floorf(rel[i]), 0), L.vmax[i]);
+            yv[i] = fminf(fmaxf(rel[i] - (float)(ii - L.idxv[i]), 0.f), 1.f);
+            off += ii * L.vs[i];
+        }
+        float sv[NP];
+#pragma unroll
+        for (int v = 0; v < NP; ++v) {
+            int vo = off;
+#pragma unroll
+            for (int i = 0; i < DOF; ++i) vo += ((v >> (DOF - 1 - i)) & 1) ? L.vs[i] : 0;
+#ifdef PVI_CHECK_BOUNDS
+            int gi[NP];
+#pragma unroll
+            for (int c = 0; c < NP; ++c) {
+                gi[c] = L.bpw[c] + vo;
+                if (gi[c] < 0 || gi[c] >= L.limit) {
+                    atomicOr(dbg, 2);
+                    dbg[1] = gi[c]; dbg[2] = L.limit; dbg[3] = a; dbg[4] = L.bpw[c]; dbg[5] = vo; dbg[6] = L.vorg;
+                    dbg[7] = L.idxv[0]; dbg[8] = (int)floorf(rel[0]); dbg[9] = L.vs[0]; dbg[10] = EXACT; dbg[11] = L.pos_in;
+                    gi[c] = 0;
+                }
+            }
+            float acc = L.wp[0] * src[gi[0]];
+#pragma unroll
+            for (int c = 1; c < NP; ++c) acc = fmaf(L.wp[c], src[gi[c]], acc);
+#else
+            float acc = L.wp[0] * src[L.bpw[0] + vo];
+#pragma unroll
+            for (int c = 1; c < NP; ++c) acc = fmaf(L.wp[c], src[L.bpw[c] + vo], acc);
+#endif
+            sv[v] = acc;
+        }
+#pragma unroll
+        for (int i = DOF - 1; i >= 0; --i) {
+#pragma unroll
+            for (int k = 0; k < (1 << i); ++k) sv[k] = fmaf(yv[i], sv[2 * k + 1] - sv[2 * k], sv[2 * k]);
+        }
+        const float Jn = inb ? sv[0] : 0.f;
+        const float G = (inb && act.w != 0.f) ? (L.on_target ? 0.f : L.gxdt + act.z) : INF_F;
+        const float q = fmaf(alpha, Jn, G);
+        if (q < best) {  // strict: first (smallest a) minimum within this lane
+            best = q;
+            arg = a;
+        }
+    }
+}
+
+template <int DYN, typename PI_T, bool UNIFORM>
+__global__ __launch_bounds__(1024) void k_sweep_tile(DevP P, TileP F, const float4* __restrict__ actp,
+                                                     const float* __restrict__ Jin, float* __restrict__ Jout,
+                                                     PI_T* __restrict__ pi, float alpha, Ctrl* ctrl,
+                                                     unsigned long long* slot) {
+    using D = Dyn<DYN>;
+    constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M, NP = 1 << DOF;
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    __shared__ int s_box[2 * N][16];
+    __shared__ int s_win[2 * N];
+    if (ctrl->done) return;
+    const int split = UNIFORM ? 1 : (1 << F.lsplit);
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long o = UNIFORM ? t : (t >> F.lsplit);
+    const int part = UNIFORM ? 0 : (int)(t & (split - 1));
+    const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
+    const bool live = o < owned;
+    const float INF_F = (float)P.INF;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
+
+    LaneState<DOF, M> L;
+    int idx[N], ci[DOF];
+    long long self = 0;
+    int lo[N], hi[N];  // this thread's gather box (inclusive); axis 0 in stored-row coordinates
+#pragma unroll
+    for (int d = 0; d < N; ++d) {
+        lo[d] = 0x7fffffff;
+        hi[d] = -0x7fffffff;
+        idx[d] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < DOF; ++i) ci[i] = 0;
+    L.pos_in = false;
+    L.on_target = false;
+    L.gxdt = 0.f;
+    if (live) {
+        decode_node<N>(P, o, idx);
+        double x[N], dx[N];
+        self = (long long)(idx[0] - P.store_begin) * P.strd[0];
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+            x[d] = P.lev[d][idx[d]];
+            dx[d] = x[d] - P.xbar[d];
+            if (d > 0) self += idx[d] * P.strd[d];
+        }
+        const double gx = quad_form<N>(P.Q, dx);
+        L.on_target = P.ontarget && (l2norm<N>(dx) < P.EPS);
+        L.gxdt = (float)(gx * P.dt);
+        bool pin = true;
+        float yp[DOF];
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) {
+            const double xn = x[DOF + i] * P.dt + x[i];
+            pin = pin && !(xn < P.glo[i]) && !(xn > P.ghi[i]);
+            ci[i] = find_interval(P.lev[i], P.dim[i], P.glo[i], P.inv_step[i], xn);
+            yp[i] = (float)((xn - P.lev[i][ci[i]]) / (P.lev[i][ci[i] + 1] - P.lev[i][ci[i]]));
+        }
+        L.pos_in = pin;
+        if (pin) {
+            int r0 = ci[0];
+            if (r0 < P.store_begin || r0 + 1 >= P.store_end) {
+                atomicOr(&ctrl->halo_err, 1);
+                r0 = min(max(r0, P.store_begin), P.store_end - 2);
+            }
+            ci[0] = r0 - P.store_begin;
+        }
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            float w = 1.f;
+#pragma unroll
+            for (int i = 0; i < DOF; ++i) w *= ((c >> (DOF - 1 - i)) & 1) ? yp[i] : (1.f - yp[i]);
+            L.wp[c] = w;
+        }
+        double tr[4], a64[DOF], B64[DOF][M];
+        D::trig_from_tables(P, idx, tr);
+        D dyn;
+        dyn.init(P.c, x, tr);
+        dyn.affine(a64, B64);
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) {
+            const double sc = P.dt * P.inv_step[DOF + i];
+            L.ta[i] = (float)(a64[i] * sc);
+#pragma unroll
+            for (int k = 0; k < M; ++k) L.tB[i][k] = (float)(B64[i][k] * sc);
+            L.idxv[i] = idx[DOF + i];
+            L.vmax[i] = P.dim[DOF + i] - 2;
+            L.selff[i] = (float)idx[DOF + i];
+            L.nm1f[i] = (float)(P.dim[DOF + i] - 1 - idx[DOF + i]);
+        }
+        if (pin) {
+#pragma unroll
+            for (int i = 0; i < DOF; ++i) {
+                lo[i] = ci[i];
+                hi[i] = ci[i] + 1;
+            }
+#pragma unroll
+            for (int cr = 0; cr < (1 << M); ++cr) {
+                int a;
+                if (M == 1)
+                    a = cr ? P.A - 1 : 0;
+                else
+                    a = ((cr & 2) ? (P.udim[0] - 1) * P.udim[1] : 0) + ((cr & 1) ? P.udim[1] - 1 : 0);
+                const float4 ac = actp[a];
+#pragma unroll
+                for (int i = 0; i < DOF; ++i) {
+                    float r = fmaf(L.tB[i][0], ac.x, L.ta[i]);
+                    if (M == 2) r = fmaf(L.tB[i][M - 1], ac.y, r);
+                    const int ii = min(max(L.idxv[i] + (int)floorf(r), 0), L.vmax[i]);
+                    lo[DOF + i] = min(lo[DOF + i], ii);
+                    hi[DOF + i] = max(hi[DOF + i], ii + 1);
+                }
+            }
+        }
+    }
+
+    // ---- workgroup window --------------------------------------------------------------------
+#pragma unroll
+    for (int d = 0; d < N; ++d) {
+        const int l = wave_min_i(lo[d]), h = wave_max_i(hi[d]);
+        if (lane == 0) {
+            s_box[d][wave] = l;
+            s_box[N + d][wave] = h;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * N) {
+        int v = s_box[threadIdx.x][0];
+        for (int w = 1; w < nwaves; ++w)
+            v = (threadIdx.x < N) ? min(v, s_box[threadIdx.x][w]) : max(v, s_box[threadIdx.x][w]);
+        s_win[threadIdx.x] = v;
+    }
+    __syncthreads();
+    int wlo[N], wdim[N];
+    long long W = 1;
+    bool any = true;
+#pragma unroll
+    for (int d = 0; d < N; ++d) {
+        wlo[d] = s_win[d];
+        any = any && s_win[N + d] >= wlo[d];  // sentinels (no in-bounds lane) must not be subtracted
+        wdim[d] = any ? s_win[N + d] - wlo[d] + 1 : 0;
+        W *= wdim[d];
+    }
+    const bool use_lds = any && W <= F.lds_floats;
+    if (use_lds) {
+        // rows of the last axis, one row per wave at a time, lanes along the row (coalesced)
+        const int rowlen = wdim[N - 1];
+        const int rows = (int)(W / rowlen);
+        for (int r = wave; r < rows; r += nwaves) {
+            int rem = r;
+            long long g = wlo[N - 1];
+#pragma unroll
+            for (int d = N - 2; d >= 0; --d) {
+                const int q = rem / wdim[d];
+                g += (long long)(wlo[d] + (rem - q * wdim[d])) * P.strd[d];
+                rem = q;
+            }
+            const float* __restrict__ grow = Jin + g;
+            float* trow = tile + r * rowlen;
+            for (int c = lane; c < rowlen; c += 64) trow[c] = grow[c];
+        }
+    }
+    __syncthreads();
+
+    // ---- per-lane gather geometry: window (LDS) or stored buffer (global fallback) --------
+    {
+        int st[N];
+        if (use_lds) {
+            int acc = 1;
+#pragma unroll
+            for (int d = N - 1; d >= 0; --d) {
+                st[d] = acc;
+                acc *= wdim[d];
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < N; ++d) st[d] = (int)P.strd[d];
+        }
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            int b = 0;
+#pragma unroll
+            for (int i = 0; i < DOF; ++i)
+                b += (ci[i] + ((c >> (DOF - 1 - i)) & 1) - (use_lds ? wlo[i] : 0)) * st[i];
+            L.bpw[c] = L.pos_in ? b : 0;
+        }
+        L.vorg = 0;
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) {
+            L.vs[i] = st[DOF + i];
+            L.vorg += (use_lds ? wlo[DOF + i] : 0) * st[DOF + i];
+        }
+        L.limit = use_lds ? (int)W : (int)((long long)(P.store_end - P.store_begin) * P.plane);
+        if (!L.pos_in) {  // nothing of this lane is in the window: keep its (discarded) reads in range
+            L.vorg = 0;
+#pragma unroll
+            for (int i = 0; i < DOF; ++i) L.vs[i] = 0;
+        }
+    }
+
+    float best = INFINITY;
+    int arg = 0x7fffffff;
+    bool need_exact = false;
+    if (live) {
+        if (use_lds)
+            run_actions<DYN, UNIFORM, false>(P, actp, F.guard, tile, L, idx, part, split, alpha, INF_F, best, arg,
+                                             need_exact, ctrl->dbg);
+        else
+            run_actions<DYN, UNIFORM, false>(P, actp, F.guard, Jin, L, idx, part, split, alpha, INF_F, best, arg,
+                                             need_exact, ctrl->dbg);
+        if (need_exact) {
+            bool dummy = false;
+            if (use_lds)
+                run_actions<DYN, false, true>(P, actp, F.guard, tile, L, idx, part, split, alpha, INF_F, best, arg,
+                                              dummy, ctrl->dbg);
+            else
+                run_actions<DYN, false, true>(P, actp, F.guard, Jin, L, idx, part, split, alpha, INF_F, best, arg,
+                                              dummy, ctrl->dbg);
+        }
+    }
+    if (!UNIFORM) {
+        for (int off = split >> 1; off > 0; off >>= 1) {
+            const float q2 = __shfl_xor(best, off, 64);
+            const int a2 = __shfl_xor(arg, off, 64);
+            if (q2 < best || (q2 == best && a2 < arg)) {
+                best = q2;
+                arg = a2;
+            }
+        }
+    }
+    double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
+    if (live && part == 0) {
         Jout[self] = best;
         pi[o] = (PI_T)arg;
         const double jn = (double)best, d = jn - (double)Jin[self];
@@ -669,6 +1276,11 @@ struct pvi_problem {
     double* d_G = nullptr;
     double* stage = nullptr;  // f64 staging for up/download
     long long stage_n = 0;
+    FastP F;                  // f32 fast path tables
+    bool fast_ok = false;
+    TileP T;                  // f32 LDS-tiled path
+    bool tile_ok = false;
+    int tile_block = 256;
 };
 
 template <typename T>
@@ -786,6 +1398,8 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
     P.m = d->m;
     P.A = (int)A;
     P.dof = d->n / 2;
+    P.udim[0] = d->u_dim[0];
+    P.udim[1] = d->m > 1 ? d->u_dim[1] : 1;
     P.plane = plane;
     P.row_begin = d->row_begin;
     P.row_end = d->row_end;
@@ -840,6 +1454,37 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
     if ((rc = dev_upload(h, utab.data(), utab.size(), &P.utab))) return bail(rc);
     if ((rc = dev_upload(h, gu.data(), gu.size(), &P.gu))) return bail(rc);
     if ((rc = dev_upload(h, aok.data(), aok.size(), &P.aok))) return bail(rc);
+    {   // f32 fast path: per-action {u0, u1, gu*dt, isavalidinput}
+        std::vector<float4> act((size_t)A);
+        for (long long a = 0; a < A; ++a)
+            act[a] = make_float4((float)utab[a * d->m], d->m > 1 ? (float)utab[a * d->m + 1] : 0.f,
+                                 (float)(gu[a] * d->dt), aok[a] ? 1.f : 0.f);
+        if ((rc = dev_upload(h, act.data(), act.size(), &h->F.act))) return bail(rc);
+        h->F.guard = 1e-3f;
+        long long threads = h->owned;
+        int ls = 0;
+        while (threads < (1ll << 20) && (2 << ls) <= 64 && (2 << ls) <= A) {
+            ++ls;
+            threads <<= 1;
+        }
+        if (const char* e = getenv("PVI_LSPLIT")) ls = atoi(e);
+        h->F.lsplit = ls;
+        bool box_is_grid = true;
+        for (int i = 0; i < d->n; ++i)
+            box_is_grid = box_is_grid && d->x_lb[i] == P.glo[i] && d->x_ub[i] == P.ghi[i];
+        h->fast_ok = d->dtype == PVI_F32 && d->dynamics_id != PVI_DYN_TABLE && box_is_grid &&
+                     h->stored < 0x7fffffffLL && !getenv("PVI_NO_FAST");
+        h->tile_ok = h->fast_ok && !getenv("PVI_NO_TILE");
+        h->T.guard = h->F.guard;
+        h->T.lsplit = ls;
+        // LDS window budget / workgroup size: 2-D windows are small (4 workgroups per CU); 4-D windows
+        // span the whole last axis, so larger workgroups amortise them
+        int lds_kb = d->n == 2 ? 32 : 96, blk = d->n == 2 ? 256 : 512;
+        if (const char* e = getenv("PVI_LDS_KB")) lds_kb = atoi(e);
+        if (const char* e = getenv("PVI_BLOCK")) blk = atoi(e);
+        h->T.lds_floats = lds_kb * 256;
+        h->tile_block = blk;
+    }
 
     // trig tables over the angle levels: supplied by the host (numpy) or computed here with libm
     auto table = [&](int slot, int axis, double (*fn)(double)) -> int {
@@ -1056,6 +1701,48 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     const REAL* Jin = (const REAL*)h->J[src];
     REAL* Jout = (REAL*)h->J[src ^ 1];
     PI_T* pi = (PI_T*)h->pi;
+    if constexpr (sizeof(REAL) == 4) {
+        if (h->tile_ok) {
+            const int blk = h->tile_block;
+            const unsigned gf = grid_for(h->owned << h->T.lsplit, blk);
+            const size_t lds = (size_t)h->T.lds_floats * 4;
+            const float al = (float)alpha;
+#define TILE(DYN)                                                                                                 \
+    if (h->T.lsplit == 0)                                                                                         \
+        hipLaunchKernelGGL((k_sweep_tile<DYN, PI_T, true>), gf, blk, lds, st, h->P, h->T, h->F.act, Jin, Jout, pi, \
+                           al, h->ctrl, slot);                                                                    \
+    else                                                                                                          \
+        hipLaunchKernelGGL((k_sweep_tile<DYN, PI_T, false>), gf, blk, lds, st, h->P, h->T, h->F.act, Jin, Jout, pi, \
+                           al, h->ctrl, slot);
+            switch (h->d.dynamics_id) {
+                case PVI_DYN_PENDULUM: TILE(PVI_DYN_PENDULUM) break;
+                case PVI_DYN_CARTPOLE: TILE(PVI_DYN_CARTPOLE) break;
+                default: TILE(PVI_DYN_TWOLINK) break;
+            }
+#undef TILE
+            HIPCHK(hipGetLastError());
+            return PVI_OK;
+        }
+        if (h->fast_ok) {
+            const unsigned gf = grid_for(h->owned << h->F.lsplit);
+            const float al = (float)alpha;
+#define FAST(DYN)                                                                                                  \
+    if (h->F.lsplit == 0)                                                                                          \
+        hipLaunchKernelGGL((k_sweep_fast<DYN, PI_T, true>), gf, 256, 0, st, h->P, h->F, Jin, Jout, pi, al, h->ctrl, \
+                           slot);                                                                                  \
+    else                                                                                                           \
+        hipLaunchKernelGGL((k_sweep_fast<DYN, PI_T, false>), gf, 256, 0, st, h->P, h->F, Jin, Jout, pi, al, h->ctrl, \
+                           slot);
+            switch (h->d.dynamics_id) {
+                case PVI_DYN_PENDULUM: FAST(PVI_DYN_PENDULUM) break;
+                case PVI_DYN_CARTPOLE: FAST(PVI_DYN_CARTPOLE) break;
+                default: FAST(PVI_DYN_TWOLINK) break;
+            }
+#undef FAST
+            HIPCHK(hipGetLastError());
+            return PVI_OK;
+        }
+    }
     switch (h->d.dynamics_id) {
         case PVI_DYN_PENDULUM:
             hipLaunchKernelGGL((k_sweep<PVI_DYN_PENDULUM, REAL, PI_T>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha,
@@ -1132,6 +1819,10 @@ extern "C" int pvi_sweep(pvi_handle h, int32_t max_sweeps, double alpha, double 
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
         ms_total += ms;
+        if (c.dbg[0])
+            return fail(PVI_EHIP, "bounds check: idx=%d limit=%d a=%d bpw=%d vo=%d vorg=%d idxv=%d fl=%d vs=%d exact=%d pos_in=%d",
+                        c.dbg[1], c.dbg[2], c.dbg[3], c.dbg[4], c.dbg[5], c.dbg[6], c.dbg[7], c.dbg[8], c.dbg[9], c.dbg[10],
+                        c.dbg[11]);
         if (c.halo_err) return fail(PVI_EHALO, "a gather left the stored rows");
         if (stats && c.k_done)
             HIPCHK(hipMemcpy(stats + 4 * (size_t)done_total, h->results, sizeof(double) * 4 * c.k_done,
