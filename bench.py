@@ -137,6 +137,7 @@ def run_single(args):
                      "note": "VALU-bound stencil/gather: see valu_frac"},
         "valu_frac": (N * A / (kern_ms * 1e-3)) * flops_cell / (VALU_PEAK_F32_TFLOPS * 1e12),
         "last_stats": [float(v) for v in stats[-1]],
+        "kernel_path": p.describe(),
     }
     if cpu is not None:
         out["cpu_baseline"] = cpu

@@ -112,6 +112,8 @@ int64_t pvi_plane_size(pvi_handle h);   /* nodes per axis-0 row */
 int64_t pvi_stored_nodes(pvi_handle h); /* (row_end+halo_hi - (row_begin-halo_lo)) * plane */
 int64_t pvi_owned_nodes(pvi_handle h);
 int pvi_pi_itemsize(pvi_handle h);      /* bytes per policy entry on the device */
+/* one-line description of the kernel path chosen for this problem (diagnostics / bench output) */
+int pvi_describe(pvi_handle h, char* buf, int32_t n);
 
 /* ---- cost-to-go ---------------------------------------------------------------------------- */
 /* evaluate_terminal_cost: J[s] = cf.h(x_s), pi = 0 on all stored rows (dynamicprogramming.py:159-171) */

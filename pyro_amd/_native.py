@@ -51,6 +51,7 @@ SYMBOLS = {
     "pvi_stored_nodes": (C.c_int64, [_h]),
     "pvi_owned_nodes": (C.c_int64, [_h]),
     "pvi_pi_itemsize": (C.c_int, [_h]),
+    "pvi_describe": (C.c_int, [_h, C.c_char_p, C.c_int32]),
     "pvi_terminal_cost": (C.c_int, [_h]),
     "pvi_set_J": (C.c_int, [_h, _dp, C.c_int32, C.c_int32]),
     "pvi_get_J": (C.c_int, [_h, _dp, C.c_int32, C.c_int32]),
@@ -204,6 +205,11 @@ class Problem:
         if row0 is None:
             row0, nrows = default[0], default[1] - default[0]
         return int(row0), int(nrows)
+
+    def describe(self):
+        buf = C.create_string_buffer(512)
+        check(lib().pvi_describe(self._h, buf, 512))
+        return buf.value.decode()
 
     def terminal_cost(self):
         check(lib().pvi_terminal_cost(self._h))

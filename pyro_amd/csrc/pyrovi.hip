@@ -24,6 +24,7 @@
 #include <cstring>
 #include <limits>
 #include <new>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/pyrovi.h"
@@ -320,6 +321,25 @@ __device__ inline int wave_max_i(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// `red`: 48 doubles of LDS scratch
+__device__ inline void block_stats_at(double* red, double j, double dmax, double ndmin, unsigned long long* slot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    j = wave_max(j);
+    dmax = wave_max(dmax);
+    ndmin = wave_max(ndmin);
+    if (lane == 0) {
+        red[wave] = j;
+        red[16 + wave] = dmax;
+        red[32 + wave] = ndmin;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double v = red[16 * threadIdx.x];
+        for (int w = 1; w < nw; ++w) v = fmax(v, red[16 * threadIdx.x + w]);
+        atomicMax(&slot[threadIdx.x], enc_f64(v));
+    }
 }
 
 __device__ inline void block_stats(double j, double dmax, double ndmin, unsigned long long* slot) {
@@ -1076,6 +1096,8 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(DevP P, TileP F, const floa
     block_stats(st_j, st_dmax, st_ndmin, slot);
 }
 
+#include "sweep_lean.inc"
+
 // =================================================================================================
 // tier B: table-driven sweep for arbitrary sys.f / cf.g (dynamicprogramming.py:564-570 verbatim:
 // Q = G + alpha * J_interp(x_next_table)).  x_next [node][A][N] f64, G [node][A] f64.
@@ -1281,6 +1303,13 @@ struct pvi_problem {
     TileP T;                  // f32 LDS-tiled path
     bool tile_ok = false;
     int tile_block = 256;
+    LeanP LP;                 // f32 lean path (sweep_lean.inc)
+    bool lean_ok = false;
+    int lean_pw1 = 2, lean_block = 256;
+    dim3 lean_grid;
+    size_t lean_lds = 0;
+    bool lean_lds_attr = false;
+    char lean_why[160] = "";
 };
 
 template <typename T>
@@ -1303,6 +1332,158 @@ static double quad_form_host(const double* M, const double* dx, int n) {
         out = (i == 0) ? term : out + term;
     }
     return out;
+}
+
+
+// ---- lean path set-up (sweep_lean.inc): per-node coefficients, pair tables, per-tile windows -------------
+static inline unsigned magic32(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
+
+template <typename T>
+static int dev_alloc(pvi_problem* h, size_t n, T** out) {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+    h->dev_allocs.push_back(p);
+    *out = (T*)p;
+    return PVI_OK;
+}
+
+static void dev_release(pvi_problem* h, void* p) {
+    if (!p) return;
+    for (auto& q : h->dev_allocs)
+        if (q == p) q = nullptr;
+    (void)hipFree(p);
+}
+
+static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats) {
+    const DevP& P = h->P;
+    LeanP& L = h->LP;
+    const int DOF = P.dof;
+    L.V0 = DOF == 2 ? P.dim[2] : 1;
+    L.V1 = P.dim[P.n - 1];
+    L.ntx = (L.V1 + tv1_t - 1) / tv1_t;
+    L.TV1 = (L.V1 + L.ntx - 1) / L.ntx;
+    const int tv0 = std::max(1, std::min(L.V0, tv0_t));
+    L.nty = (L.V0 + tv0 - 1) / tv0;
+    L.TV0 = (L.V0 + L.nty - 1) / L.nty;
+    L.tv1_magic = ((1 << 20) + L.TV1 - 1) / L.TV1;
+    L.posdim1 = DOF == 2 ? P.dim[1] : 1;
+    L.pd_magic = magic32((unsigned)L.posdim1);
+    L.vplane = (long long)L.V0 * L.V1;
+    L.owned = h->owned;
+    const int pnodes = (P.row_end - P.row_begin) * L.posdim1;
+    if (pnodes > 65535 || L.nty > 65535) return 1;
+    h->lean_grid = dim3((unsigned)L.ntx, (unsigned)L.nty, (unsigned)pnodes);
+    const long long ntiles = (long long)L.ntx * L.nty * pnodes;
+    int rc;
+    if (L.win) dev_release(h, L.win);
+    L.win = nullptr;
+    if ((rc = dev_alloc(h, (size_t)ntiles * 8, &L.win))) return rc;
+    hipLaunchKernelGGL(k_lean_winit, grid_for(std::max<long long>(ntiles * 4, 4)), 256, 0, h->stream, L.win, ntiles,
+                       L.summary);
+    const int sthreads = ((L.TV0 * L.TV1 + 63) / 64) * 64;
+    if (sthreads > 1024) return 1;
+    switch (h->d.dynamics_id) {
+        case PVI_DYN_PENDULUM:
+            hipLaunchKernelGGL((k_lean_setup<PVI_DYN_PENDULUM>), h->lean_grid, sthreads, 0, h->stream, P, L, h->F.act);
+            break;
+        case PVI_DYN_CARTPOLE:
+            hipLaunchKernelGGL((k_lean_setup<PVI_DYN_CARTPOLE>), h->lean_grid, sthreads, 0, h->stream, P, L, h->F.act);
+            break;
+        default:
+            hipLaunchKernelGGL((k_lean_setup<PVI_DYN_TWOLINK>), h->lean_grid, sthreads, 0, h->stream, P, L, h->F.act);
+            break;
+    }
+    HIPCHK(hipGetLastError());
+    int summary[4];
+    HIPCHK(hipMemcpyAsync(summary, L.summary, sizeof(summary), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (summary[3]) {
+        snprintf(h->lean_why, sizeof(h->lean_why), "%s", (summary[3] & 2) ? "an action fails isavalidinput" : "halo too small");
+        return (summary[3] & 1) ? 2 : 1;
+    }
+    // row pitch 32k+1 dwords >= longest row (+1: the j+1 corner of the last in-row cell is inside the row)
+    const int rs = 32 * ((summary[1] + 30) / 32) + 1;
+    const long long need = (long long)summary[0] * rs + 128;
+    const int rs_opts[6] = {33, 65, 97, 129, 193, 257};
+    bool rs_ok = DOF == 1;
+    for (int k = 0; k < 6; ++k) rs_ok = rs_ok || rs == rs_opts[k];
+    if (need <= lds_budget_floats && rs_ok) {
+        L.RS = rs;
+        h->lean_pw1 = rs;
+        h->lean_lds = (size_t)need * 4;
+        return 0;
+    }
+    snprintf(h->lean_why, sizeof(h->lean_why), "tile %dx%d needs %lld LDS floats (%d rows x pitch %d; budget %d)", L.TV0,
+             L.TV1, need, summary[0], rs, lds_budget_floats);
+    return 1;
+}
+
+static int lean_setup(pvi_problem* h) {
+    const DevP& P = h->P;
+    LeanP& L = h->LP;
+    memset(&L, 0, sizeof(L));
+    h->lean_ok = false;
+    if (!h->fast_ok || getenv("PVI_NO_LEAN")) return PVI_OK;
+    const int DOF = P.dof, M = P.m;
+    int rc;
+    if ((rc = dev_alloc(h, (size_t)DOF * h->owned, &L.ta))) return rc;
+    if ((rc = dev_alloc(h, (size_t)DOF * M * h->owned, &L.tB))) return rc;
+    if ((rc = dev_alloc(h, (size_t)h->owned, &L.gx))) return rc;
+    if ((rc = dev_alloc(h, (size_t)h->owned, &L.flag))) return rc;
+    if ((rc = dev_alloc(h, (size_t)P.dim[0] * P.dim[DOF], &L.pt0))) return rc;
+    if (DOF == 2 && (rc = dev_alloc(h, (size_t)P.dim[1] * P.dim[3], &L.pt1))) return rc;
+    if ((rc = dev_alloc(h, 4, &L.summary))) return rc;
+    L.guard = h->F.guard;
+    hipLaunchKernelGGL(k_lean_pairs, grid_for((long long)P.dim[0] * P.dim[DOF]), 256, 0, h->stream, P, 0, L.pt0);
+    if (DOF == 2)
+        hipLaunchKernelGGL(k_lean_pairs, grid_for((long long)P.dim[1] * P.dim[3]), 256, 0, h->stream, P, 1, L.pt1);
+    HIPCHK(hipGetLastError());
+    // lanes per node for small grids
+    int ls = 0;
+    while ((h->owned << ls) < (1ll << 19) && (2 << ls) <= 16 && (4 << ls) <= P.A) ++ls;
+    if (const char* e = getenv("PVI_LSPLIT")) ls = atoi(e);
+    L.lsplit = ls;
+    const int spb = std::max(16, 256 >> ls);  // nodes per workgroup
+    int budget = DOF == 1 ? 8 * 1024 : 20 * 1024;  // floats: 32 KB (2-D), 80 KB (4-D: two workgroups per CU)
+    if (const char* e = getenv("PVI_LDS_KB")) budget = atoi(e) * 256;
+    budget = std::min(budget, 40000);
+    int shapes[6][2];
+    int ns = 0;
+    if (getenv("PVI_TV0") && getenv("PVI_TV1")) {
+        shapes[ns][0] = atoi(getenv("PVI_TV0"));
+        shapes[ns++][1] = atoi(getenv("PVI_TV1"));
+    } else if (DOF == 1) {
+        shapes[ns][0] = 1; shapes[ns++][1] = spb;
+        shapes[ns][0] = 1; shapes[ns++][1] = std::max(16, spb / 2);
+    } else {
+        // 4-D: long tiles along the last axis amortise the window best (measured on 101^4: 10x51 tile)
+        const int V1 = P.dim[3];
+        const int t1 = (V1 + (V1 + 63) / 64 - 1) / ((V1 + 63) / 64);
+        shapes[ns][0] = std::max(1, 2 * spb / t1); shapes[ns++][1] = t1;
+        shapes[ns][0] = std::max(1, spb / t1); shapes[ns++][1] = t1;
+        shapes[ns][0] = std::max(1, 2 * spb / 32); shapes[ns++][1] = 32;
+        shapes[ns][0] = std::max(1, spb / 32); shapes[ns++][1] = 32;
+        shapes[ns][0] = std::max(1, spb / 16); shapes[ns++][1] = 16;
+    }
+    for (int k = 0; k < ns; ++k) {
+        rc = lean_try(h, shapes[k][0], shapes[k][1], budget);
+        if (rc < 0) return rc;
+        if (rc == 2) break;
+        if (rc == 0) {
+            const int threads = ((L.TV0 * L.TV1) << L.lsplit);
+            h->lean_block = ((threads + 63) / 64) * 64;
+            if (h->lean_block > 512) continue;
+            h->lean_ok = true;
+            h->lean_lds_attr = false;
+            break;
+        }
+    }
+    if (!h->lean_ok) {  // release the per-node arrays: the fast / tiled kernels do not need them
+        dev_release(h, L.ta); dev_release(h, L.tB); dev_release(h, L.gx); dev_release(h, L.flag);
+        dev_release(h, L.win);
+        L.ta = L.tB = L.gx = nullptr; L.flag = nullptr; L.win = nullptr;
+    }
+    return PVI_OK;
 }
 
 extern "C" int pvi_abi_version(void) { return PVI_ABI_VERSION; }
@@ -1461,6 +1642,7 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
                                  (float)(gu[a] * d->dt), aok[a] ? 1.f : 0.f);
         if ((rc = dev_upload(h, act.data(), act.size(), &h->F.act))) return bail(rc);
         h->F.guard = 1e-3f;
+        if (const char* e = getenv("PVI_GUARD")) h->F.guard = (float)atof(e);  // experiments only
         long long threads = h->owned;
         int ls = 0;
         while (threads < (1ll << 20) && (2 << ls) <= 64 && (2 << ls) <= A) {
@@ -1545,6 +1727,7 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
     h->results = (double*)p;
     HCHK(hipStreamSynchronize(h->stream));
 #undef HCHK
+    if ((rc = lean_setup(h))) return bail(rc);
     *out = h;
     return PVI_OK;
 }
@@ -1553,6 +1736,18 @@ extern "C" int64_t pvi_plane_size(pvi_handle h) { return h ? h->plane : 0; }
 extern "C" int64_t pvi_stored_nodes(pvi_handle h) { return h ? h->stored : 0; }
 extern "C" int64_t pvi_owned_nodes(pvi_handle h) { return h ? h->owned : 0; }
 extern "C" int pvi_pi_itemsize(pvi_handle h) { return h ? h->pi_size : 0; }
+
+extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
+    if (!h || !buf || n <= 0) return fail(PVI_EINVAL, "bad argument");
+    const char* path = h->d.dtype == PVI_F64 ? "exact-f64"
+                       : h->lean_ok ? "lean"
+                       : h->tile_ok ? "tile"
+                       : h->fast_ok ? "fast" : (h->d.dynamics_id == PVI_DYN_TABLE ? "table" : "exact-f32");
+    snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d note=%s", path,
+             h->LP.TV0, h->LP.TV1, h->lean_grid.x, h->lean_grid.y, h->lean_grid.z, h->lean_block, h->lean_pw1,
+             h->lean_lds, h->lean_ok ? h->LP.lsplit : h->F.lsplit, h->lean_why);
+    return PVI_OK;
+}
 
 extern "C" int pvi_synchronize(pvi_handle h) {
     if (!h) return fail(PVI_EINVAL, "NULL handle");
@@ -1702,6 +1897,43 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     REAL* Jout = (REAL*)h->J[src ^ 1];
     PI_T* pi = (PI_T*)h->pi;
     if constexpr (sizeof(REAL) == 4) {
+        if (h->lean_ok) {
+            const float al = (float)alpha;
+#define LEAN3(DYN, PW, U)                                                                                           \
+    {                                                                                                               \
+        auto kfn = k_sweep_lean<DYN, PI_T, PW, U>;                                                                  \
+        if (!h->lean_lds_attr && h->lean_lds > 48 * 1024) {                                                         \
+            HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lean_lds)); \
+            h->lean_lds_attr = true;                                                                                \
+        }                                                                                                           \
+        hipLaunchKernelGGL(kfn, h->lean_grid, h->lean_block, h->lean_lds, st, h->P, h->LP, h->F.act, Jin, Jout, pi, al, \
+                           h->ctrl, slot);                                                                          \
+    }
+#define LEAN2(DYN, PW)         \
+    if (h->LP.lsplit == 0)     \
+        LEAN3(DYN, PW, true)   \
+    else                       \
+        LEAN3(DYN, PW, false)
+#define LEAN(DYN)                         \
+    switch (h->lean_pw1) {                \
+        case 33: LEAN2(DYN, 33) break;    \
+        case 65: LEAN2(DYN, 65) break;    \
+        case 97: LEAN2(DYN, 97) break;    \
+        case 129: LEAN2(DYN, 129) break;  \
+        case 193: LEAN2(DYN, 193) break;  \
+        default: LEAN2(DYN, 257) break;   \
+    }
+            switch (h->d.dynamics_id) {
+                case PVI_DYN_PENDULUM: LEAN2(PVI_DYN_PENDULUM, 0) break;
+                case PVI_DYN_CARTPOLE: LEAN(PVI_DYN_CARTPOLE) break;
+                default: LEAN(PVI_DYN_TWOLINK) break;
+            }
+#undef LEAN
+#undef LEAN2
+#undef LEAN3
+            HIPCHK(hipGetLastError());
+            return PVI_OK;
+        }
         if (h->tile_ok) {
             const int blk = h->tile_block;
             const unsigned gf = grid_for(h->owned << h->T.lsplit, blk);

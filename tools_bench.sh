@@ -6,7 +6,7 @@ for w in c2 c2p c3; do
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); print(d['config']['workload'][:4], 'ms/sweep %.4f' % d['ms_per_step'], 'kern_ms %.4f' % d['roofline']['kernel_ms'], 'Gcells/s %.1f' % (d['value']/1e9), 'sweeps/s %.1f' % d['sweeps_per_sec'])
+        d = json.loads(l); print(d['config']['workload'][:4], 'ms/sweep %.4f' % d['ms_per_step'], 'kern_ms %.4f' % d['roofline']['kernel_ms'], 'Gcells/s %.1f' % (d['value']/1e9), 'sweeps/s %.1f' % d['sweeps_per_sec'], d.get('kernel_path',''))
     else: print(l, end='')
 "
 done
