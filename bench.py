@@ -155,7 +155,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("PVI_FORCE_PARALLEL"):
         from pyro_amd import parallel_bench
         return parallel_bench.run(args)
     args.workload = args.workload or "c2"

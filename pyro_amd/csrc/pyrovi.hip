@@ -1371,9 +1371,15 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
     L.vplane = (long long)L.V0 * L.V1;
     L.owned = h->owned;
     const int pnodes = (P.row_end - P.row_begin) * L.posdim1;
-    if (pnodes > 65535 || L.nty > 65535) return 1;
-    h->lean_grid = dim3((unsigned)L.ntx, (unsigned)L.nty, (unsigned)pnodes);
     const long long ntiles = (long long)L.ntx * L.nty * pnodes;
+    if (ntiles >= 0x7fffffffLL) return 1;
+    L.ntx_magic = magic32((unsigned)L.ntx);
+    L.ntxy_magic = magic32((unsigned)(L.ntx * L.nty));
+    L.nblocks = (unsigned)ntiles;
+    L.xq = L.nblocks / 8u;
+    L.xrem = L.nblocks % 8u;
+    L.xcd_remap = getenv("PVI_NO_XCD") ? 0 : 1;
+    h->lean_grid = dim3((unsigned)ntiles, 1, 1);
     int rc;
     if (L.win) dev_release(h, L.win);
     L.win = nullptr;

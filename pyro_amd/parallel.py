@@ -1,0 +1,175 @@
+"""
+Multi-GPU value iteration: the state grid is cut into contiguous slabs of the OUTERMOST axis
+(C order -> each slab is one contiguous block of J), one process per GPU, and after every sweep
+the ranks exchange halo rows of the new cost-to-go with their +-1 neighbours (point-to-point
+over xGMI through RCCL; `gloo` on CPU for the tests) and all-reduce the three sweep statistics.
+The reference has no counterpart (single thread); the partition follows SURVEY.md section 8(e).
+
+    rank r owns rows [r0, r1), stores [r0-h, r1+h) clipped to the grid;
+    h = ceil(max|x_next_0 - x_0| / dx_0) + 1; for mechanical systems x_next_0 - x_0 = dq_0*dt exactly.
+
+The compute backend is pluggable so that the exchange logic can be exercised on CPU:
+  HipSlab     -- product path: libpyrovi handle over caller-owned torch buffers (ext_J / ext_pi)
+  (tests inject an oracle-backed slab; the product never imports the oracle)
+"""
+import math
+
+import numpy as np
+
+
+def partition_rows(n_rows, world):
+    """Contiguous slabs whose sizes differ by at most one (the first n_rows % world get one more)."""
+    base, extra = divmod(n_rows, world)
+    out, r = [], 0
+    for k in range(world):
+        n = base + (1 if k < extra else 0)
+        out.append((r, r + n))
+        r += n
+    return out
+
+
+def halo_rows(grid_sys):
+    """Rows of axis 0 a gather can reach beyond a node's own row (+1 for the upper corner)."""
+    s = grid_sys.sys
+    dof = getattr(s, "dof", None)
+    if dof is None:
+        raise NotImplementedError("halo width is only known analytically for mechanical systems (x_next_0 = q_0 + dq_0 dt)")
+    vmax = max(abs(float(s.x_lb[dof])), abs(float(s.x_ub[dof])))
+    return int(math.ceil(vmax * grid_sys.dt / float(grid_sys.x_step_size[0]))) + 1
+
+
+class HipSlab:
+    """One rank's slab on its GPU.  J lives in torch tensors so RCCL can move halo rows in place."""
+
+    def __init__(self, grid_sys, cost, dtype, rows, halo, device):
+        import torch
+        from pyro_amd import _native
+        self.torch = torch
+        self.dev = torch.device("cuda", device)
+        torch.cuda.set_device(self.dev)
+        n0 = int(grid_sys.x_grid_dim[0])
+        self.rows = rows
+        self.store_rows = (max(0, rows[0] - halo), min(n0, rows[1] + halo))
+        self.plane = int(np.prod(grid_sys.x_grid_dim[1:]))
+        tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
+        nst = (self.store_rows[1] - self.store_rows[0]) * self.plane
+        nown = (rows[1] - rows[0]) * self.plane
+        self.J = [torch.zeros(nst, dtype=tdt, device=self.dev) for _ in range(2)]
+        A = int(np.prod(grid_sys.u_grid_dim))
+        self.pi = torch.zeros(nown, dtype=torch.uint8 if A <= 256 else torch.int16, device=self.dev)
+        self.cur = 0
+        self.p = grid_sys._device_problem(cost=cost, dtype=dtype, rows=rows, halo=(halo, halo), device=device,
+                                          ext_J=[t.data_ptr() for t in self.J], ext_pi=self.pi.data_ptr())
+        self._stream = torch.cuda.current_stream(self.dev).cuda_stream
+
+    def terminal_cost(self):
+        self.p.terminal_cost()
+
+    def sweep(self, alpha):
+        self.p.sweep_async(alpha, self._stream)
+        self.cur ^= 1
+        assert self.p.device_J(0) == self.J[self.cur].data_ptr()
+
+    def stats(self):
+        return self.p.sweep_stats(self._stream)
+
+    def rows_view(self, row0, nrows):
+        o = (row0 - self.store_rows[0]) * self.plane
+        return self.J[self.cur][o:o + nrows * self.plane]
+
+    def owned_J(self):
+        return self.rows_view(self.rows[0], self.rows[1] - self.rows[0]).double().cpu().numpy()
+
+    def owned_pi(self):
+        return self.pi.cpu().numpy().astype(np.int64)
+
+    def describe(self):
+        return self.p.describe()
+
+
+class ShardedValueIteration:
+    """Drives one slab per rank; `dist` is torch.distributed (already initialised)."""
+
+    def __init__(self, grid_sys, cost_function, dist, dtype="float32", device=0, slab_factory=None, halo=None):
+        import torch
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.grid_sys = grid_sys
+        n0 = int(grid_sys.x_grid_dim[0])
+        self.parts = partition_rows(n0, self.world)
+        self.halo = halo_rows(grid_sys) if halo is None else halo
+        self.rows = self.parts[self.rank]
+        if self.rows[1] - self.rows[0] < 1:
+            raise ValueError("more ranks than rows of axis 0")
+        # the +-1 neighbour exchange needs every neighbour slab to be at least `halo` thick
+        self.p2p = all(b - a >= self.halo for a, b in self.parts) or self.world == 1
+        cost = cost_function.device_cost() if hasattr(cost_function, "device_cost") else cost_function
+        factory = slab_factory or HipSlab
+        store_halo = self.halo if self.p2p else n0          # fall-back: every rank stores the whole grid
+        self.slab = factory(grid_sys, cost, dtype, self.rows, store_halo, device)
+        self.k = 0
+        self.slab.terminal_cost()
+
+    # ---- halo exchange of the CURRENT cost-to-go ---------------------------------------------------
+    def exchange(self):
+        if self.world == 1:
+            return
+        d, s, h = self.dist, self.slab, self.halo
+        r0, r1 = self.rows
+        if self.p2p:
+            ops = []
+            if self.rank > 0:                                   # lower neighbour
+                lo = s.store_rows[0]
+                ops.append(d.P2POp(d.isend, s.rows_view(r0, h), self.rank - 1))
+                ops.append(d.P2POp(d.irecv, s.rows_view(lo, r0 - lo), self.rank - 1))
+            if self.rank < self.world - 1:                      # upper neighbour
+                hi = s.store_rows[1]
+                ops.append(d.P2POp(d.isend, s.rows_view(r1 - h, h), self.rank + 1))
+                ops.append(d.P2POp(d.irecv, s.rows_view(r1, hi - r1), self.rank + 1))
+            for w in d.batch_isend_irecv(ops):
+                w.wait()
+        else:
+            # slabs thinner than the halo: gather everybody's rows (padded to equal length)
+            width = max(b - a for a, b in self.parts)
+            mine = s.rows_view(r0, r1 - r0)
+            pad = self.torch.zeros(width * s.plane, dtype=mine.dtype, device=mine.device)
+            pad[:mine.numel()] = mine
+            bufs = [self.torch.empty_like(pad) for _ in range(self.world)]
+            d.all_gather(bufs, pad)
+            for k, (a, b) in enumerate(self.parts):
+                if k != self.rank:
+                    s.rows_view(a, b - a).copy_(bufs[k][:(b - a) * s.plane])
+
+    def sweep(self, alpha=1.0):
+        """One Bellman backup of the whole grid; returns (max J, max d, min d, delta) of the grid."""
+        self.slab.sweep(alpha)
+        self.exchange()
+        st = np.asarray(self.slab.stats(), dtype=np.float64)
+        if self.world > 1:
+            t = self.torch.tensor([st[0], st[1], -st[2]], dtype=self.torch.float64)
+            dev = getattr(self.slab, "dev", None)
+            if dev is not None:
+                t = t.to(dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            t = t.cpu().numpy()
+            st = np.array([t[0], t[1], -t[2]])
+        self.k += 1
+        return float(st[0]), float(st[1]), float(st[2]), float(max(abs(st[1]), abs(st[2])))
+
+    def run(self, max_sweeps, alpha=1.0, tol=-1.0):
+        """compute_steps / solve_bellman_equation semantics (dynamicprogramming.py:265-314)."""
+        out = None
+        for _ in range(max_sweeps):
+            out = self.sweep(alpha)
+            if tol >= 0 and out[3] <= tol:
+                break
+        return out
+
+    def gather(self):
+        """J and pi of the whole grid on every rank (host arrays)."""
+        J, pi = self.slab.owned_J(), self.slab.owned_pi()
+        if self.world == 1:
+            return J, pi
+        objs = [None] * self.world
+        self.dist.all_gather_object(objs, (J, pi))
+        return np.concatenate([o[0] for o in objs]), np.concatenate([o[1] for o in objs])

@@ -1,0 +1,82 @@
+"""bench.py for N > 1: one process per GPU (torchrun), axis-0 slabs, halo exchange over RCCL."""
+import contextlib
+import io
+import json
+import os
+import time
+
+import numpy as np
+
+
+def run(args):
+    import torch
+    import torch.distributed as dist
+    from pyro_amd import configs, parallel
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    name = args.workload or "c3"
+    steps = args.steps if args.steps is not None else 20
+    warmup = args.warmup if args.warmup is not None else 2
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg = configs.build(name)
+    g = cfg["grid_sys"]
+    N, A = g.nodes_n, g.actions_n
+    w = 4 if cfg["dtype"] == "float32" else 8
+
+    # single-GPU reference of the SAME workload on rank 0 (strong-scaling denominator)
+    one_gpu = None
+    if rank == 0 and not args.no_cpu:
+        from pyro_amd.planning import dynamicprogramming
+        with contextlib.redirect_stdout(io.StringIO()):
+            dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, cfg["cf"], dtype=cfg["dtype"], device=local)
+        p = dp._p
+        p.sweep(2, 1.0, -1.0)
+        p.synchronize()
+        t0 = time.perf_counter()
+        p.sweep(max(3, steps // 4), 1.0, -1.0)
+        p.synchronize()
+        one_gpu = N * A * max(3, steps // 4) / (time.perf_counter() - t0)
+        p.close()
+        del dp
+
+    vi = parallel.ShardedValueIteration(g, cfg["cf"], dist, dtype=cfg["dtype"], device=local)
+    for _ in range(warmup):
+        vi.sweep(1.0)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st = vi.sweep(1.0)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        pbytes = 1 if A <= 256 else 2
+        alg = N * (2 * w + pbytes)
+        out = {
+            "metric": "vi_state_action_cell_updates_per_sec", "value": N * A * steps / dt, "unit": "cells/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if w == 4 else "f64", "data": "synthetic",
+            "config": {"workload": "%s: %s" % (cfg["name"], cfg["description"]), "nodes": N, "actions": A,
+                       "cells_per_sweep": N * A, "dt": g.dt, "alpha": 1.0,
+                       "parallelism": "axis-0 slabs x%d, halo %d rows, %s" % (world, vi.halo, "p2p send/recv" if vi.p2p else "all-gather")},
+            "sweeps_per_sec": steps / dt,
+            "roofline": {"bound": "hbm", "achieved": alg * steps / dt / 1e9, "peak": 8000.0 * world, "unit": "GB/s",
+                         "frac": alg * steps / dt / 1e9 / (8000.0 * world), "traffic": None,
+                         "note": "whole-step rate incl. halo exchange; per-kernel figures are in the N=1 line"},
+            "value_1gpu_same_workload": one_gpu,
+            "strong_scaling_speedup": (N * A * steps / dt) / one_gpu if one_gpu else None,
+            "last_stats": list(st), "kernel_path": vi.slab.describe(),
+        }
+        print(json.dumps(out))
+    dist.destroy_process_group()

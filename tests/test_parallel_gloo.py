@@ -1,0 +1,131 @@
+"""
+The multi-rank path (slab partition + halo exchange + statistics all-reduce) on CPU: two processes,
+`gloo` backend, the oracle as the per-slab compute (the product's HipSlab needs a GPU; the exchange
+logic in pyro_amd/parallel.py is the same).  Rows outside a rank's stored slab are NaN, so a halo
+that is too small, or a wrong exchange, poisons the result.
+"""
+import contextlib
+import io
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import vi_oracle as O
+
+
+class OracleSlab:
+    def __init__(self, grid_sys, cost, dtype, rows, halo, device):
+        import torch
+        s = grid_sys.sys
+        dyn_id, params = s.device_dynamics()
+        self.p = O.Problem(grid_sys.x_level, grid_sys.u_level, grid_sys.dt, dyn_id, np.array(params), cost["Q"], cost["R"],
+                           cost["S"], cost["xbar"], cost["ubar"], cost["INF"], cost["EPS"])
+        n0 = self.p.dims[0]
+        self.rows = rows
+        self.store_rows = (max(0, rows[0] - halo), min(n0, rows[1] + halo))
+        self.plane = self.p.nodes_n // n0
+        self.buf = [np.full(self.p.nodes_n, np.nan), np.full(self.p.nodes_n, np.nan)]
+        self.t = [torch.from_numpy(b) for b in self.buf]
+        self.cur = 0
+        self.ids = np.arange(rows[0] * self.plane, rows[1] * self.plane)
+        self.pi = np.zeros(len(self.ids), dtype=np.int64)
+        self._st = None
+
+    def terminal_cost(self):
+        a, b = self.store_rows[0] * self.plane, self.store_rows[1] * self.plane
+        self.buf[self.cur][a:b] = O.terminal_cost(self.p)[a:b]
+
+    def sweep(self, alpha):
+        Jc = self.buf[self.cur]
+        Jn, self.pi = O.sweep(self.p, Jc, alpha, ids=self.ids)
+        nxt = self.buf[self.cur ^ 1]
+        nxt[:] = np.nan
+        nxt[self.ids] = Jn
+        d = Jn - Jc[self.ids]
+        self._st = np.array([Jn.max(), d.max(), d.min()])
+        self.cur ^= 1
+
+    def stats(self):
+        return self._st
+
+    def rows_view(self, row0, nrows):
+        return self.t[self.cur][row0 * self.plane:(row0 + nrows) * self.plane]
+
+    def owned_J(self):
+        return self.buf[self.cur][self.ids].copy()
+
+    def owned_pi(self):
+        return self.pi
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(case):
+    from pyro_amd import configs
+    with contextlib.redirect_stdout(io.StringIO()):
+        return configs.build(case)
+
+
+def _worker(rank, world, port, case, sweeps, halo, out):
+    import torch.distributed as dist
+    from pyro_amd import parallel
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        cfg = _build(case)
+        vi = parallel.ShardedValueIteration(cfg["grid_sys"], cfg["cf"], dist, dtype="float64", slab_factory=OracleSlab,
+                                            halo=halo)
+        stats = [vi.sweep(1.0) for _ in range(sweeps)]
+        J, pi = vi.gather()
+        if rank == 0:
+            np.savez(out, J=J, pi=pi, stats=np.array(stats), p2p=vi.p2p, halo=vi.halo)
+    finally:
+        dist.destroy_process_group()
+
+
+def _reference(case, sweeps):
+    cfg = _build(case)
+    g, cf, s = cfg["grid_sys"], cfg["cf"], cfg["sys"]
+    dyn_id, params = s.device_dynamics()
+    p = O.Problem(g.x_level, g.u_level, g.dt, dyn_id, np.array(params), cf.Q, cf.R, cf.S, cf.xbar, cf.ubar, cf.INF, cf.EPS)
+    J = O.terminal_cost(p)
+    stats = []
+    for _ in range(sweeps):
+        Jn, pi = O.sweep(p, J)
+        st, delta = O.sweep_stats(Jn, J)
+        stats.append(list(st) + [delta])
+        J = Jn
+    return J, pi, np.array(stats)
+
+
+@pytest.mark.parametrize("case,world,halo", [
+    ("pendulum:41,21:5:float64", 2, None),        # neighbour exchange (halo 2 rows < slab)
+    ("pendulum:12,31:5:float64", 3, 5),           # slabs thinner than the halo -> all-gather fall-back
+    ("cartpole:9,7,9,7:3:float64", 2, None),      # 4-D
+])
+def test_sharded_sweeps_equal_single_process(tmp_path, case, world, halo):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "res.npz")
+    sweeps = 5
+    mp.spawn(_worker, args=(world, _free_port(), case, sweeps, halo, out), nprocs=world, join=True)
+    r = np.load(out)
+    J, pi, stats = _reference(case, sweeps)
+    assert not np.isnan(r["J"]).any()
+    assert np.array_equal(r["J"], J)                       # bit-identical: same arithmetic per node
+    assert np.array_equal(r["pi"], pi)
+    np.testing.assert_allclose(r["stats"], stats, rtol=0, atol=0)
+    assert bool(r["p2p"]) == (halo is None)
+
+
+def test_partition_and_halo():
+    from pyro_amd import parallel
+    assert parallel.partition_rows(151, 8) == [(0, 19), (19, 38), (38, 57), (57, 76), (76, 95), (95, 114), (114, 133), (133, 151)]
+    assert parallel.partition_rows(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    cfg = _build("cartpole:151,5,5,5:3:float32")
+    # C4 halo = ceil(2*pi*0.05 / (4*pi/150)) + 1 = ceil(3.75) + 1 = 5
+    assert parallel.halo_rows(cfg["grid_sys"]) == 5
