@@ -59,8 +59,24 @@ struct Ctrl {
     int done;      // set by finalize when delta <= tol
     int k_done;    // sweeps executed in the current batch
     int halo_err;  // a gather fell outside the stored rows
-    int pad;
+    unsigned ticket;  // shards that finished the current sweep
     int dbg[12];   // PVI_CHECK_BOUNDS builds: first out-of-range gather
+    unsigned shard_ticket[64];  // workgroups of shard s (blockIdx.x % 64 == s) that finished
+};
+
+// The three sweep statistics are reduced through device-scope atomicMax.  One address sustains only
+// ~80 atomics/us, so every sweep owns 64 shards x 4 words and a workgroup uses shard blockIdx.x % 64.
+#define STAT_SHARDS 64
+#define STAT_WORDS (STAT_SHARDS * 4)
+
+// per-launch control block of a sweep kernel
+struct SweepCtl {
+    Ctrl* ctrl;
+    unsigned long long* slot;  // this sweep's three encoded statistics
+    double* result;            // [4] (max J, dmax, dmin, delta) written by the last workgroup
+    double tol;                // stop criterion (dynamicprogramming.py:305), < 0: never
+    int k;                     // sweep index inside the batch
+    unsigned nblocks;
 };
 
 // order-preserving encoding of doubles for integer atomicMax
@@ -338,7 +354,8 @@ __device__ inline void block_stats_at(double* red, double j, double dmax, double
     if (threadIdx.x < 3) {
         double v = red[16 * threadIdx.x];
         for (int w = 1; w < nw; ++w) v = fmax(v, red[16 * threadIdx.x + w]);
-        atomicMax(&slot[threadIdx.x], enc_f64(v));
+        const unsigned long long old = atomicMax(&slot[4 * (blockIdx.x & (STAT_SHARDS - 1)) + threadIdx.x], enc_f64(v));
+        asm volatile("" ::"v"(old));  // consume the return value: the atomic has been performed
     }
 }
 
@@ -357,7 +374,51 @@ __device__ inline void block_stats(double j, double dmax, double ndmin, unsigned
     if (threadIdx.x < 3) {
         double v = red[threadIdx.x][0];
         for (int w = 1; w < nw; ++w) v = fmax(v, red[threadIdx.x][w]);
-        atomicMax(&slot[threadIdx.x], enc_f64(v));
+        const unsigned long long old = atomicMax(&slot[4 * (blockIdx.x & (STAT_SHARDS - 1)) + threadIdx.x], enc_f64(v));
+        asm volatile("" ::"v"(old));  // consume the return value: the atomic has been performed
+    }
+}
+
+// finalize_backward_step (dynamicprogramming.py:247-261) without a second launch: the workgroup that
+// draws the last ticket folds the three statistics, records them and decides the stop.  The slot
+// values are read back through atomic RMWs (performed at the device coherence point, like the
+// atomicMax that produced them); results / done are consumed by the NEXT kernel, after the boundary.
+__device__ inline void sweep_finish(const SweepCtl& sc) {
+    // No fence: a release fence would write back this XCD's dirty L2 lines (all of J_{k+1}) once per
+    // workgroup.  The statistics travel in device-scope atomics only; block_stats consumes their
+    // return values, so they have been performed before the barrier below is passed.
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        int last = 0;
+        if (threadIdx.x == 0) {
+            const unsigned sh = blockIdx.x & (STAT_SHARDS - 1);
+            const unsigned in_shard = (sc.nblocks - sh + STAT_SHARDS - 1) / STAT_SHARDS;
+            if (atomicAdd(&sc.ctrl->shard_ticket[sh], 1u) == in_shard - 1u) {
+                sc.ctrl->shard_ticket[sh] = 0u;
+                const unsigned nshards = sc.nblocks < STAT_SHARDS ? sc.nblocks : STAT_SHARDS;
+                last = atomicAdd(&sc.ctrl->ticket, 1u) == nshards - 1u;
+            }
+        }
+        last = __shfl(last, 0, 64);
+        if (last) {  // wave 0 of the last workgroup folds the shards: lane = shard
+            const int l = threadIdx.x;
+            double v0 = dec_f64(atomicMax(&sc.slot[4 * l + 0], 0ull));
+            double v1 = dec_f64(atomicMax(&sc.slot[4 * l + 1], 0ull));
+            double v2 = dec_f64(atomicMax(&sc.slot[4 * l + 2], 0ull));
+            v0 = wave_max(v0);
+            v1 = wave_max(v1);
+            v2 = wave_max(v2);
+            if (l == 0) {
+                const double dmin = -v2, delta = fmax(fabs(v1), fabs(dmin));
+                sc.result[0] = v0;
+                sc.result[1] = v1;
+                sc.result[2] = dmin;
+                sc.result[3] = delta;
+                sc.ctrl->k_done = sc.k + 1;
+                if (sc.tol >= 0.0 && delta <= sc.tol) sc.ctrl->done = 1;
+                sc.ctrl->ticket = 0u;
+            }
+        }
     }
 }
 
@@ -369,19 +430,8 @@ __global__ void k_reset_stats(unsigned long long* slots, int n) {
 __global__ void k_begin_batch(Ctrl* ctrl) {
     ctrl->done = 0;
     ctrl->k_done = 0;
-}
-
-// finalize_backward_step (dynamicprogramming.py:247-261): delta = max(|dmax|, |dmin|)
-__global__ void k_finalize(Ctrl* ctrl, const unsigned long long* slots, double* results, int k, double tol) {
-    if (ctrl->done) return;
-    const double mj = dec_f64(slots[3 * k]), dmax = dec_f64(slots[3 * k + 1]), dmin = -dec_f64(slots[3 * k + 2]);
-    const double delta = fmax(fabs(dmax), fabs(dmin));
-    results[4 * k] = mj;
-    results[4 * k + 1] = dmax;
-    results[4 * k + 2] = dmin;
-    results[4 * k + 3] = delta;
-    ctrl->k_done = k + 1;
-    if (tol >= 0.0 && delta <= tol) ctrl->done = 1;
+    ctrl->ticket = 0u;
+    for (int i = 0; i < STAT_SHARDS; ++i) ctrl->shard_ticket[i] = 0u;
 }
 
 // =================================================================================================
@@ -426,11 +476,10 @@ __global__ void k_terminal_cost(DevP P, REAL* __restrict__ J) {
 // =================================================================================================
 template <int DYN, typename REAL, typename PI_T>
 __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ Jin, REAL* __restrict__ Jout,
-                                               PI_T* __restrict__ pi, double alpha, Ctrl* ctrl,
-                                               unsigned long long* slot) {
+                                               PI_T* __restrict__ pi, double alpha, SweepCtl sc) {
     using D = Dyn<DYN>;
     constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M;
-    if (ctrl->done) return;
+    if (sc.ctrl->done) return;
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
     double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
@@ -472,7 +521,7 @@ __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ 
 #pragma unroll
             for (int i = 1; i < DOF; ++i) base += ci[i] * P.strd[i];
         }
-        if (halo_bad) atomicOr(&ctrl->halo_err, 1);
+        if (halo_bad) atomicOr(&sc.ctrl->halo_err, 1);
 
         double tr[4];
         D::trig_from_tables(P, idx, tr);
@@ -520,7 +569,8 @@ __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ 
         st_dmax = d;
         st_ndmin = -d;
     }
-    block_stats(st_j, st_dmax, st_ndmin, slot);
+    block_stats(st_j, st_dmax, st_ndmin, sc.slot);
+    sweep_finish(sc);
 }
 
 
@@ -548,10 +598,10 @@ struct FastP {
 template <int DYN, typename PI_T, bool UNIFORM>
 __global__ __launch_bounds__(256) void k_sweep_fast(DevP P, FastP F, const float* __restrict__ Jin,
                                                     float* __restrict__ Jout, PI_T* __restrict__ pi, float alpha,
-                                                    Ctrl* ctrl, unsigned long long* slot) {
+                                                    SweepCtl sc) {
     using D = Dyn<DYN>;
     constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M, NP = 1 << DOF;
-    if (ctrl->done) return;
+    if (sc.ctrl->done) return;
     const int split = UNIFORM ? 1 : (1 << F.lsplit);
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long o = UNIFORM ? t : (t >> F.lsplit);
@@ -594,7 +644,7 @@ __global__ __launch_bounds__(256) void k_sweep_fast(DevP P, FastP F, const float
         if (pos_in) {
             int r0 = ci[0];
             if (r0 < P.store_begin || r0 + 1 >= P.store_end) {
-                atomicOr(&ctrl->halo_err, 1);
+                atomicOr(&sc.ctrl->halo_err, 1);
                 r0 = min(max(r0, P.store_begin), P.store_end - 2);
             }
             ci[0] = r0 - P.store_begin;
@@ -724,7 +774,8 @@ __global__ __launch_bounds__(256) void k_sweep_fast(DevP P, FastP F, const float
         st_dmax = d;
         st_ndmin = -d;
     }
-    block_stats(st_j, st_dmax, st_ndmin, slot);
+    block_stats(st_j, st_dmax, st_ndmin, sc.slot);
+    sweep_finish(sc);
 }
 
 
@@ -858,14 +909,13 @@ __device__ __forceinline__ void run_actions(const DevP& P, const float4* __restr
 template <int DYN, typename PI_T, bool UNIFORM>
 __global__ __launch_bounds__(1024) void k_sweep_tile(DevP P, TileP F, const float4* __restrict__ actp,
                                                      const float* __restrict__ Jin, float* __restrict__ Jout,
-                                                     PI_T* __restrict__ pi, float alpha, Ctrl* ctrl,
-                                                     unsigned long long* slot) {
+                                                     PI_T* __restrict__ pi, float alpha, SweepCtl sc) {
     using D = Dyn<DYN>;
     constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M, NP = 1 << DOF;
     extern __shared__ __attribute__((aligned(16))) float tile[];
     __shared__ int s_box[2 * N][16];
     __shared__ int s_win[2 * N];
-    if (ctrl->done) return;
+    if (sc.ctrl->done) return;
     const int split = UNIFORM ? 1 : (1 << F.lsplit);
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long o = UNIFORM ? t : (t >> F.lsplit);
@@ -916,7 +966,7 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(DevP P, TileP F, const floa
         if (pin) {
             int r0 = ci[0];
             if (r0 < P.store_begin || r0 + 1 >= P.store_end) {
-                atomicOr(&ctrl->halo_err, 1);
+                atomicOr(&sc.ctrl->halo_err, 1);
                 r0 = min(max(r0, P.store_begin), P.store_end - 2);
             }
             ci[0] = r0 - P.store_begin;
@@ -1060,18 +1110,18 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(DevP P, TileP F, const floa
     if (live) {
         if (use_lds)
             run_actions<DYN, UNIFORM, false>(P, actp, F.guard, tile, L, idx, part, split, alpha, INF_F, best, arg,
-                                             need_exact, ctrl->dbg);
+                                             need_exact, sc.ctrl->dbg);
         else
             run_actions<DYN, UNIFORM, false>(P, actp, F.guard, Jin, L, idx, part, split, alpha, INF_F, best, arg,
-                                             need_exact, ctrl->dbg);
+                                             need_exact, sc.ctrl->dbg);
         if (need_exact) {
             bool dummy = false;
             if (use_lds)
                 run_actions<DYN, false, true>(P, actp, F.guard, tile, L, idx, part, split, alpha, INF_F, best, arg,
-                                              dummy, ctrl->dbg);
+                                              dummy, sc.ctrl->dbg);
             else
                 run_actions<DYN, false, true>(P, actp, F.guard, Jin, L, idx, part, split, alpha, INF_F, best, arg,
-                                              dummy, ctrl->dbg);
+                                              dummy, sc.ctrl->dbg);
         }
     }
     if (!UNIFORM) {
@@ -1093,7 +1143,8 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(DevP P, TileP F, const floa
         st_dmax = d;
         st_ndmin = -d;
     }
-    block_stats(st_j, st_dmax, st_ndmin, slot);
+    block_stats(st_j, st_dmax, st_ndmin, sc.slot);
+    sweep_finish(sc);
 }
 
 #include "sweep_lean.inc"
@@ -1106,8 +1157,8 @@ template <int N, typename REAL, typename PI_T>
 __global__ __launch_bounds__(256) void k_sweep_table(DevP P, const double* __restrict__ xnext,
                                                      const double* __restrict__ Gt, const REAL* __restrict__ Jin,
                                                      REAL* __restrict__ Jout, PI_T* __restrict__ pi, double alpha,
-                                                     Ctrl* ctrl, unsigned long long* slot) {
-    if (ctrl->done) return;
+                                                     SweepCtl sc) {
+    if (sc.ctrl->done) return;
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
     double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
@@ -1130,7 +1181,7 @@ __global__ __launch_bounds__(256) void k_sweep_table(DevP P, const double* __res
                 y[d] = (v - P.lev[d][ci[d]]) / (P.lev[d][ci[d] + 1] - P.lev[d][ci[d]]);
                 int c = ci[d];
                 if (d == 0) {
-                    if (inb && (c < P.store_begin || c + 1 >= P.store_end)) atomicOr(&ctrl->halo_err, 1);
+                    if (inb && (c < P.store_begin || c + 1 >= P.store_end)) atomicOr(&sc.ctrl->halo_err, 1);
                     c = min(max(c, P.store_begin), P.store_end - 2) - P.store_begin;
                 }
                 b += c * P.strd[d];
@@ -1154,7 +1205,8 @@ __global__ __launch_bounds__(256) void k_sweep_table(DevP P, const double* __res
         st_dmax = d;
         st_ndmin = -d;
     }
-    block_stats(st_j, st_dmax, st_ndmin, slot);
+    block_stats(st_j, st_dmax, st_ndmin, sc.slot);
+    sweep_finish(sc);
 }
 
 // =================================================================================================
@@ -1725,7 +1777,7 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
     h->dev_allocs.push_back(p);
     h->ctrl = (Ctrl*)p;
     HCHK(hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream));
-    HCHK(hipMalloc(&p, sizeof(unsigned long long) * 3 * MAX_BATCH));
+    HCHK(hipMalloc(&p, sizeof(unsigned long long) * STAT_WORDS * MAX_BATCH));
     h->dev_allocs.push_back(p);
     h->slots = (unsigned long long*)p;
     HCHK(hipMalloc(&p, sizeof(double) * 4 * MAX_BATCH));
@@ -1897,14 +1949,16 @@ extern "C" int pvi_device_pi(pvi_handle h, void** p) {
 
 // ---- sweep launch -----------------------------------------------------------------------------------
 template <typename REAL, typename PI_T>
-static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st, unsigned long long* slot) {
+static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st, SweepCtl sc) {
     const unsigned g = grid_for(h->owned);
+    sc.nblocks = g;
     const REAL* Jin = (const REAL*)h->J[src];
     REAL* Jout = (REAL*)h->J[src ^ 1];
     PI_T* pi = (PI_T*)h->pi;
     if constexpr (sizeof(REAL) == 4) {
         if (h->lean_ok) {
             const float al = (float)alpha;
+            sc.nblocks = h->lean_grid.x;
 #define LEAN3(DYN, PW, U)                                                                                           \
     {                                                                                                               \
         auto kfn = k_sweep_lean<DYN, PI_T, PW, U>;                                                                  \
@@ -1913,7 +1967,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             h->lean_lds_attr = true;                                                                                \
         }                                                                                                           \
         hipLaunchKernelGGL(kfn, h->lean_grid, h->lean_block, h->lean_lds, st, h->P, h->LP, h->F.act, Jin, Jout, pi, al, \
-                           h->ctrl, slot);                                                                          \
+                           sc);                                                                          \
     }
 #define LEAN2(DYN, PW)         \
     if (h->LP.lsplit == 0)     \
@@ -1945,13 +1999,14 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             const unsigned gf = grid_for(h->owned << h->T.lsplit, blk);
             const size_t lds = (size_t)h->T.lds_floats * 4;
             const float al = (float)alpha;
+            sc.nblocks = gf;
 #define TILE(DYN)                                                                                                 \
     if (h->T.lsplit == 0)                                                                                         \
         hipLaunchKernelGGL((k_sweep_tile<DYN, PI_T, true>), gf, blk, lds, st, h->P, h->T, h->F.act, Jin, Jout, pi, \
-                           al, h->ctrl, slot);                                                                    \
+                           al, sc);                                                                    \
     else                                                                                                          \
         hipLaunchKernelGGL((k_sweep_tile<DYN, PI_T, false>), gf, blk, lds, st, h->P, h->T, h->F.act, Jin, Jout, pi, \
-                           al, h->ctrl, slot);
+                           al, sc);
             switch (h->d.dynamics_id) {
                 case PVI_DYN_PENDULUM: TILE(PVI_DYN_PENDULUM) break;
                 case PVI_DYN_CARTPOLE: TILE(PVI_DYN_CARTPOLE) break;
@@ -1964,13 +2019,12 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         if (h->fast_ok) {
             const unsigned gf = grid_for(h->owned << h->F.lsplit);
             const float al = (float)alpha;
+            sc.nblocks = gf;
 #define FAST(DYN)                                                                                                  \
     if (h->F.lsplit == 0)                                                                                          \
-        hipLaunchKernelGGL((k_sweep_fast<DYN, PI_T, true>), gf, 256, 0, st, h->P, h->F, Jin, Jout, pi, al, h->ctrl, \
-                           slot);                                                                                  \
+        hipLaunchKernelGGL((k_sweep_fast<DYN, PI_T, true>), gf, 256, 0, st, h->P, h->F, Jin, Jout, pi, al, sc);                                                                                  \
     else                                                                                                           \
-        hipLaunchKernelGGL((k_sweep_fast<DYN, PI_T, false>), gf, 256, 0, st, h->P, h->F, Jin, Jout, pi, al, h->ctrl, \
-                           slot);
+        hipLaunchKernelGGL((k_sweep_fast<DYN, PI_T, false>), gf, 256, 0, st, h->P, h->F, Jin, Jout, pi, al, sc);
             switch (h->d.dynamics_id) {
                 case PVI_DYN_PENDULUM: FAST(PVI_DYN_PENDULUM) break;
                 case PVI_DYN_CARTPOLE: FAST(PVI_DYN_CARTPOLE) break;
@@ -1984,30 +2038,30 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     switch (h->d.dynamics_id) {
         case PVI_DYN_PENDULUM:
             hipLaunchKernelGGL((k_sweep<PVI_DYN_PENDULUM, REAL, PI_T>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha,
-                               h->ctrl, slot);
+                               sc);
             break;
         case PVI_DYN_CARTPOLE:
             hipLaunchKernelGGL((k_sweep<PVI_DYN_CARTPOLE, REAL, PI_T>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha,
-                               h->ctrl, slot);
+                               sc);
             break;
         case PVI_DYN_TWOLINK:
             hipLaunchKernelGGL((k_sweep<PVI_DYN_TWOLINK, REAL, PI_T>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha,
-                               h->ctrl, slot);
+                               sc);
             break;
         case PVI_DYN_TABLE:
             if (!h->d_xnext || !h->d_G) return fail(PVI_ESTATE, "tier B sweep before pvi_set_tables");
             switch (h->P.n) {
                 case 2:
                     hipLaunchKernelGGL((k_sweep_table<2, REAL, PI_T>), g, 256, 0, st, h->P, h->d_xnext, h->d_G, Jin,
-                                       Jout, pi, alpha, h->ctrl, slot);
+                                       Jout, pi, alpha, sc);
                     break;
                 case 3:
                     hipLaunchKernelGGL((k_sweep_table<3, REAL, PI_T>), g, 256, 0, st, h->P, h->d_xnext, h->d_G, Jin,
-                                       Jout, pi, alpha, h->ctrl, slot);
+                                       Jout, pi, alpha, sc);
                     break;
                 default:
                     hipLaunchKernelGGL((k_sweep_table<4, REAL, PI_T>), g, 256, 0, st, h->P, h->d_xnext, h->d_G, Jin,
-                                       Jout, pi, alpha, h->ctrl, slot);
+                                       Jout, pi, alpha, sc);
                     break;
             }
             break;
@@ -2018,12 +2072,19 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     return PVI_OK;
 }
 
-static int launch_sweep(pvi_problem* h, int src, double alpha, hipStream_t st, unsigned long long* slot) {
+static int launch_sweep(pvi_problem* h, int src, double alpha, hipStream_t st, int k, double tol) {
+    SweepCtl sc;
+    sc.ctrl = h->ctrl;
+    sc.slot = h->slots + (size_t)STAT_WORDS * k;
+    sc.result = h->results + 4 * k;
+    sc.tol = tol;
+    sc.k = k;
+    sc.nblocks = 0;
     if (h->d.dtype == PVI_F64)
-        return h->pi_size == 1 ? launch_sweep_t<double, unsigned char>(h, src, alpha, st, slot)
-                               : launch_sweep_t<double, unsigned short>(h, src, alpha, st, slot);
-    return h->pi_size == 1 ? launch_sweep_t<float, unsigned char>(h, src, alpha, st, slot)
-                           : launch_sweep_t<float, unsigned short>(h, src, alpha, st, slot);
+        return h->pi_size == 1 ? launch_sweep_t<double, unsigned char>(h, src, alpha, st, sc)
+                               : launch_sweep_t<double, unsigned short>(h, src, alpha, st, sc);
+    return h->pi_size == 1 ? launch_sweep_t<float, unsigned char>(h, src, alpha, st, sc)
+                           : launch_sweep_t<float, unsigned short>(h, src, alpha, st, sc);
 }
 
 extern "C" int pvi_sweep(pvi_handle h, int32_t max_sweeps, double alpha, double tol, double* stats,
@@ -2038,15 +2099,14 @@ extern "C" int pvi_sweep(pvi_handle h, int32_t max_sweeps, double alpha, double 
     bool stopped = false;
     while (done_total < max_sweeps && !stopped) {
         const int nb = max_sweeps - done_total < MAX_BATCH ? max_sweeps - done_total : MAX_BATCH;
-        hipLaunchKernelGGL(k_reset_stats, grid_for(3 * nb), 256, 0, h->stream, h->slots, 3 * nb);
+        hipLaunchKernelGGL(k_reset_stats, grid_for(STAT_WORDS * nb), 256, 0, h->stream, h->slots, STAT_WORDS * nb);
         hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, h->stream, h->ctrl);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(h->ev0, h->stream));
         int src = h->cur;
         for (int k = 0; k < nb; ++k) {
-            int rc = launch_sweep(h, src, alpha, h->stream, h->slots + 3 * k);
+            int rc = launch_sweep(h, src, alpha, h->stream, k, tol);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_finalize, 1, 1, 0, h->stream, h->ctrl, h->slots, h->results, k, tol);
             src ^= 1;
         }
         HIPCHK(hipGetLastError());
@@ -2084,9 +2144,9 @@ extern "C" int pvi_sweep_async(pvi_handle h, double alpha, void* stream) {
     if (!h) return fail(PVI_EINVAL, "NULL handle");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    hipLaunchKernelGGL(k_reset_stats, 1, 64, 0, st, h->slots, 3);
+    hipLaunchKernelGGL(k_reset_stats, 1, STAT_WORDS, 0, st, h->slots, STAT_WORDS);
     hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, st, h->ctrl);
-    int rc = launch_sweep(h, h->cur, alpha, st, h->slots);
+    int rc = launch_sweep(h, h->cur, alpha, st, 0, -1.0);
     if (rc) return rc;
     h->cur ^= 1;
     return PVI_OK;
@@ -2096,15 +2156,15 @@ extern "C" int pvi_sweep_stats(pvi_handle h, double stats3[3], void* stream) {
     if (!h || !stats3) return fail(PVI_EINVAL, "NULL argument");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    unsigned long long raw[3];
+    double res[4];
     Ctrl c;
-    HIPCHK(hipMemcpyAsync(raw, h->slots, sizeof(raw), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(res, h->results, sizeof(res), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&c, h->ctrl, sizeof(c), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (c.halo_err) return fail(PVI_EHALO, "a gather left the stored rows: halo too small");
-    stats3[0] = dec_f64(raw[0]);
-    stats3[1] = dec_f64(raw[1]);
-    stats3[2] = -dec_f64(raw[2]);
+    stats3[0] = res[0];
+    stats3[1] = res[1];
+    stats3[2] = res[2];
     return PVI_OK;
 }
 
