@@ -51,14 +51,19 @@ def cpu_baseline(cfg, budget_s=20.0):
     cores = CO.max_threads()
     J = c.terminal_cost()
     cells_per_sweep = p.nodes_n * p.actions_n
-    # calibrate on a slice
-    n_probe = max(1, min(p.nodes_n, 200000 // max(1, p.actions_n // 8)))
-    t0 = time.perf_counter()
-    c.sweep(J, 1.0, 0, n_probe)
-    rate = n_probe * p.actions_n / max(time.perf_counter() - t0, 1e-9)
+    # calibrate on a slice that runs for at least ~0.3 s (thread start-up would bias a shorter probe)
+    n_probe = max(1, min(p.nodes_n, 4096))
+    while True:
+        t0 = time.perf_counter()
+        c.sweep(J, 1.0, 0, n_probe)
+        el = time.perf_counter() - t0
+        if el >= 0.3 or n_probe >= p.nodes_n:
+            break
+        n_probe = min(p.nodes_n, n_probe * 4)
+    rate = n_probe * p.actions_n / max(el, 1e-9)
     sweep_s = cells_per_sweep / rate
     if sweep_s <= budget_s / 2:
-        nsweeps = int(max(1, min(10, budget_s // sweep_s)))
+        nsweeps = int(max(1, min(50, budget_s // sweep_s)))
         t0 = time.perf_counter()
         for _ in range(nsweeps):
             J, _ = c.sweep(J, 1.0)
