@@ -342,3 +342,141 @@ def test_class_surface_generic_system_uses_table_tier():
         J, pi, _ = O.sweep_lut(grid.x_level, grid.x_next_table, dp.G, J)
     assert relerr(dp.J, J) < 1e-13
     assert np.array_equal(dp.pi, pi)
+
+
+# ------------------------------------------------------------------------------------- f32 kernel variants
+@pytest.mark.parametrize("name", ["pendulum_demo_51x51x9", "cartpole_11p4x5", "twolink_11p4x3x3", "doublependulum_13x11x13x11x3x3"])
+def test_f32_kernel_variants_agree(name, monkeypatch):
+    """lean (LDS window, precomputed coefficients), tile, fast and action-split variants compute the same
+    recursion; they may differ in float32 summation order only."""
+    g = load(name)
+    p = oracle_problem(g, *CASES[name])
+    alpha = float(g["alpha"]) if "alpha" in g.files else 1.0
+    nsw = 6
+    ref = O.terminal_cost(p)
+    for _ in range(nsw):
+        ref, _ = O.sweep(p, ref, alpha)
+    outs = {}
+    for tag, env in [("lean", {}), ("lean_split", {"PVI_LSPLIT": "2"}), ("lean_nosplit", {"PVI_LSPLIT": "0"}),
+                     ("tile", {"PVI_NO_LEAN": "1"}), ("fast", {"PVI_NO_LEAN": "1", "PVI_NO_TILE": "1"}),
+                     ("exact32", {"PVI_NO_FAST": "1"})]:
+        for k in ("PVI_LSPLIT", "PVI_NO_LEAN", "PVI_NO_TILE", "PVI_NO_FAST"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        h = native_problem(p, dtype="float32")
+        desc = h.describe()
+        h.terminal_cost()
+        h.sweep(nsw, alpha, -1.0)
+        outs[tag] = (h.get_J(), h.get_pi(), desc)
+        h.close()
+    for tag, (J, pi, desc) in outs.items():
+        assert relerr(J, ref) <= REL_F32, (tag, desc)
+        assert relerr(J, outs["exact32"][0]) <= 2e-6, (tag, desc)
+    assert "path=lean" in outs["lean"][2] or "note=" in outs["lean"][2]
+    assert "path=tile" in outs["tile"][2] and "path=fast" in outs["fast"][2]
+
+
+# ------------------------------------------------------------------------------------- full size (BASELINE configs[1])
+def _c2():
+    from pyro_amd import configs
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg = configs.build("c2")
+    s, g, cf = cfg["sys"], cfg["grid_sys"], cfg["cf"]
+    dyn_id, params = s.device_dynamics()
+    p = O.Problem(g.x_level, g.u_level, g.dt, dyn_id, np.array(params), cf.Q, cf.R, cf.S, cf.xbar, cf.ubar,
+                  float(cf.INF), float(cf.EPS))
+    return p
+
+
+def test_full_size_c2_against_c_oracle():
+    """1001 x 1001 x 51 (51.1 M cells per sweep): three sweeps, f32 within 1e-5 and f64 within 1e-12 of the
+    oracle's C twin (itself bit-identical to the NumPy oracle)."""
+    from oracle import c_oracle as CO
+    p = _c2()
+    c = CO.CProblem(p)
+    J = c.terminal_cost()
+    for _ in range(3):
+        J, pi = c.sweep(J)
+    for dtype, tol in (("float32", REL_F32), ("float64", 1e-12)):
+        h = native_problem(p, dtype=dtype)
+        h.terminal_cost()
+        stats, n = h.sweep(3, 1.0, -1.0)
+        Jg, pig = h.get_J(), h.get_pi()
+        assert relerr(Jg, J) <= tol
+        assert (pig != pi).mean() < (1e-9 if dtype == "float64" else 5e-3)
+        assert abs(stats[-1, 0] - J.max()) <= 1e-5 * J.max()
+        h.close()
+
+
+def test_full_size_c2_bellman_operator_properties():
+    """Size-independent properties of the backup T at full size (f32 production path):
+    monotone (J <= J' => TJ <= TJ'), constant shift (T(J+c) <= TJ + alpha*c, equality where the minimiser
+    stays in bounds), and the device-side stop equals the host-side rule."""
+    p = _c2()
+    h = native_problem(p, dtype="float32")
+    h.terminal_cost()
+    h.sweep(40, 1.0, -1.0)
+    J = h.get_J()
+    h.sweep(1, 1.0, -1.0)
+    TJ = h.get_J()
+    c = 2.5
+    h.set_J(J + c)
+    h.sweep(1, 1.0, -1.0)
+    TJc = h.get_J()
+    assert (TJc >= TJ - 1e-3).all()                      # monotone
+    assert (TJc <= TJ + c + 1e-3).all()                  # shift upper bound
+    # in-bounds actions shift by exactly alpha*c (weights sum to 1), out-of-bounds ones stay at INF:
+    # T(J+c) = min(TJ + c, INF) wherever INF is not already the minimum
+    inside = TJ < float(p.INF) - c - 1.0
+    assert inside.sum() > 100000
+    assert np.abs(TJc[inside] - TJ[inside] - c).max() < 2e-3
+    # stop rule: first sweep with delta <= tol ends the batch, later launches are no-ops
+    h.set_J(J)
+    stats, n = h.sweep(1000, 1.0, 0.3)
+    assert 1 <= n < 1000 and stats[n - 1, 3] <= 0.3 and (n == 1 or stats[n - 2, 3] > 0.3)
+    h.close()
+
+
+_WORLD1 = r"""
+import contextlib, io, sys
+import numpy as np
+import torch                      # torch first: it brings its own HIP runtime, libpyrovi then shares it
+import torch.distributed as dist
+sys.path.insert(0, %r)
+from pyro_amd import configs, parallel
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1)
+with contextlib.redirect_stdout(io.StringIO()):
+    cfg = configs.build("cartpole:21,21,21,21:7:float32")
+vi = parallel.ShardedValueIteration(cfg["grid_sys"], cfg["cf"], dist, dtype="float32")
+for _ in range(5):
+    st = vi.sweep(1.0)
+J, pi = vi.gather()
+from pyro_amd.planning import dynamicprogramming
+with contextlib.redirect_stdout(io.StringIO()):
+    dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype="float32")
+stats, _ = dp._p.sweep(5, 1.0, -1.0)
+assert np.array_equal(J, dp._p.get_J()) and np.array_equal(pi, dp._p.get_pi())
+assert np.allclose(st, stats[-1], rtol=1e-12)
+np.save(%r, J)
+dist.destroy_process_group()
+print("WORLD1-OK")
+"""
+
+
+def test_sharded_driver_world1_on_gpu(tmp_path):
+    """pyro_amd.parallel with the product HipSlab (torch buffers handed to the library as ext_J / ext_pi, kernels
+    on torch's stream) at world size 1; checked against the reference golden as well.  Runs in a fresh
+    interpreter because torch must initialise its bundled HIP runtime before libpyrovi is loaded."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = str(tmp_path / "J.npy")
+    r = subprocess.run([sys.executable, "-c", _WORLD1 % (ROOT, out)], capture_output=True, text=True, timeout=900)
+    assert "WORLD1-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    g = load("cartpole_21p4x7")
+    p = oracle_problem(g, O.DYN_CARTPOLE, O.cartpole_consts())
+    J = O.terminal_cost(p)
+    for _ in range(5):
+        J, _ = O.sweep(p, J)
+    assert relerr(np.load(out), J) <= REL_F32
