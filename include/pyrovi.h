@@ -155,9 +155,12 @@ int pvi_synchronize(pvi_handle h);
    Any output pointer may be NULL.  Shapes: x_next [nodes][A][n], masks [nodes][A], G [nodes][A]. */
 int pvi_build_tables(pvi_handle h, int32_t row0, int32_t nrows, double* x_next, uint8_t* x_next_isok,
                      uint8_t* action_isok, double* G);
-/* tier B: host-built tables for arbitrary sys.f / cf.g (dynamics_id == PVI_DYN_TABLE); `ok` is
-   unused by the sweep (G already carries INF) and may be NULL. */
-int pvi_set_tables(pvi_handle h, const double* x_next, const double* G);
+/* tier B: host-built tables for arbitrary sys.f / cf.g (dynamics_id == PVI_DYN_TABLE, desc.INF = cf.INF).
+   ok == NULL : look-up-table semantics, Q = G + alpha*J_interp(x_next) with G already INF on invalid cells
+                (DynamicProgrammingWithLookUpTable, dynamicprogramming.py:564-570);
+   ok != NULL : ok[node][a] = action_isok & x_next_isok; invalid cells cost exactly INF
+                (base class DynamicProgramming.compute_backward_step, dynamicprogramming.py:195-236). */
+int pvi_set_tables(pvi_handle h, const double* x_next, const double* G, const uint8_t* ok);
 
 /* ---- batched dynamics ------------------------------------------------------------------------ */
 /* dX[b] = f(X[b], U[b]) for B states (mechanical.py:238-263); host pointers, float64 */

@@ -65,7 +65,7 @@ SYMBOLS = {
     "pvi_device_pi": (C.c_int, [_h, C.POINTER(C.c_void_p)]),
     "pvi_synchronize": (C.c_int, [_h]),
     "pvi_build_tables": (C.c_int, [_h, C.c_int32, C.c_int32, _dp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), _dp]),
-    "pvi_set_tables": (C.c_int, [_h, _dp, _dp]),
+    "pvi_set_tables": (C.c_int, [_h, _dp, _dp, C.POINTER(C.c_uint8)]),
     "pvi_eval_f": (C.c_int, [C.c_int32, _dp, C.c_int32, C.c_int32, C.c_int64, _dp, _dp, _dp]),
 }
 
@@ -130,7 +130,8 @@ class Problem:
     """Owner of one pvi_handle.  All arrays are host NumPy; see include/pyrovi.h."""
 
     def __init__(self, x_levels, u_levels, x_lb, x_ub, u_lb, u_ub, dt, dtype="float64", dynamics_id=DYN_TABLE,
-                 dyn_params=(), trig=(), cost=None, rows=None, halo=(0, 0), device=0, ext_J=None, ext_pi=None):
+                 dyn_params=(), trig=(), cost=None, rows=None, halo=(0, 0), device=0, ext_J=None, ext_pi=None,
+                 table_inf=0.0):
         L = lib()
         self._keep = []                      # host buffers the descriptor points to
         d = pvi_desc()
@@ -173,6 +174,7 @@ class Problem:
             d.ontarget_check = int(bool(cost.get("ontarget_check", True)))
         else:
             d.cost_id = COST_TABLE
+            d.INF = float(table_inf)
         r0, r1 = (0, self.dims[0]) if rows is None else rows
         d.row_begin, d.row_end, d.halo_lo, d.halo_hi = int(r0), int(r1), int(halo[0]), int(halo[1])
         d.device = int(device)
@@ -281,9 +283,16 @@ class Problem:
             _ptr(g) if G else None))
         return xn, (xo.astype(bool) if xo is not None else None), (ao.astype(bool) if ao is not None else None), g
 
-    def set_tables(self, x_next, G):
+    def set_tables(self, x_next, G, ok=None):
+        """ok=None: look-up-table semantics (INF + alpha*J); ok mask: base-class semantics (exactly INF)."""
         x_next, G = _f64(x_next), _f64(G)
         A = self.actions_n
         if x_next.shape != (self.owned_nodes, A, self.n) or G.shape != (self.owned_nodes, A):
             raise ValueError("table shapes do not match the grid")
-        check(lib().pvi_set_tables(self._h, _ptr(x_next), _ptr(G)))
+        okp = None
+        if ok is not None:
+            ok = np.ascontiguousarray(ok, dtype=np.uint8)
+            if ok.shape != G.shape:
+                raise ValueError("ok mask shape does not match the grid")
+            okp = ok.ctypes.data_as(C.POINTER(C.c_uint8))
+        check(lib().pvi_set_tables(self._h, _ptr(x_next), _ptr(G), okp))

@@ -1155,7 +1155,9 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(DevP P, TileP F, const floa
 // =================================================================================================
 template <int N, typename REAL, typename PI_T>
 __global__ __launch_bounds__(256) void k_sweep_table(DevP P, const double* __restrict__ xnext,
-                                                     const double* __restrict__ Gt, const REAL* __restrict__ Jin,
+                                                     const double* __restrict__ Gt,
+                                                     const unsigned char* __restrict__ okt,
+                                                     const REAL* __restrict__ Jin,
                                                      REAL* __restrict__ Jout, PI_T* __restrict__ pi, double alpha,
                                                      SweepCtl sc) {
     if (sc.ctrl->done) return;
@@ -1193,6 +1195,9 @@ __global__ __launch_bounds__(256) void k_sweep_table(DevP P, const double* __res
                 q = G + alpha_r * Jn;
             else
                 q = fmaf(alpha_r, Jn, G);
+            // base-class semantics (dynamicprogramming.py:195-236): an invalid action / next state costs
+            // exactly INF, not INF + alpha*J as in the look-up-table class (:567)
+            if (okt && !okt[(long long)o * P.A + a]) q = (REAL)P.INF;
             if (a == 0 || q < best) {
                 best = q;
                 arg = a;
@@ -1348,6 +1353,7 @@ struct pvi_problem {
     double* results = nullptr;
     double* d_xnext = nullptr;  // tier B tables
     double* d_G = nullptr;
+    unsigned char* d_ok = nullptr;  // tier B base-class semantics (NULL: LUT semantics)
     double* stage = nullptr;  // f64 staging for up/download
     long long stage_n = 0;
     FastP F;                  // f32 fast path tables
@@ -2052,15 +2058,15 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             if (!h->d_xnext || !h->d_G) return fail(PVI_ESTATE, "tier B sweep before pvi_set_tables");
             switch (h->P.n) {
                 case 2:
-                    hipLaunchKernelGGL((k_sweep_table<2, REAL, PI_T>), g, 256, 0, st, h->P, h->d_xnext, h->d_G, Jin,
+                    hipLaunchKernelGGL((k_sweep_table<2, REAL, PI_T>), g, 256, 0, st, h->P, h->d_xnext, h->d_G, h->d_ok, Jin,
                                        Jout, pi, alpha, sc);
                     break;
                 case 3:
-                    hipLaunchKernelGGL((k_sweep_table<3, REAL, PI_T>), g, 256, 0, st, h->P, h->d_xnext, h->d_G, Jin,
+                    hipLaunchKernelGGL((k_sweep_table<3, REAL, PI_T>), g, 256, 0, st, h->P, h->d_xnext, h->d_G, h->d_ok, Jin,
                                        Jout, pi, alpha, sc);
                     break;
                 default:
-                    hipLaunchKernelGGL((k_sweep_table<4, REAL, PI_T>), g, 256, 0, st, h->P, h->d_xnext, h->d_G, Jin,
+                    hipLaunchKernelGGL((k_sweep_table<4, REAL, PI_T>), g, 256, 0, st, h->P, h->d_xnext, h->d_G, h->d_ok, Jin,
                                        Jout, pi, alpha, sc);
                     break;
             }
@@ -2229,7 +2235,7 @@ extern "C" int pvi_build_tables(pvi_handle h, int32_t row0, int32_t nrows, doubl
     return PVI_OK;
 }
 
-extern "C" int pvi_set_tables(pvi_handle h, const double* x_next, const double* G) {
+extern "C" int pvi_set_tables(pvi_handle h, const double* x_next, const double* G, const uint8_t* ok) {
     if (!h || !x_next || !G) return fail(PVI_EINVAL, "NULL argument");
     if (h->d.dynamics_id != PVI_DYN_TABLE) return fail(PVI_ESTATE, "handle was created with in-kernel dynamics");
     HIPCHK(hipSetDevice(h->device));
@@ -2245,6 +2251,17 @@ extern "C" int pvi_set_tables(pvi_handle h, const double* x_next, const double* 
     }
     HIPCHK(hipMemcpyAsync(h->d_xnext, x_next, cells * h->P.n * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_G, G, cells * 8, hipMemcpyHostToDevice, h->stream));
+    if (ok) {
+        if (!h->d_ok) {
+            void* p = nullptr;
+            HIPCHK(hipMalloc(&p, cells));
+            h->dev_allocs.push_back(p);
+            h->d_ok = (unsigned char*)p;
+        }
+        HIPCHK(hipMemcpyAsync(h->d_ok, ok, cells, hipMemcpyHostToDevice, h->stream));
+    } else {
+        h->d_ok = nullptr;  // (a previously uploaded mask stays allocated until destroy)
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     return PVI_OK;
 }

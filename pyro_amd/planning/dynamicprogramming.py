@@ -55,6 +55,7 @@ class DynamicProgramming:
     For box-only validity the reference's cell-by-cell base class and its look-up-table subclass
     compute the same recursion; both map to the same fused kernel here."""
 
+    HARD_INF = True                 # base class: an invalid action / next state costs exactly INF (:225-233)
     HISTORY_MAX_BYTES = 1 << 30     # save_time_history is dropped beyond this (J+pi per sweep)
     BATCH = 256                     # sweeps enqueued per host round trip when no history is kept
 
@@ -84,8 +85,10 @@ class DynamicProgramming:
         else:
             g, s = self.grid_sys, self.sys
             self._p = _native.Problem(g.x_level, g.u_level, s.x_lb, s.x_ub, s.u_lb, s.u_ub, g.dt, dtype=self.dtype,
-                                      dynamics_id=_native.DYN_TABLE, cost=None, device=self.device)
-            self._p.set_tables(g.x_next_table, self._host_cost_table())
+                                      dynamics_id=_native.DYN_TABLE, cost=None, device=self.device,
+                                      table_inf=float(self.cf.INF))
+            ok = (g.action_isok & g.x_next_isok) if self.HARD_INF else None
+            self._p.set_tables(g.x_next_table, self._host_cost_table(), ok)
         self._host = {}             # cached downloads: 'J', 'pi', 'J_next'
         self._dirty = False         # host J newer than the device copy
 
@@ -265,6 +268,8 @@ class DynamicProgrammingWithLookUpTable(DynamicProgramming):
     """dynamicprogramming.py:505-570.  `G` is available as an attribute (built on the GPU for the
     fused tier) but the fused sweep never materialises it."""
 
+    HARD_INF = False                # Q = G + alpha*J_interp even where G = INF (:567)
+
     @property
     def G(self):
         if "_G" not in self.__dict__:
@@ -279,3 +284,46 @@ class DynamicProgrammingWithLookUpTable(DynamicProgramming):
         else:
             self.__dict__["_G"] = self._host_cost_table()
         print("completed in %4.2f sec" % (time.time() - t0))
+
+
+class PolicyEvaluator(DynamicProgramming):
+    """Cost-to-go of a GIVEN control law u = ctl.c(x, ctl.rbar, t) (dynamicprogramming.py:623-677): the
+    same backup with exactly one action per node.  The controller is arbitrary Python, so x_next and G are
+    evaluated on the host node by node like the reference (:704-735); the sweeps run on the GPU (table
+    tier, A = 1).  Base class: an invalid input / next state costs exactly INF."""
+
+    HARD_INF = True
+
+    def __init__(self, ctl, grid_sys, cost_function, final_time=0, dtype="float64", device=0):
+        self.ctl = ctl
+        super().__init__(grid_sys, cost_function, final_time, dtype=dtype, device=device)
+
+    def _make_engine(self):
+        g, s = self.grid_sys, self.sys
+        N = g.nodes_n
+        X = g.state_from_node_id
+        self.x_next_table = np.zeros((N, s.n))
+        self.G = np.zeros(N)
+        ok = np.zeros(N, dtype=bool)
+        r = self.ctl.rbar
+        for i in range(N):
+            x = X[i]
+            u = self.ctl.c(x, r, self.t)
+            x_next = s.f(x, u, self.t) * g.dt + x
+            self.x_next_table[i] = x_next
+            ok[i] = s.isavalidinput(x, u) and s.isavalidstate(x_next)
+            self.G[i] = self.cf.g(x, u, self.t) * g.dt if ok[i] else self.cf.INF
+        one = [np.zeros(1) for _ in range(s.m)]                     # a single placeholder action
+        self.tier = "table"
+        self._p = _native.Problem(g.x_level, one, s.x_lb, s.x_ub, np.zeros(s.m), np.zeros(s.m), g.dt, dtype=self.dtype,
+                                  dynamics_id=_native.DYN_TABLE, cost=None, device=self.device,
+                                  table_inf=float(self.cf.INF))
+        self._p.set_tables(self.x_next_table[:, None, :], self.G[:, None], ok[:, None] if self.HARD_INF else None)
+        self._host = {}
+        self._dirty = False
+
+
+class PolicyEvaluatorWithLookUpTable(PolicyEvaluator):
+    """dynamicprogramming.py:683-753: J = G + alpha * J_interp(x_next_table), G = INF on invalid nodes."""
+
+    HARD_INF = False

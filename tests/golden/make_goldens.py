@@ -320,7 +320,109 @@ def case_doublependulum():
     save("doublependulum_13x11x13x11x3x3", **out)
 
 
-CASES = dict(f_kat=case_f_kat, cost_kat=case_cost_kat, grid_kat=case_grid_kat,
+def _lut_and_base(g, q, sweeps, keep, alpha=1.0):
+    """Tables + LUT-class and base-class J/pi after the sweeps in `keep`."""
+    import warnings
+    out = {}
+    with quiet():
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, q)
+        dp.save_time_history = False
+        dp.alpha = alpha
+        out.update(x_next_table=g.x_next_table, x_next_isok=g.x_next_isok, action_isok=g.action_isok, G=dp.G,
+                   J0=dp.J.copy())
+        for k in range(1, sweeps + 1):
+            dp.initialize_backward_step(); dp.compute_backward_step(); dp.finalize_backward_step()
+            if k in keep:
+                out["J_%d" % k] = dp.J.copy(); out["pi_%d" % k] = dp.pi.astype(np.int16)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            db = dynamicprogramming.DynamicProgramming(g, q)
+            db.save_time_history = False
+            db.alpha = alpha
+            for k in range(1, sweeps + 1):
+                db.initialize_backward_step(); db.compute_backward_step(); db.finalize_backward_step()
+                if k in keep:
+                    out["Jbase_%d" % k] = db.J.copy(); out["pibase_%d" % k] = db.pi.astype(np.int16)
+    return out
+
+
+def case_obstacles():
+    """HolonomicMobileRobotwithObstacles 21x21 x 3x3 (2D_navigation.py weights): isavalidstate with obstacles,
+    where LUT (INF + alpha*J) and base class (INF) semantics differ."""
+    from pyro.dynamic import vehicle_steering
+    with quiet():
+        s = vehicle_steering.HolonomicMobileRobotwithObstacles()
+        g = discretizer.GridDynamicSystem(s, [21, 21], [3, 3])
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+        q.xbar = np.array([10.0, 0.0])
+        q.R[0, 0] = 0.0; q.R[1, 1] = 0.0; q.S[0, 0] = 10.0; q.S[1, 1] = 10.0
+        q.INF = 8000
+    out = _meta(s, g, q)
+    out.update(_lut_and_base(g, q, 5, (1, 5)))
+    out["differs"] = int((out["J_5"] != out["Jbase_5"]).sum())
+    save("obstacles_21x21x3x3", **out)
+
+
+def case_helicopter():
+    """ConstantSpeedHelicopterTunnel 3-D 11x11x11 x 5 with QuadraticCostFunctionWithDomainCheck, alpha 0.999."""
+    from pyro.dynamic import drone
+    with quiet():
+        s = drone.ConstantSpeedHelicopterTunnel()
+        s.obstacles = [[(2, 2), (4, 4)], [(8, 5), (10, 10)], [(14, 0), (16, 4)]]
+        s.mass = 0.1; s.vx = 5.0; s.width = 1.0
+        s.x_ub = np.array([+60, 10, +20]); s.x_lb = np.array([-60, 0, +0])
+        s.u_ub = np.array([+20]); s.u_lb = np.array([-20])
+        g = discretizer.GridDynamicSystem(s, (11, 11, 11), [5], 0.05)
+        q = costfunction.QuadraticCostFunctionWithDomainCheck.from_sys(s)
+        q.xbar = np.array([0.0, 2.0, 20]); q.INF = 100000; q.EPS = 0.2
+        q.Q[0, 0] = 2.0; q.Q[1, 1] = 200.0; q.Q[2, 2] = 0.0; q.R[0, 0] = 5.0
+        q.S[0, 0] = 20.0; q.S[1, 1] = 50.0; q.S[2, 2] = 0.0
+    out = _meta(s, g, q)
+    out.update(_lut_and_base(g, q, 5, (1, 5), alpha=0.999))
+    save("helicopter_11x11x11x5", **out)
+
+
+def case_reachability():
+    """Reachability cost on the pendulum 41x41 x 3 (pendulum_reachability.py), 20 sweeps."""
+    with quiet():
+        s = pendulum.SinglePendulum()
+        s.xbar = np.array([-3.14, 0])
+        g = discretizer.GridDynamicSystem(s, [41, 41], [3])
+        cf = costfunction.Reachability(s.isavalidstate, s.xbar)
+    out = dict(x_lb=s.x_lb, x_ub=s.x_ub, u_lb=s.u_lb, u_ub=s.u_ub, dims=g.x_grid_dim, udims=g.u_grid_dim, dt=g.dt,
+               xbar=s.xbar, INF=cf.INF, EPS=cf.EPS)
+    out.update(_lut_and_base(g, cf, 20, (1, 20)))
+    save("reachability_41x41x3", **out)
+
+
+def case_policy_eval():
+    """PolicyEvaluatorWithLookUpTable with a computed-torque controller on the pendulum 41x41 (A = 1)."""
+    from pyro.control import nonlinear
+    with quiet():
+        s = pendulum.SinglePendulum()
+        s.x_ub = np.array([+6.0, +6.0]); s.x_lb = np.array([-9.0, -6.0])
+        ctl = nonlinear.ComputedTorqueController(s)
+        ctl.rbar = np.array([-3.14])
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+        q.xbar = np.array([ctl.rbar[0], 0]); q.INF = 300
+        q.S[0, 0] = 10.0; q.S[1, 1] = 10.0
+        s.u_ub[0] = +200; s.u_lb[0] = -200
+        g = discretizer.GridDynamicSystem(s, [41, 41], [11], 0.05, False)
+        ev = dynamicprogramming.PolicyEvaluatorWithLookUpTable(ctl, g, q)
+        ev.save_time_history = False
+        out = _meta(s, g, q)
+        out.update(x_next_table=ev.x_next_table, G=ev.G, J0=ev.J.copy())
+        U = np.array([ctl.c(g.state_from_node_id[i], ctl.rbar, 0) for i in range(g.nodes_n)])
+        out["U"] = U
+        for k in range(1, 11):
+            ev.initialize_backward_step(); ev.compute_backward_step(); ev.finalize_backward_step()
+            if k in (1, 10):
+                out["J_%d" % k] = ev.J.copy()
+    save("policy_eval_41x41", **out)
+
+
+CASES = dict(f_kat=case_f_kat, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
+             policy_eval=case_policy_eval, cost_kat=case_cost_kat, grid_kat=case_grid_kat,
              pendulum_small=case_pendulum_small, config1=case_config1, lowdef=case_lowdef,
              pendulum_demo=case_pendulum_demo, cartpole_small=case_cartpole_small,
              cartpole_mid=case_cartpole_mid, twolink_small=case_twolink_small,

@@ -480,3 +480,62 @@ def test_sharded_driver_world1_on_gpu(tmp_path):
     for _ in range(5):
         J, _ = O.sweep(p, J)
     assert relerr(np.load(out), J) <= REL_F32
+
+
+# ------------------------------------------------------------------------------------- tier B on the reference's tables
+@pytest.mark.parametrize("name,sweeps", [("obstacles_21x21x3x3", 5), ("helicopter_11x11x11x5", 5), ("reachability_41x41x3", 20)])
+def test_table_tier_lut_and_base_semantics(name, sweeps):
+    """Obstacles (2-D, m=2), domain-check cost (3-D) and reachability cost through pvi_set_tables: the
+    look-up-table class semantics (ok = NULL) and the base-class semantics (ok mask) against the reference."""
+    from pyro_amd import _native
+    g = load(name)
+    lv = O.make_levels(g["x_lb"], g["x_ub"], g["dims"])
+    ul = O.make_levels(g["u_lb"], g["u_ub"], g["udims"])
+    alpha = 0.999 if "helicopter" in name else 1.0
+    ok = g["x_next_isok"] & g["action_isok"]
+    for mask, key, pkey in ((None, "J_%d", "pi_%d"), (ok, "Jbase_%d", "pibase_%d")):
+        h = _native.Problem(lv, ul, g["x_lb"], g["x_ub"], g["u_lb"], g["u_ub"], float(g["dt"]),
+                            dynamics_id=_native.DYN_TABLE, table_inf=float(g["INF"]))
+        h.set_tables(g["x_next_table"], g["G"], mask)
+        h.set_J(g["J0"])
+        for k in range(1, sweeps + 1):
+            h.sweep(1, alpha, -1.0)
+            if k in (1, sweeps):
+                assert relerr(h.get_J(), g[key % k]) < 1e-13
+                assert np.array_equal(h.get_pi(), g[pkey % k])
+        h.close()
+
+
+def test_policy_evaluator_classes():
+    """PolicyEvaluatorWithLookUpTable driven like examples/.../policy_evaluator_with_computed_torque.py, with a
+    stand-in controller that replays the reference controller's inputs (U of the golden)."""
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.control import controller
+    from pyro_amd.dynamic import pendulum
+    from pyro_amd.planning import discretizer, dynamicprogramming
+    g = load("policy_eval_41x41")
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = pendulum.SinglePendulum()
+        s.x_ub, s.x_lb = g["x_ub"].copy(), g["x_lb"].copy()
+        s.u_ub, s.u_lb = g["u_ub"].copy(), g["u_lb"].copy()
+        grid = discretizer.GridDynamicSystem(s, [41, 41], [11], 0.05, False)
+
+        class Replay(controller.StaticController):
+            def __init__(self):
+                super().__init__(1, 1, 2)
+                self.rbar = np.array([-3.14])
+
+            def c(self, y, r, t=0):
+                return g["U"][grid.get_nearest_node_id_from_state(y)]
+
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+        q.xbar, q.INF = g["xbar"].copy(), float(g["INF"])
+        q.S = g["S"].copy()
+        ev = dynamicprogramming.PolicyEvaluatorWithLookUpTable(Replay(), grid, q)
+        ev.save_time_history = False
+        np.testing.assert_allclose(ev.x_next_table, g["x_next_table"], rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(ev.G, g["G"], rtol=1e-13, atol=1e-13)
+        ev.compute_steps(10)
+    assert relerr(ev.J, g["J_10"]) < 1e-12
+    assert (ev.pi == 0).all()

@@ -259,3 +259,35 @@ def test_cartpole_mid_f32_golden():
     if not os.path.exists(path):
         pytest.skip("fixture not generated")
     _check_4d("cartpole_21p4x7", O.DYN_CARTPOLE, O.cartpole_consts(), sample=False, rtol=1e-6)
+
+
+# ------------------------------------------------------------------------- table-driven goldens (tier B)
+@pytest.mark.parametrize("name,sweeps", [("obstacles_21x21x3x3", 5), ("helicopter_11x11x11x5", 5), ("reachability_41x41x3", 20)])
+def test_table_goldens_lut_and_base(name, sweeps):
+    """Obstacle / domain-check / reachability cases: arbitrary sys.isavalidstate and cost -> the recursion on
+    the reference's own tables, LUT semantics (INF + alpha*J) and base-class semantics (exactly INF)."""
+    g = load(name)
+    lv = O.make_levels(g["x_lb"], g["x_ub"], g["dims"])
+    alpha = 0.999 if "helicopter" in name else 1.0
+    ok = g["x_next_isok"] & g["action_isok"]
+    J = Jb = g["J0"]
+    for k in range(1, sweeps + 1):
+        J, pi, _ = O.sweep_lut(lv, g["x_next_table"], g["G"], J, alpha)
+        Jb, pib, _ = O.sweep_base(lv, g["x_next_table"], g["G"], ok, Jb, float(g["INF"]), alpha)
+        if k in (1, sweeps):
+            np.testing.assert_allclose(J, g["J_%d" % k], rtol=1e-13, atol=1e-13)
+            assert np.array_equal(pi, g["pi_%d" % k])
+            np.testing.assert_allclose(Jb, g["Jbase_%d" % k], rtol=1e-13, atol=1e-13)
+            assert np.array_equal(pib, g["pibase_%d" % k])
+    if "obstacles" in name:
+        assert int(g["differs"]) > 0 and (J != Jb).sum() == int(g["differs"])   # the two semantics really differ
+
+
+def test_policy_evaluator_golden():
+    g = load("policy_eval_41x41")
+    lv = O.make_levels(g["x_lb"], g["x_ub"], g["dims"])
+    J = g["J0"]
+    for k in range(1, 11):
+        J, _, _ = O.sweep_lut(lv, g["x_next_table"][:, None, :], g["G"][:, None], J)
+        if k in (1, 10):
+            np.testing.assert_allclose(J, g["J_%d" % k], rtol=1e-13, atol=1e-13)
