@@ -81,13 +81,18 @@ def cpu_baseline(cfg, budget_s=20.0):
                 sweeps_per_sec=v / cells_per_sweep), None, 0
 
 
-def load_traffic(workload):
-    """HBM bytes per sweep-kernel launch from the committed rocprofv3 PMC passes (profiles/)."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0   # wave64 VALU instructions / s: one per quad-cycle per SIMD (measured:
+                                          # SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU on gfx950), 256 CUs x 4 SIMDs, 2.4 GHz
+
+
+def load_counters(workload):
+    """Per-launch hardware counters of the sweep kernel from the committed rocprofv3 PMC passes
+    (profiles/counters.json, produced by tools_counters.sh): HBM bytes and VALU instructions."""
+    path = os.path.join(ROOT, "profiles", "counters.json")
     try:
-        return json.load(open(path)).get(workload, {}).get("hbm_bytes_per_launch")
+        return json.load(open(path)).get(workload, {})
     except Exception:
-        return None
+        return {}
 
 
 def run_single(args):
@@ -125,6 +130,7 @@ def run_single(args):
     kern_ms = p.last_sweep_ms() / args.steps           # HIP events on the kernel's stream
 
     alg_bytes = N * (2 * w + pbytes)
+    ctr = load_counters(cfg["name"])
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     flops_cell = {2: 30, 4: 90}[g.sys.n] if g.sys.m == 1 else 120
     out = {
@@ -137,10 +143,16 @@ def run_single(args):
         "sweeps_per_sec": args.steps / dt,
         "jstar_rel_err_vs_cpu": rel_err, "jstar_rel_err_after_sweeps": n_cmp,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(cfg["name"]),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": ctr.get("hbm_bytes_per_launch"),
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
-                     "note": "VALU-bound stencil/gather: see valu_frac"},
-        "valu_frac": (N * A / (kern_ms * 1e-3)) * flops_cell / (VALU_PEAK_F32_TFLOPS * 1e12),
+                     "note": "nominal: the sweep is VALU-issue bound (A actions per node on 9 B of traffic), see roofline_valu"},
+        "roofline_valu": None if not ctr.get("valu_insts_per_launch") else {
+            "bound": "valu-issue", "achieved": ctr["valu_insts_per_launch"] / (kern_ms * 1e-3) / 1e9,
+            "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave64-instr/s",
+            "frac": ctr["valu_insts_per_launch"] / (kern_ms * 1e-3) / VALU_ISSUE_PEAK,
+            "valu_insts_per_launch": ctr["valu_insts_per_launch"],
+            "valu_insts_per_cell": ctr["valu_insts_per_launch"] * 64.0 / (N * A)},
+        "flops_frac_f32_vector_peak": (N * A / (kern_ms * 1e-3)) * flops_cell / (VALU_PEAK_F32_TFLOPS * 1e12),
         "last_stats": [float(v) for v in stats[-1]],
         "kernel_path": p.describe(),
     }

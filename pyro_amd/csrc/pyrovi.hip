@@ -1419,7 +1419,7 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
     L.V0 = DOF == 2 ? P.dim[2] : 1;
     L.V1 = P.dim[P.n - 1];
     L.ntx = (L.V1 + tv1_t - 1) / tv1_t;
-    L.TV1 = (L.V1 + L.ntx - 1) / L.ntx;
+    L.TV1 = getenv("PVI_TV_EXACT") ? tv1_t : (L.V1 + L.ntx - 1) / L.ntx;
     const int tv0 = std::max(1, std::min(L.V0, tv0_t));
     L.nty = (L.V0 + tv0 - 1) / tv0;
     L.TV0 = (L.V0 + L.nty - 1) / L.nty;
@@ -1465,13 +1465,17 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
         snprintf(h->lean_why, sizeof(h->lean_why), "%s", (summary[3] & 2) ? "an action fails isavalidinput" : "halo too small");
         return (summary[3] & 1) ? 2 : 1;
     }
-    // row pitch 32k+1 dwords >= longest row (+1: the j+1 corner of the last in-row cell is inside the row)
-    const int rs = 32 * ((summary[1] + 30) / 32) + 1;
+    // row pitch: >= longest row + 1 (the j+1 corner), odd so that rows start on different banks.
+    // (A pitch congruent to the tile width modulo 32 -- consecutive lanes on consecutive banks across
+    // tile rows -- was measured: fewer conflict cycles per LDS instruction, but the larger pitch costs
+    // LDS capacity and one more address add per corner; no net gain.  PVI_RS_MODE=1 selects it.)
+    int rs = (summary[1] + 1) | 1;
+    if (const char* e = getenv("PVI_RS_MODE")) {
+        if (atoi(e) == 1 && DOF == 2) rs = summary[1] + 1 + (((L.TV1 - summary[1] - 1) % 32 + 32) % 32);
+        if (atoi(e) == 2) rs = 32 * ((summary[1] + 31) / 32) + 1;
+    }
     const long long need = (long long)summary[0] * rs + 128;
-    const int rs_opts[6] = {33, 65, 97, 129, 193, 257};
-    bool rs_ok = DOF == 1;
-    for (int k = 0; k < 6; ++k) rs_ok = rs_ok || rs == rs_opts[k];
-    if (need <= lds_budget_floats && rs_ok) {
+    if (need <= lds_budget_floats) {
         L.RS = rs;
         h->lean_pw1 = rs;
         h->lean_lds = (size_t)need * 4;
@@ -1965,37 +1969,27 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         if (h->lean_ok) {
             const float al = (float)alpha;
             sc.nblocks = h->lean_grid.x;
-#define LEAN3(DYN, PW, U)                                                                                           \
+#define LEAN3(DYN, U)                                                                                               \
     {                                                                                                               \
-        auto kfn = k_sweep_lean<DYN, PI_T, PW, U>;                                                                  \
+        auto kfn = k_sweep_lean<DYN, PI_T, U>;                                                                      \
         if (!h->lean_lds_attr && h->lean_lds > 48 * 1024) {                                                         \
             HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lean_lds)); \
             h->lean_lds_attr = true;                                                                                \
         }                                                                                                           \
         hipLaunchKernelGGL(kfn, h->lean_grid, h->lean_block, h->lean_lds, st, h->P, h->LP, h->F.act, Jin, Jout, pi, al, \
-                           sc);                                                                          \
+                           sc);                                                                                     \
     }
-#define LEAN2(DYN, PW)         \
+#define LEAN(DYN)              \
     if (h->LP.lsplit == 0)     \
-        LEAN3(DYN, PW, true)   \
+        LEAN3(DYN, true)       \
     else                       \
-        LEAN3(DYN, PW, false)
-#define LEAN(DYN)                         \
-    switch (h->lean_pw1) {                \
-        case 33: LEAN2(DYN, 33) break;    \
-        case 65: LEAN2(DYN, 65) break;    \
-        case 97: LEAN2(DYN, 97) break;    \
-        case 129: LEAN2(DYN, 129) break;  \
-        case 193: LEAN2(DYN, 193) break;  \
-        default: LEAN2(DYN, 257) break;   \
-    }
+        LEAN3(DYN, false)
             switch (h->d.dynamics_id) {
-                case PVI_DYN_PENDULUM: LEAN2(PVI_DYN_PENDULUM, 0) break;
+                case PVI_DYN_PENDULUM: LEAN(PVI_DYN_PENDULUM) break;
                 case PVI_DYN_CARTPOLE: LEAN(PVI_DYN_CARTPOLE) break;
                 default: LEAN(PVI_DYN_TWOLINK) break;
             }
 #undef LEAN
-#undef LEAN2
 #undef LEAN3
             HIPCHK(hipGetLastError());
             return PVI_OK;

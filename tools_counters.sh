@@ -1,0 +1,29 @@
+#!/bin/bash
+# usage: tools_counters.sh <workload> -> gpurun_out/counters_<workload>.json
+# separate rocprofv3 --pmc passes (kernel-trace only): FETCH_SIZE | WRITE_SIZE | SQ set 1 | SQ set 2
+W=$1
+cd /tmp && export TMPDIR=/tmp
+OUT=/root/repo/gpurun_out/counters_$W; mkdir -p $OUT
+i=0
+for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -o p -- python /root/repo/tools_traffic.py $W > $OUT/p$i.log 2>&1
+done
+python3 - <<PY
+import csv, glob, collections, json
+res = collections.defaultdict(dict)
+for i in (1, 2, 3, 4):
+    fs = glob.glob('$OUT/p%d/*counter_collection.csv' % i)
+    if not fs: print('no counters pass', i); continue
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(fs[0])):
+        acc[r['Kernel_Name'].split('(')[0][:64]][r['Counter_Name']].append(float(r['Counter_Value']))
+    for k, d in acc.items():
+        for c, v in d.items():
+            res[k][c] = sum(v) / len(v)
+            res[k]['calls'] = len(v)
+keep = {k: v for k, v in res.items() if 'sweep' in k or 'to_f64' in k or 'setup' in k}
+json.dump({"workload": "$W", "kernels": keep}, open('/root/repo/gpurun_out/counters_$W.json', 'w'), indent=1)
+for k, v in keep.items():
+    if 'sweep' in k: print(k, json.dumps(v))
+PY
