@@ -1416,7 +1416,10 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
     const DevP& P = h->P;
     LeanP& L = h->LP;
     const int DOF = P.dof;
-    L.V0 = DOF == 2 ? P.dim[2] : 1;
+    // 4-D: tiles of the (i2, i3) velocity plane, one (i0, i1) position node per workgroup;
+    // 2-D: tiles of the (i0, i1) grid itself (TV0 rows share most of their window rows)
+    L.dof1 = DOF == 1;
+    L.V0 = DOF == 2 ? P.dim[2] : (P.row_end - P.row_begin);
     L.V1 = P.dim[P.n - 1];
     L.ntx = (L.V1 + tv1_t - 1) / tv1_t;
     L.TV1 = getenv("PVI_TV_EXACT") ? tv1_t : (L.V1 + L.ntx - 1) / L.ntx;
@@ -1428,7 +1431,7 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
     L.pd_magic = magic32((unsigned)L.posdim1);
     L.vplane = (long long)L.V0 * L.V1;
     L.owned = h->owned;
-    const int pnodes = (P.row_end - P.row_begin) * L.posdim1;
+    const int pnodes = DOF == 2 ? (P.row_end - P.row_begin) * L.posdim1 : 1;
     const long long ntiles = (long long)L.ntx * L.nty * pnodes;
     if (ntiles >= 0x7fffffffLL) return 1;
     L.ntx_magic = magic32((unsigned)L.ntx);
@@ -1515,12 +1518,15 @@ static int lean_setup(pvi_problem* h) {
     int budget = DOF == 1 ? 8 * 1024 : 20 * 1024;  // floats: 32 KB (2-D), 80 KB (4-D: two workgroups per CU)
     if (const char* e = getenv("PVI_LDS_KB")) budget = atoi(e) * 256;
     budget = std::min(budget, 40000);
-    int shapes[6][2];
+    int shapes[8][2];
     int ns = 0;
     if (getenv("PVI_TV0") && getenv("PVI_TV1")) {
         shapes[ns][0] = atoi(getenv("PVI_TV0"));
         shapes[ns++][1] = atoi(getenv("PVI_TV1"));
     } else if (DOF == 1) {
+        // measured on 1001^2 x 51: 8x32 51.7 us, 4x63 52.3, 2x126 53.8, 1x251 55.0, 512-thread shapes 56-60
+        shapes[ns][0] = std::max(1, spb / 32); shapes[ns++][1] = 32;
+        shapes[ns][0] = std::max(1, spb / 64); shapes[ns++][1] = 64;
         shapes[ns][0] = 1; shapes[ns++][1] = spb;
         shapes[ns][0] = 1; shapes[ns++][1] = std::max(16, spb / 2);
     } else {
