@@ -1368,6 +1368,11 @@ struct pvi_problem {
     size_t lean_lds = 0;
     bool lean_lds_attr = false;
     char lean_why[160] = "";
+    MarchP MP;                // 4-D march variant of the lean path
+    bool march_ok = false;
+    size_t march_lds = 0;
+    bool march_lds_attr = false;
+    int march_block = 256;
 };
 
 template <typename T>
@@ -1550,6 +1555,31 @@ static int lean_setup(pvi_problem* h) {
             h->lean_ok = true;
             h->lean_lds_attr = false;
             break;
+        }
+    }
+    h->march_ok = false;
+    // the march variant is opt-in (PVI_MARCH=1): measured within 3 % of the tiled lean kernel on 101^4
+    if (h->lean_ok && DOF == 2 && getenv("PVI_MARCH") && L.lsplit == 0) {
+        MarchP& Mp = h->MP;
+        memset(&Mp, 0, sizeof(Mp));
+        Mp.ncols = (P.row_end - P.row_begin) * L.ntx * L.nty;
+        if ((rc = dev_alloc(h, (size_t)Mp.ncols * 8, &Mp.cwin))) return rc;
+        HIPCHK(hipMemsetAsync(L.summary, 0, 4 * sizeof(int), h->stream));
+        hipLaunchKernelGGL(k_march_colbox, grid_for(Mp.ncols), 256, 0, h->stream, P, L, Mp, L.summary);
+        HIPCHK(hipGetLastError());
+        int summary[4];
+        HIPCHK(hipMemcpyAsync(summary, L.summary, sizeof(summary), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        Mp.RS = (summary[1] + 1) | 1;
+        const long long need = (long long)summary[0] * Mp.RS + 128;
+        int mbudget = 20 * 1024;
+        if (const char* e = getenv("PVI_MARCH_LDS_KB")) mbudget = atoi(e) * 256;
+        if (need <= mbudget) {
+            h->march_ok = true;
+            h->march_lds = (size_t)need * 4;
+            h->march_block = ((L.TV0 * L.TV1 + 63) / 64) * 64;
+        } else {
+            snprintf(h->lean_why, sizeof(h->lean_why), "march ring needs %lld LDS floats (budget %d)", need, mbudget);
         }
     }
     if (!h->lean_ok) {  // release the per-node arrays: the fast / tiled kernels do not need them
@@ -1814,6 +1844,7 @@ extern "C" int pvi_pi_itemsize(pvi_handle h) { return h ? h->pi_size : 0; }
 extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
     if (!h || !buf || n <= 0) return fail(PVI_EINVAL, "bad argument");
     const char* path = h->d.dtype == PVI_F64 ? "exact-f64"
+                       : h->march_ok ? "march"
                        : h->lean_ok ? "lean"
                        : h->tile_ok ? "tile"
                        : h->fast_ok ? "fast" : (h->d.dynamics_id == PVI_DYN_TABLE ? "table" : "exact-f32");
@@ -1972,6 +2003,27 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     REAL* Jout = (REAL*)h->J[src ^ 1];
     PI_T* pi = (PI_T*)h->pi;
     if constexpr (sizeof(REAL) == 4) {
+        if (h->march_ok) {
+            const float al = (float)alpha;
+            sc.nblocks = (unsigned)h->MP.ncols;
+#define MARCH(DYN)                                                                                                  \
+    {                                                                                                               \
+        auto kfn = k_sweep_march<DYN, PI_T>;                                                                        \
+        if (!h->march_lds_attr && h->march_lds > 48 * 1024) {                                                       \
+            HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->march_lds)); \
+            h->march_lds_attr = true;                                                                               \
+        }                                                                                                           \
+        hipLaunchKernelGGL(kfn, dim3(sc.nblocks), h->march_block, h->march_lds, st, h->P, h->LP, h->MP, h->F.act, Jin, \
+                           Jout, pi, al, sc);                                                                       \
+    }
+            if (h->d.dynamics_id == PVI_DYN_CARTPOLE)
+                MARCH(PVI_DYN_CARTPOLE)
+            else
+                MARCH(PVI_DYN_TWOLINK)
+#undef MARCH
+            HIPCHK(hipGetLastError());
+            return PVI_OK;
+        }
         if (h->lean_ok) {
             const float al = (float)alpha;
             sc.nblocks = h->lean_grid.x;

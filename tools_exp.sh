@@ -1,4 +1,4 @@
 #!/bin/bash
-for sh in "1 251" "2 251" "2 126" "4 126" "4 64" "8 64" "3 167" "8 32" "6 84"; do set -- $sh; PVI_TV0=$1 PVI_TV1=$2 ./tools_b1.sh c2 200 20; done
-./tools_b1.sh c2p 200 20
-for sh in "2 16" "4 16" "4 8" "8 8"; do set -- $sh; PVI_TV0=$1 PVI_TV1=$2 ./tools_b1.sh c2p 200 20; done
+for sh in "16 26" "12 26" "4 51" "8 34" "10 34" "19 21"; do set -- $sh; PVI_TV0=$1 PVI_TV1=$2 PVI_LDS_KB=80 PVI_MARCH_LDS_KB=80 ./tools_b1.sh c3 5 1; done
+PVI_TV0=10 PVI_TV1=51 PVI_LDS_KB=80 PVI_MARCH_LDS_KB=150 ./tools_b1.sh c3 5 1
+PVI_TV0=8 PVI_TV1=51 PVI_LDS_KB=80 PVI_MARCH_LDS_KB=110 ./tools_b1.sh c3 5 1
