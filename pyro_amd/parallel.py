@@ -140,10 +140,7 @@ class ShardedValueIteration:
                 if k != self.rank:
                     s.rows_view(a, b - a).copy_(bufs[k][:(b - a) * s.plane])
 
-    def sweep(self, alpha=1.0):
-        """One Bellman backup of the whole grid; returns (max J, max d, min d, delta) of the grid."""
-        self.slab.sweep(alpha)
-        self.exchange()
+    def _reduce_stats(self):
         st = np.asarray(self.slab.stats(), dtype=np.float64)
         if self.world > 1:
             t = self.torch.tensor([st[0], st[1], -st[2]], dtype=self.torch.float64)
@@ -153,14 +150,24 @@ class ShardedValueIteration:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             t = t.cpu().numpy()
             st = np.array([t[0], t[1], -t[2]])
-        self.k += 1
         return float(st[0]), float(st[1]), float(st[2]), float(max(abs(st[1]), abs(st[2])))
 
+    def sweep(self, alpha=1.0, want_stats=True):
+        """One Bellman backup of the whole grid; returns (max J, max d, min d, delta) of the grid, or None
+        when want_stats is False (no host synchronisation at all: kernel + halo exchange are just enqueued)."""
+        self.slab.sweep(alpha)
+        self.exchange()
+        self.k += 1
+        return self._reduce_stats() if want_stats else None
+
     def run(self, max_sweeps, alpha=1.0, tol=-1.0):
-        """compute_steps / solve_bellman_equation semantics (dynamicprogramming.py:265-314)."""
+        """compute_steps / solve_bellman_equation semantics (dynamicprogramming.py:265-314).  With tol < 0 the
+        sweep count is fixed, so the per-sweep statistics (a host synchronisation + an all-reduce) are only
+        taken for the last sweep."""
         out = None
-        for _ in range(max_sweeps):
-            out = self.sweep(alpha)
+        for i in range(max_sweeps):
+            last = i == max_sweeps - 1
+            out = self.sweep(alpha, want_stats=(tol >= 0 or last))
             if tol >= 0 and out[3] <= tol:
                 break
         return out

@@ -46,13 +46,12 @@ def run(args):
         del dp
 
     vi = parallel.ShardedValueIteration(g, cfg["cf"], dist, dtype=cfg["dtype"], device=local)
-    for _ in range(warmup):
-        vi.sweep(1.0)
+    if warmup:
+        vi.run(warmup, 1.0, -1.0)
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        st = vi.sweep(1.0)
+    st = vi.run(steps, 1.0, -1.0)          # fixed sweep count: statistics of the last sweep only
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
