@@ -539,3 +539,79 @@ def test_policy_evaluator_classes():
         ev.compute_steps(10)
     assert relerr(ev.J, g["J_10"]) < 1e-12
     assert (ev.pi == 0).all()
+
+
+# ------------------------------------------------------------------------------------- edge cases
+def _custom_problem(kind, dims, udims, dt=0.05, alpha=1.0, seed=0, fancy_cost=False, INF=500.0, EPS=1e-3, bounds=None):
+    rng = np.random.default_rng(seed)
+    if kind == "pendulum":
+        dyn, c, n, m = O.DYN_PENDULUM, O.pendulum_consts(d1=0.3), 2, 1
+        lb, ub, ulb, uub = [-2 * np.pi] * 2, [2 * np.pi] * 2, [-5.0], [5.0]
+    elif kind == "cartpole":
+        dyn, c, n, m = O.DYN_CARTPOLE, O.cartpole_consts(), 4, 1
+        lb, ub, ulb, uub = [-3.0, -np.pi, -4.0, -6.0], [2.0, 2 * np.pi, 5.0, 7.0], [-8.0], [10.0]
+    else:
+        dyn, c, n, m = O.DYN_TWOLINK, O.twolink_consts(**DOUBLEP), 4, 2
+        lb, ub, ulb, uub = [-5.0, -1.5, -4.0, -4.0], [0.5, 4.0, 5.5, 7.0], [-12.0, -10.0], [12.0, 11.0]
+    if bounds is not None:
+        lb, ub = bounds
+    lv = O.make_levels(lb, ub, dims)
+    ul = O.make_levels(ulb, uub, udims)
+    Q, R, S = np.eye(n), np.eye(m), np.zeros((n, n))
+    xbar, ubar = np.zeros(n), np.zeros(m)
+    if fancy_cost:
+        A = rng.normal(size=(n, n)); Q = A @ A.T / n
+        B = rng.normal(size=(m, m)); R = B @ B.T + 0.1 * np.eye(m)
+        C = rng.normal(size=(n, n)); S = 3.0 * C @ C.T / n
+        xbar = 0.3 * rng.normal(size=n); ubar = 0.5 * rng.normal(size=m)
+    return O.Problem(lv, ul, dt, dyn, c, Q, R, S, xbar, ubar, INF, EPS), alpha
+
+
+EDGE_CASES = {
+    "A300_u16_policy": dict(kind="pendulum", dims=(64, 37), udims=(300,)),
+    "minimal_2x2_A1": dict(kind="pendulum", dims=(2, 2), udims=(1,)),
+    "cartpole_ragged_fancy_cost": dict(kind="cartpole", dims=(9, 8, 7, 6), udims=(70,), alpha=0.9, fancy_cost=True, EPS=0.8),
+    "doublependulum_72_actions": dict(kind="twolink", dims=(8, 8, 8, 8), udims=(9, 8), dt=0.1, alpha=0.97),
+    "everything_out_of_bounds": dict(kind="pendulum", dims=(15, 15), udims=(5,), dt=50.0),
+    "tiny_box": dict(kind="pendulum", dims=(33, 65), udims=(7,), bounds=([-0.2, -0.1], [0.3, 0.4])),
+}
+
+
+@pytest.mark.parametrize("name", list(EDGE_CASES))
+def test_edge_cases_f64_exact_and_f32_within_tolerance(name):
+    kw = dict(EDGE_CASES[name])
+    p, alpha = _custom_problem(**kw)
+    J = O.terminal_cost(p)
+    Jprev = J
+    for _ in range(4):
+        Jprev = J
+        J, pi = O.sweep(p, J, alpha)
+    for dtype, tol in (("float64", 1e-12), ("float32", REL_F32)):
+        h = native_problem(p, dtype=dtype)
+        h.terminal_cost()
+        stats, n = h.sweep(4, alpha, -1.0)
+        Jg, pig = h.get_J(), h.get_pi()
+        assert relerr(Jg, J) <= tol, (name, dtype, h.describe())
+        bad = pig != pi
+        if dtype == "float64":
+            assert not bad.any() or O.q_regret(p, Jprev, pig, alpha)[bad].max() < 1e-9
+        else:
+            assert O.q_regret(p, Jprev, pig, alpha).max() <= 1e-3 * max(1.0, np.abs(J).max())
+        assert pig.min() >= 0 and pig.max() < p.actions_n
+        h.close()
+    if name == "everything_out_of_bounds":      # dt = 50 s: only nodes at rest with zero net torque stay inside
+        assert (J == p.INF).mean() > 0.9 and (pi[J == p.INF] == 0).all()
+
+
+def test_c2_solve_to_convergence_f32_vs_f64():
+    """BASELINE configs[1] solved to tol 0.1 in both precisions: same sweep count, J* within 1e-5."""
+    p = _c2()
+    out = {}
+    for dtype in ("float64", "float32"):
+        h = native_problem(p, dtype=dtype)
+        h.terminal_cost()
+        stats, n = h.sweep(20000, 1.0, 0.1)
+        out[dtype] = (h.get_J(), n)
+        h.close()
+    assert out["float64"][1] == out["float32"][1] and 100 < out["float64"][1] < 20000
+    assert relerr(out["float32"][0], out["float64"][0]) <= REL_F32
