@@ -162,6 +162,17 @@ int pvi_build_tables(pvi_handle h, int32_t row0, int32_t nrows, double* x_next, 
                 (base class DynamicProgramming.compute_backward_step, dynamicprogramming.py:195-236). */
 int pvi_set_tables(pvi_handle h, const double* x_next, const double* G, const uint8_t* ok);
 
+/* ---- policy consumers (SURVEY 8f "next": the step after the path) ------------------------------------ */
+/* replace the device policy, e.g. after clean_infeasible_set on the host (dynamicprogramming.py:322-334) */
+int pvi_set_pi(pvi_handle h, const int64_t* pi_rows, int32_t row0, int32_t nrows);
+/* B closed-loop Euler rollouts of the look-up-table policy: u = LookUpTableController.c(x) (n-linear
+   interpolation of the INPUT values selected by pi, 0 outside the grid; dynamicprogramming.py:72-107),
+   dx = f(x,u) (pyro/control/controller.py:328-355), x_{i+1} = dx*dt + x_i (pyro/analysis/simulation.py:298-324).
+   X_traj [B][npts][n] and U_traj [B][npts][m] may be NULL; X_end [B][n] may be NULL.  float64, whole-grid handle
+   with in-kernel dynamics. */
+int pvi_rollout(pvi_handle h, int64_t B, const double* X0, int32_t npts, double dt, double* X_traj, double* U_traj,
+                double* X_end);
+
 /* ---- batched dynamics ------------------------------------------------------------------------ */
 /* dX[b] = f(X[b], U[b]) for B states (mechanical.py:238-263); host pointers, float64 */
 int pvi_eval_f(int32_t dynamics_id, const double* dyn_params, int32_t n, int32_t m, int64_t B, const double* X,

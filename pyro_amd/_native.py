@@ -66,6 +66,8 @@ SYMBOLS = {
     "pvi_synchronize": (C.c_int, [_h]),
     "pvi_build_tables": (C.c_int, [_h, C.c_int32, C.c_int32, _dp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), _dp]),
     "pvi_set_tables": (C.c_int, [_h, _dp, _dp, C.POINTER(C.c_uint8)]),
+    "pvi_set_pi": (C.c_int, [_h, C.POINTER(C.c_int64), C.c_int32, C.c_int32]),
+    "pvi_rollout": (C.c_int, [_h, C.c_int64, _dp, C.c_int32, C.c_double, _dp, _dp, _dp]),
     "pvi_eval_f": (C.c_int, [C.c_int32, _dp, C.c_int32, C.c_int32, C.c_int64, _dp, _dp, _dp]),
 }
 
@@ -235,6 +237,25 @@ class Problem:
         out = np.empty(nrows * self.plane, dtype=np.int64)
         check(lib().pvi_get_pi(self._h, out.ctypes.data_as(C.POINTER(C.c_int64)), row0, nrows))
         return out
+
+    def set_pi(self, pi, row0=None, nrows=None):
+        row0, nrows = self._rows(row0, nrows, self.rows)
+        pi = np.ascontiguousarray(pi, dtype=np.int64).ravel()
+        if pi.size != nrows * self.plane:
+            raise ValueError("Grid size does not match optimal action table size")
+        check(lib().pvi_set_pi(self._h, pi.ctypes.data_as(C.POINTER(C.c_int64)), row0, nrows))
+
+    def rollout(self, X0, npts, dt, trajectory=True):
+        """Closed-loop Euler rollouts of the device policy.  Returns (X [B,npts,n], U [B,npts,m]) or X_end [B,n]."""
+        X0 = _f64(np.atleast_2d(X0))
+        B = X0.shape[0]
+        if trajectory:
+            X = np.empty((B, npts, self.n)); U = np.empty((B, npts, self.m))
+            check(lib().pvi_rollout(self._h, B, _ptr(X0), int(npts), float(dt), _ptr(X), _ptr(U), None))
+            return X, U
+        Xe = np.empty((B, self.n))
+        check(lib().pvi_rollout(self._h, B, _ptr(X0), int(npts), float(dt), None, None, _ptr(Xe)))
+        return Xe
 
     def sweep(self, max_sweeps, alpha=1.0, tol=-1.0):
         """Returns (stats[k,4] = max J, dmax, dmin, delta ; sweeps_done)."""

@@ -1292,6 +1292,95 @@ __global__ void k_eval_f(const double* __restrict__ c16, long long B, const doub
     }
 }
 
+
+// =================================================================================================
+// batched closed-loop Euler rollouts of the look-up-table policy (one thread per trajectory, float64)
+// =================================================================================================
+template <int DYN, typename PI_T>
+__global__ void k_rollout(DevP P, const PI_T* __restrict__ pi, long long B, const double* __restrict__ X0, int npts,
+                          double dt, double* __restrict__ Xt, double* __restrict__ Ut, double* __restrict__ Xe) {
+    using D = Dyn<DYN>;
+    constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M;
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double x[N];
+#pragma unroll
+    for (int d = 0; d < N; ++d) x[d] = X0[b * N + d];
+    for (int i = 0; i < npts; ++i) {
+        // u_k = interpolation of input_from_action_id[pi[node], k] over the grid, fill 0 outside
+        double u[M], y[N];
+        int ci[N];
+        bool inb = true;
+        long long base = 0;
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+            inb = inb && !(x[d] < P.glo[d]) && !(x[d] > P.ghi[d]);
+            ci[d] = find_interval(P.lev[d], P.dim[d], P.glo[d], P.inv_step[d], x[d]);
+            y[d] = (x[d] - P.lev[d][ci[d]]) / (P.lev[d][ci[d] + 1] - P.lev[d][ci[d]]);
+            base += ci[d] * P.strd[d];
+        }
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+            double val = 0.0;
+            if (inb) {
+                if (N == 2) {
+                    const double v00 = P.utab[(int)pi[base] * M + k], v01 = P.utab[(int)pi[base + P.strd[1]] * M + k];
+                    const double v10 = P.utab[(int)pi[base + P.strd[0]] * M + k];
+                    const double v11 = P.utab[(int)pi[base + P.strd[0] + P.strd[1]] * M + k];
+                    const double a0 = 1.0 - y[0], a1 = 1.0 - y[1];
+                    val = v00 * a0 * a1 + v01 * a0 * y[1] + v10 * y[0] * a1 + v11 * y[0] * y[1];
+                } else {
+#pragma unroll
+                    for (int corner = 0; corner < (1 << N); ++corner) {
+                        double w = 1.0;
+                        long long off = base;
+#pragma unroll
+                        for (int d = 0; d < N; ++d) {
+                            const int bit = (corner >> (N - 1 - d)) & 1;
+                            w = w * (bit ? y[d] : (1.0 - y[d]));
+                            off += bit ? P.strd[d] : 0;
+                        }
+                        val = val + P.utab[(int)pi[off] * M + k] * w;
+                    }
+                }
+            }
+            u[k] = val;
+        }
+        if (Xt) {
+#pragma unroll
+            for (int d = 0; d < N; ++d) Xt[(b * npts + i) * N + d] = x[d];
+        }
+        if (Ut) {
+#pragma unroll
+            for (int k = 0; k < M; ++k) Ut[(b * npts + i) * M + k] = u[k];
+        }
+        if (i + 1 < npts) {
+            double tr[4], acc[DOF], xn[N];
+            D::trig_from_state(x, tr);
+            D dyn;
+            dyn.init(P.c, x, tr);
+            dyn.accel(u, acc);
+#pragma unroll
+            for (int j = 0; j < DOF; ++j) {
+                xn[j] = x[DOF + j] * dt + x[j];
+                xn[DOF + j] = acc[j] * dt + x[DOF + j];
+            }
+#pragma unroll
+            for (int d = 0; d < N; ++d) x[d] = xn[d];
+        }
+    }
+    if (Xe) {
+#pragma unroll
+        for (int d = 0; d < N; ++d) Xe[b * N + d] = x[d];
+    }
+}
+
+template <typename PI_T>
+__global__ void k_pi_from_i64(const long long* __restrict__ src, PI_T* __restrict__ dst, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (PI_T)src[i];
+}
+
 // dtype conversions for upload / download
 template <typename REAL>
 __global__ void k_from_f64(const double* __restrict__ src, REAL* __restrict__ dst, long long n) {
@@ -2315,6 +2404,73 @@ extern "C" int pvi_set_tables(pvi_handle h, const double* x_next, const double* 
         h->d_ok = nullptr;  // (a previously uploaded mask stays allocated until destroy)
     }
     HIPCHK(hipStreamSynchronize(h->stream));
+    return PVI_OK;
+}
+
+
+extern "C" int pvi_set_pi(pvi_handle h, const int64_t* pr, int32_t row0, int32_t nrows) {
+    if (!h || !pr) return fail(PVI_EINVAL, "NULL argument");
+    int rc = rows_check(h, row0, nrows, true);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    const long long n = (long long)nrows * h->plane, off = (long long)(row0 - h->P.row_begin) * h->plane;
+    for (long long s = 0; s < n; s += STAGE_CHUNK) {
+        const long long c = n - s < STAGE_CHUNK ? n - s : STAGE_CHUNK;
+        if ((rc = ensure_stage(h, c))) return rc;
+        HIPCHK(hipMemcpyAsync(h->stage, pr + s, (size_t)c * 8, hipMemcpyHostToDevice, h->stream));
+        if (h->pi_size == 1)
+            hipLaunchKernelGGL((k_pi_from_i64<unsigned char>), grid_for(c), 256, 0, h->stream, (const long long*)h->stage,
+                               (unsigned char*)h->pi + off + s, c);
+        else
+            hipLaunchKernelGGL((k_pi_from_i64<unsigned short>), grid_for(c), 256, 0, h->stream, (const long long*)h->stage,
+                               (unsigned short*)h->pi + off + s, c);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return PVI_OK;
+}
+
+extern "C" int pvi_rollout(pvi_handle h, int64_t B, const double* X0, int32_t npts, double dt, double* X_traj,
+                           double* U_traj, double* X_end) {
+    if (!h || !X0) return fail(PVI_EINVAL, "NULL argument");
+    if (h->d.dynamics_id == PVI_DYN_TABLE) return fail(PVI_ESTATE, "rollouts need in-kernel dynamics");
+    if (h->P.store_begin != 0 || h->P.store_end != h->P.dim[0] || h->P.row_begin != 0 || h->P.row_end != h->P.dim[0])
+        return fail(PVI_ESTATE, "rollouts need a whole-grid handle");
+    if (B <= 0 || npts < 1) return PVI_OK;
+    HIPCHK(hipSetDevice(h->device));
+    const int N = h->P.n, M = h->P.m;
+    double *dX0 = nullptr, *dXt = nullptr, *dUt = nullptr, *dXe = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(dX0); (void)hipFree(dXt); (void)hipFree(dUt); (void)hipFree(dXe);
+    };
+    hipError_t e = hipMalloc((void**)&dX0, (size_t)B * N * 8);
+    if (e == hipSuccess && X_traj) e = hipMalloc((void**)&dXt, (size_t)B * npts * N * 8);
+    if (e == hipSuccess && U_traj) e = hipMalloc((void**)&dUt, (size_t)B * npts * M * 8);
+    if (e == hipSuccess && X_end) e = hipMalloc((void**)&dXe, (size_t)B * N * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(dX0, X0, (size_t)B * N * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        const unsigned g = grid_for(B, 64);
+#define ROLL(DYN)                                                                                                    \
+    if (h->pi_size == 1)                                                                                             \
+        hipLaunchKernelGGL((k_rollout<DYN, unsigned char>), g, 64, 0, h->stream, h->P, (const unsigned char*)h->pi,   \
+                           (long long)B, dX0, npts, dt, dXt, dUt, dXe);                                              \
+    else                                                                                                             \
+        hipLaunchKernelGGL((k_rollout<DYN, unsigned short>), g, 64, 0, h->stream, h->P, (const unsigned short*)h->pi, \
+                           (long long)B, dX0, npts, dt, dXt, dUt, dXe);
+        switch (h->d.dynamics_id) {
+            case PVI_DYN_PENDULUM: ROLL(PVI_DYN_PENDULUM) break;
+            case PVI_DYN_CARTPOLE: ROLL(PVI_DYN_CARTPOLE) break;
+            default: ROLL(PVI_DYN_TWOLINK) break;
+        }
+#undef ROLL
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && X_traj) e = hipMemcpyAsync(X_traj, dXt, (size_t)B * npts * N * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && U_traj) e = hipMemcpyAsync(U_traj, dUt, (size_t)B * npts * M * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && X_end) e = hipMemcpyAsync(X_end, dXe, (size_t)B * N * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(PVI_EHIP, "pvi_rollout failed: %s", hipGetErrorString(e));
     return PVI_OK;
 }
 

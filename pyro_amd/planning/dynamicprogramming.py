@@ -242,6 +242,17 @@ class DynamicProgramming:
     def get_lookup_table_controller(self):
         return LookUpTableController(self.grid_sys, self.pi)
 
+    def simulate_closed_loop(self, X0, tf=10.0, n=10001):
+        """(not in the reference) B closed-loop Euler trajectories of the current policy on the GPU: what
+        `(dp.get_lookup_table_controller() + sys).compute_trajectory(tf, n, 'euler')` does for one x0
+        (controller.py:328-355, simulation.py:298-324).  Returns t [n], X [B,n,sys.n], U [B,n,sys.m]."""
+        if self.tier != "fused":
+            raise NotImplementedError("batched rollouts need in-kernel dynamics")
+        self._p.set_pi(self.pi)                 # the host policy may have been edited (clean_infeasible_set)
+        dt = (tf + 0.0) / (n - 1)
+        X, U = self._p.rollout(X0, n, dt)
+        return np.linspace(0, tf, n), X, U
+
     def save_latest(self, name="test_data"):
         """Writes J_next (not J), as the reference does (:481-485)."""
         np.save(name + "_J_inf", self.J_next)

@@ -421,7 +421,38 @@ def case_policy_eval():
     save("policy_eval_41x41", **out)
 
 
-CASES = dict(f_kat=case_f_kat, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
+def case_rollout():
+    """Closed-loop Euler rollouts of a LookUpTableController (pendulum 21x21x5, 40 sweeps, cleaned policy):
+    x_{i+1} = cl_sys.f(x_i, r, t_i)*dt + x_i exactly as Simulator('euler') (simulation.py:298-324) with
+    cl_sys = ctl + sys (controller.py:328-355)."""
+    s, g, q = _pendulum_problem((21, 21), (5,))
+    with quiet():
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, q)
+        dp.save_time_history = False
+        dp.compute_steps(40)
+        dp.clean_infeasible_set()
+        ctl = dp.get_lookup_table_controller()
+        cl = ctl + s
+    rng = np.random.default_rng(5)
+    X0 = rng.uniform(s.x_lb * 0.9, s.x_ub * 0.9, size=(12, 2))
+    X0[0] = [0.0, 0.0]; X0[1] = [-3.0, 0.5]; X0[2] = [6.2, 6.2]        # the last one leaves the grid quickly
+    tf, npts = 3.0, 121
+    dt = (tf + 0.0) / (npts - 1)
+    t = np.linspace(0, tf, npts)
+    X = np.zeros((12, npts, 2)); U = np.zeros((12, npts, 1))
+    for b in range(12):
+        x = X0[b].copy()
+        for i in range(npts):
+            X[b, i] = x
+            U[b, i] = ctl.c(x, ctl.rbar, t[i])
+            if i + 1 < npts:
+                x = cl.f(x, ctl.rbar, t[i]) * dt + x
+    out = _meta(s, g, q)
+    out.update(J=dp.J, pi=dp.pi.astype(np.int16), X0=X0, tf=tf, npts=npts, X=X, U=U)
+    save("rollout_pendulum_21x21x5", **out)
+
+
+CASES = dict(f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
              policy_eval=case_policy_eval, cost_kat=case_cost_kat, grid_kat=case_grid_kat,
              pendulum_small=case_pendulum_small, config1=case_config1, lowdef=case_lowdef,
              pendulum_demo=case_pendulum_demo, cartpole_small=case_cartpole_small,

@@ -615,3 +615,33 @@ def test_c2_solve_to_convergence_f32_vs_f64():
         h.close()
     assert out["float64"][1] == out["float32"][1] and 100 < out["float64"][1] < 20000
     assert relerr(out["float32"][0], out["float64"][0]) <= REL_F32
+
+
+# ------------------------------------------------------------------------------------- batched rollouts (next #2)
+def test_batched_rollouts_match_reference():
+    """pvi_rollout: LookUpTableController interpolation + f + Euler for a batch of initial states, against the
+    reference's closed loop (golden) and through the class surface (policy edited on the host, re-uploaded)."""
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import pendulum
+    from pyro_amd.planning import discretizer, dynamicprogramming
+    g = load("rollout_pendulum_21x21x5")
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = pendulum.SinglePendulum()
+        grid = discretizer.GridDynamicSystem(s, [21, 21], [5])
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+        q.xbar, q.INF = np.array([-3.14, 0.0]), 300
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(grid, q)
+        dp.save_time_history = False
+        dp.compute_steps(40)
+        dp.clean_infeasible_set()
+    assert np.array_equal(dp.pi, g["pi"])
+    t, X, U = dp.simulate_closed_loop(g["X0"], tf=float(g["tf"]), n=int(g["npts"]))
+    np.testing.assert_allclose(U, g["U"], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(X, g["X"], rtol=1e-8, atol=1e-8)
+    # a larger batch: end states only
+    rng = np.random.default_rng(0)
+    X0 = rng.uniform(s.x_lb, s.x_ub, size=(4096, 2))
+    Xe = dp._p.rollout(X0, 121, 0.025, trajectory=False)
+    p = oracle_problem(g, O.DYN_PENDULUM, O.pendulum_consts())
+    Xo, _ = O.rollout(p, dp.pi, X0[:64], 121, 3.0)
+    np.testing.assert_allclose(Xe[:64], Xo[:, -1], rtol=1e-7, atol=1e-7)

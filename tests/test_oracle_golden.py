@@ -291,3 +291,13 @@ def test_policy_evaluator_golden():
         J, _, _ = O.sweep_lut(lv, g["x_next_table"][:, None, :], g["G"][:, None], J)
         if k in (1, 10):
             np.testing.assert_allclose(J, g["J_%d" % k], rtol=1e-13, atol=1e-13)
+
+
+def test_rollout_golden():
+    """Closed-loop Euler rollouts of the look-up-table policy against the reference's ctl + sys loop."""
+    g = load("rollout_pendulum_21x21x5")
+    p = problem_from(g, O.DYN_PENDULUM, O.pendulum_consts())
+    X, U = O.rollout(p, g["pi"].astype(np.int64), g["X0"], int(g["npts"]), float(g["tf"]))
+    np.testing.assert_allclose(U, g["U"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(X, g["X"], rtol=1e-9, atol=1e-9)
+    assert (g["U"][2, 5:] == 0).all()          # the trajectory that leaves the grid gets u = 0 (fill value)
