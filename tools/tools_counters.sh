@@ -7,7 +7,7 @@ OUT=/root/repo/gpurun_out/counters_$W; mkdir -p $OUT
 i=0
 for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -o p -- python /root/repo/tools_traffic.py $W > $OUT/p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -o p -- python /root/repo/tools/tools_traffic.py $W > $OUT/p$i.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, json

@@ -4,7 +4,7 @@ W=$1
 cd /tmp && export TMPDIR=/tmp
 OUT=/root/repo/gpurun_out/traffic_$W; mkdir -p $OUT
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -o p -- python /root/repo/tools_traffic.py $W > $OUT/$C.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -o p -- python /root/repo/tools/tools_traffic.py $W > $OUT/$C.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, json
