@@ -645,3 +645,38 @@ def test_batched_rollouts_match_reference():
     p = oracle_problem(g, O.DYN_PENDULUM, O.pendulum_consts())
     Xo, _ = O.rollout(p, dp.pi, X0[:64], 121, 3.0)
     np.testing.assert_allclose(Xe[:64], Xo[:, -1], rtol=1e-7, atol=1e-7)
+
+
+def test_class_surface_host_edits_and_three_step_api(tmp_path):
+    """dp.J assigned on the host is uploaded before the next sweep; the initialize/compute/finalize triple and
+    save_latest / load_J_next behave like the reference (dynamicprogramming.py:175-261, :481-499)."""
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import pendulum
+    from pyro_amd.planning import discretizer, dynamicprogramming
+    g = load("pendulum_21x21x5")
+    p = oracle_problem(g, O.DYN_PENDULUM, O.pendulum_consts())
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = pendulum.SinglePendulum()
+        grid = discretizer.GridDynamicSystem(s, [21, 21], [5])
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+        q.xbar, q.INF = np.array([-3.14, 0.0]), 300
+        dp = dynamicprogramming.DynamicProgramming(grid, q)        # base class: same recursion for box validity
+        rng = np.random.default_rng(3)
+        J0 = rng.uniform(0, 50, grid.nodes_n)
+        dp.J = J0
+        dp.alpha = 0.9
+        dp.initialize_backward_step()
+        dp.compute_backward_step()
+        delta = dp.finalize_backward_step()
+    Jn, pi = O.sweep(p, J0, 0.9)
+    assert relerr(dp.J, Jn) < 1e-13 and np.array_equal(dp.pi, pi)
+    assert abs(delta - O.sweep_stats(Jn, J0)[1]) < 1e-9
+    assert relerr(dp.J_next, J0) < 1e-15 and dp.k == 1 and abs(dp.t + 0.05) < 1e-12
+    name = str(tmp_path / "vi")
+    dp.save_latest(name)
+    assert np.array_equal(np.load(name + "_J_inf.npy"), dp.J_next)             # J_next, not J (:484)
+    assert np.array_equal(np.load(name + "_pi_inf.npy"), dp.pi)
+    dp.load_J_next(name)
+    assert relerr(dp.J_next, J0) < 1e-15
+    with pytest.raises(ValueError):
+        dp.J = np.zeros(7)
