@@ -1537,8 +1537,12 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
     h->lean_grid = dim3((unsigned)ntiles, 1, 1);
     int rc;
     if (L.win) dev_release(h, L.win);
+    if (L.tbt) dev_release(h, L.tbt);
     L.win = nullptr;
+    L.tbt = nullptr;
+    L.tb_tile = 0;
     if ((rc = dev_alloc(h, (size_t)ntiles * 8, &L.win))) return rc;
+    if ((rc = dev_alloc(h, (size_t)ntiles * 4, &L.tbt))) return rc;
     hipLaunchKernelGGL(k_lean_winit, grid_for(std::max<long long>(ntiles * 4, 4)), 256, 0, h->stream, L.win, ntiles,
                        L.summary);
     const int sthreads = ((L.TV0 * L.TV1 + 63) / 64) * 64;
@@ -1566,6 +1570,7 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
     // (A pitch congruent to the tile width modulo 32 -- consecutive lanes on consecutive banks across
     // tile rows -- was measured: fewer conflict cycles per LDS instruction, but the larger pitch costs
     // LDS capacity and one more address add per corner; no net gain.  PVI_RS_MODE=1 selects it.)
+    L.tb_tile = (summary[2] == 0 && !getenv("PVI_NO_TBTILE")) ? 1 : 0;
     int rs = (summary[1] + 1) | 1;
     if (const char* e = getenv("PVI_RS_MODE")) {
         if (atoi(e) == 1 && DOF == 2) rs = summary[1] + 1 + (((L.TV1 - summary[1] - 1) % 32 + 32) % 32);
@@ -1643,6 +1648,10 @@ static int lean_setup(pvi_problem* h) {
             if (h->lean_block > 512) continue;
             h->lean_ok = true;
             h->lean_lds_attr = false;
+            if (L.tb_tile) {  // tB lives per tile: the per-node copy is not needed any more
+                dev_release(h, L.tB);
+                L.tB = nullptr;
+            }
             break;
         }
     }
@@ -1673,8 +1682,8 @@ static int lean_setup(pvi_problem* h) {
     }
     if (!h->lean_ok) {  // release the per-node arrays: the fast / tiled kernels do not need them
         dev_release(h, L.ta); dev_release(h, L.tB); dev_release(h, L.gx); dev_release(h, L.flag);
-        dev_release(h, L.win);
-        L.ta = L.tB = L.gx = nullptr; L.flag = nullptr; L.win = nullptr;
+        dev_release(h, L.win); dev_release(h, L.tbt);
+        L.ta = L.tB = L.gx = nullptr; L.flag = nullptr; L.win = nullptr; L.tbt = nullptr;
     }
     return PVI_OK;
 }
@@ -1937,9 +1946,9 @@ extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
                        : h->lean_ok ? "lean"
                        : h->tile_ok ? "tile"
                        : h->fast_ok ? "fast" : (h->d.dynamics_id == PVI_DYN_TABLE ? "table" : "exact-f32");
-    snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d note=%s", path,
+    snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d note=%s", path,
              h->LP.TV0, h->LP.TV1, h->lean_grid.x, h->lean_grid.y, h->lean_grid.z, h->lean_block, h->lean_pw1,
-             h->lean_lds, h->lean_ok ? h->LP.lsplit : h->F.lsplit, h->lean_why);
+             h->lean_lds, h->lean_ok ? h->LP.lsplit : h->F.lsplit, h->LP.tb_tile, h->lean_why);
     return PVI_OK;
 }
 
