@@ -224,21 +224,51 @@ class GridDynamicSystem:
         out = np.asarray(Z[tuple(idx)], dtype=float)
         return out if axis_1 < axis_2 else out.T
 
-    # ------------------------------------------------------------------ plots: host pass-through
-    def plot_grid_value(self, J, name="Value on the grid", x=0, y=1, jmax=np.inf, jmin=0):
+    # ------------------------------------------------------------------ plots: host pass-through (matplotlib)
+    def _slice_2d(self, J, x, y, jmin, jmax):
+        Z = self.get_2D_slice_of_grid(self.get_grid_from_array(np.asarray(J, dtype=float)), x, y)
+        return np.clip(Z, jmin, jmax)
+
+    def _label_axes(self, ax, x, y):
+        s = self.sys
+        ax.set_xlabel(s.state_label[x] + " " + s.state_units[x], fontsize=self.fontsize)
+        ax.set_ylabel(s.state_label[y] + " " + s.state_units[y], fontsize=self.fontsize)
+        ax.tick_params(labelsize=self.fontsize)
+
+    def plot_grid_value(self, J, name="Value on the grid", x=0, y=1, jmax=np.inf, jmin=-1, cmap="YlOrRd"):
+        """2-D colour map of a node array over state axes (x, y); other axes sliced at sys.xbar
+        (discretizer.py:668-735).  Returns (fig, ax, mesh)."""
         import matplotlib.pyplot as plt
-        fig, ax = plt.subplots(figsize=self.figsize, dpi=self.dpi)
-        Z = self.get_2D_slice_of_grid(self.get_grid_from_array(J), x, y)
-        pcm = ax.pcolormesh(self.x_level[x], self.x_level[y], np.clip(Z, jmin, jmax).T, shading="gouraud")
-        ax.set_xlabel(self.sys.state_label[x] + " " + self.sys.state_units[x], fontsize=self.fontsize)
-        ax.set_ylabel(self.sys.state_label[y] + " " + self.sys.state_units[y], fontsize=self.fontsize)
-        ax.set_title(name, fontsize=self.fontsize)
-        fig.colorbar(pcm, ax=ax)
-        return fig, ax, pcm
+        fig, ax = plt.subplots(figsize=self.figsize, dpi=self.dpi, frameon=True)
+        fig.canvas.manager.set_window_title(name)
+        mesh = ax.pcolormesh(self.x_level[x], self.x_level[y], self._slice_2d(J, x, y, jmin, jmax).T,
+                             shading="gouraud", cmap=cmap)
+        self._label_axes(ax, x, y)
+        ax.grid(True)
+        cbar = fig.colorbar(mesh, ax=ax)
+        cbar.ax.tick_params(labelsize=self.fontsize)
+        fig.tight_layout()
+        return fig, ax, mesh
+
+    def plot_grid_value_3D(self, J, J2=None, name="Value on the grid", x=0, y=1, jmax=np.inf, jmin=-1, cmap="YlOrRd"):
+        """Surface plot of one (or two) node arrays (discretizer.py:739-823).  Returns (fig, ax, surf)."""
+        import matplotlib.pyplot as plt
+        fig = plt.figure(figsize=self.figsize, dpi=self.dpi)
+        ax = fig.add_subplot(projection="3d")
+        fig.canvas.manager.set_window_title(name)
+        X, Y = np.meshgrid(self.x_level[x], self.x_level[y], indexing="ij")
+        surf = ax.plot_surface(X, Y, self._slice_2d(J, x, y, jmin, jmax), cmap=cmap, linewidth=0, antialiased=False)
+        if J2 is not None:
+            ax.plot_surface(X, Y, self._slice_2d(J2, x, y, jmin, jmax), alpha=0.5, linewidth=0)
+        self._label_axes(ax, x, y)
+        ax.set_zlabel(name, fontsize=self.fontsize)
+        fig.tight_layout()
+        return fig, ax, surf
 
     def plot_control_input_from_policy(self, pi, k, i=0, j=1):
-        u = self.get_input_from_policy(pi, k)
-        return self.plot_grid_value(u, self.sys.input_label[k], i, j, self.sys.u_ub[k], self.sys.u_lb[k])
+        """Colour map of input axis k selected by the policy (discretizer.py:826-834)."""
+        return self.plot_grid_value(self.get_input_from_policy(pi, k), self.sys.input_label[k], i, j,
+                                    self.sys.u_ub[k], self.sys.u_lb[k], cmap="bwr")
 
 
 def device_dynamics_of(sys):

@@ -215,10 +215,29 @@ class DynamicProgramming:
             self.pi_list.append(self.pi)
         return delta
 
+    def _animated(self, max_sweeps, tol, animate_cost2go, animate_policy, k):
+        """Sweep-by-sweep driver used when a live plot is requested (one host round trip per sweep)."""
+        if animate_cost2go:
+            self.plot_cost2go()
+        if animate_policy:
+            self.plot_policy(k)
+        delta, done = self.cf.INF, 0
+        while done < max_sweeps and (tol < 0 or delta > tol):
+            delta = self._run(1, -1.0)
+            done += 1
+            if animate_cost2go:
+                self.update_cost2go_plot()
+            if animate_policy:
+                self.update_policy_plot()
+        return delta
+
     def compute_steps(self, n=50, animate_cost2go=False, animate_policy=False, k=0):
         print("\nComputing %d backward DP iterations:" % n)
         print("-----------------------------------------")
-        self._run(n, -1.0)
+        if animate_cost2go or animate_policy:
+            self._animated(n, -1.0, animate_cost2go, animate_policy, k)
+        else:
+            self._run(n, -1.0)
 
     def solve_bellman_equation(self, tol=0.1, animate_cost2go=False, animate_policy=False, k=0):
         """Backups until max|J - J_next| <= tol (dynamicprogramming.py:283-314); delta starts at
@@ -226,8 +245,12 @@ class DynamicProgramming:
         print("\nComputing backward DP iterations until dJ<%2.2f:" % tol)
         print("---------------------------------------------------------")
         delta = self.cf.INF
-        while delta > tol:
-            delta = self._run(1 << 30, tol)
+        if animate_cost2go or animate_policy:
+            if delta > tol:
+                self._animated(1 << 30, tol, animate_cost2go, animate_policy, k)
+        else:
+            while delta > tol:
+                delta = self._run(1 << 30, tol)
         print("\nBellman equation solved!")
 
     def clean_infeasible_set(self, tol=1):
@@ -264,15 +287,84 @@ class DynamicProgramming:
         except Exception:
             print("Failed to load J_next ")
 
-    # ------------------------------------------------------------------ plots: host pass-through
+    # ------------------------------------------------------------------ plots: host pass-through (matplotlib)
+    # (dynamicprogramming.py:343-464: thin wrappers over the GridDynamicSystem plots, on downloaded arrays)
     def plot_cost2go(self, jmax=None, i=0, j=1, show=True):
+        import matplotlib.pyplot as plt
         jmax = self.cf.INF if jmax is None else jmax
         fig, ax, pcm = self.grid_sys.plot_grid_value(self.J, "Cost-to-go", i, j, jmax, 0)
         self.cost2go_fig = [fig, ax, pcm, ax.text(0.05, 0.05, "", transform=ax.transAxes, fontsize=8), i, j]
+        plt.ion()
+        if show:
+            plt.pause(0.001)
+
+    def update_cost2go_plot(self, show=True):
+        import matplotlib.pyplot as plt
+        g = self.grid_sys
+        Z = g.get_2D_slice_of_grid(g.get_grid_from_array(self.J), self.cost2go_fig[4], self.cost2go_fig[5])
+        self.cost2go_fig[2].set_array(np.ravel(Z.T))
+        self.cost2go_fig[3].set_text("Optimal cost2go at time = %4.2f" % self.t)
+        if show:
+            plt.pause(0.001)
 
     def plot_policy(self, k=0, i=0, j=1, show=True):
+        import matplotlib.pyplot as plt
         fig, ax, pcm = self.grid_sys.plot_control_input_from_policy(self.pi, k, i, j)
         self.policy_fig = [fig, ax, pcm, ax.text(0.05, 0.05, "", transform=ax.transAxes, fontsize=8), k, i, j]
+        plt.ion()
+        if show:
+            plt.pause(0.001)
+
+    def update_policy_plot(self, show=True):
+        import matplotlib.pyplot as plt
+        g = self.grid_sys
+        uk = g.get_grid_from_array(g.get_input_from_policy(self.pi, self.policy_fig[4]))
+        self.policy_fig[2].set_array(np.ravel(g.get_2D_slice_of_grid(uk, self.policy_fig[5], self.policy_fig[6]).T))
+        self.policy_fig[3].set_text("Optimal policy at time = %4.2f" % self.t)
+        if show:
+            plt.pause(0.001)
+
+    def plot_cost2go_3D(self, jmax=None, i=0, j=1, show=True):
+        jmax = self.cf.INF if jmax is None else jmax
+        fig, ax, surf = self.grid_sys.plot_grid_value_3D(self.J, None, "Cost-to-go", i, j, jmax, 0)
+        self.cost2go_3D_fig = [fig, ax, surf, ax.text2D(0.05, 0.05, "", transform=ax.transAxes, fontsize=8), i, j]
+
+    def _frame(self, n, with_policy):
+        self.J, self.t = self.J_list[n], self.t_list[n]
+        if with_policy:
+            self.pi = self.pi_list[n]
+        self.clean_infeasible_set()
+
+    def animate_cost2go(self, i=0, j=1, jmax=None, show=True, save=False, file_name="cost2go_animation"):
+        """Replays J_list (needs save_time_history)."""
+        import matplotlib.animation as animation
+        self._frame(0, False)
+        self.plot_cost2go(jmax=jmax, i=i, j=j, show=False)
+
+        def step(n):
+            self._frame(n, False)
+            self.update_cost2go_plot(show=False)
+        self.ani = animation.FuncAnimation(self.cost2go_fig[0], step, len(self.J_list), interval=20)
+        if save:
+            self.ani.save(file_name + ".gif", writer="imagemagick", fps=30)
+        if show:
+            self.cost2go_fig[0].show()
+        return self.ani
+
+    def animate_policy(self, k=0, i=0, j=1, show=True, save=False, file_name="policy_animation"):
+        import matplotlib.animation as animation
+        self._frame(1, True)
+        self.plot_policy(k=k, i=i, j=j, show=False)
+
+        def step(n):
+            self._frame(n + 1, True)
+            self.update_policy_plot(show=False)
+        self.ani = animation.FuncAnimation(self.policy_fig[0], step, len(self.pi_list) - 1, interval=20)
+        if save:
+            self.ani.save(file_name + ".gif", writer="imagemagick", fps=30)
+        if show:
+            self.policy_fig[0].show()
+        return self.ani
 
 
 class DynamicProgrammingWithLookUpTable(DynamicProgramming):

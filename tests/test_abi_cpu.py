@@ -143,3 +143,27 @@ def test_host_costs_match_reference_kat():
     assert np.array_equal([r.g(X[i], U[i], 0) for i in range(48)], g["reach_g"])
     assert np.array_equal([r.h(X[i], 0) for i in range(48)], g["reach_h"])
     assert q.INF == 1e3 and r.INF == float(g["reach_INF"]) and r.EPS == float(g["reach_EPS"])
+
+
+def test_grid_plot_passthroughs():
+    """The plot helpers are thin matplotlib pass-throughs on host arrays (Agg backend, nothing is shown)."""
+    import matplotlib
+    matplotlib.use("Agg")
+    from pyro_amd.dynamic import cartpole, pendulum
+    from pyro_amd.planning import discretizer
+    with contextlib.redirect_stdout(io.StringIO()):
+        g2 = discretizer.GridDynamicSystem(pendulum.SinglePendulum(), [21, 17], [5])
+        g4 = discretizer.GridDynamicSystem(cartpole.CartPole(), [5, 6, 7, 8], [3])
+    rng = np.random.default_rng(0)
+    fig, ax, mesh = g2.plot_grid_value(rng.uniform(0, 100, g2.nodes_n), "J", 0, 1, 80, 0)
+    assert mesh.get_array().shape == (17, 21) and float(mesh.get_array().max()) <= 80
+    fig, ax, surf = g2.plot_grid_value_3D(rng.uniform(0, 100, g2.nodes_n), None, "J")
+    fig, ax, mesh = g2.plot_control_input_from_policy(rng.integers(0, 5, g2.nodes_n), 0)
+    fig, ax, mesh = g4.plot_grid_value(rng.uniform(0, 1, g4.nodes_n), "J", 1, 3)      # 4-D: sliced at sys.xbar
+    assert mesh.get_array().shape == (8, 6)
+    Z = rng.uniform(size=(5, 6, 7, 8))
+    idx = g4.get_nearest_index_from_state(g4.sys.xbar)
+    assert np.array_equal(g4.get_2D_slice_of_grid(Z, 1, 3), Z[idx[0], :, idx[2], :])
+    assert np.array_equal(g4.get_2D_slice_of_grid(Z, 3, 1), Z[idx[0], :, idx[2], :].T)
+    import matplotlib.pyplot as plt
+    plt.close("all")

@@ -309,6 +309,17 @@ def test_class_surface_small_with_history_and_controller():
         dp.clean_infeasible_set()
         np.testing.assert_allclose(dp.J, g["J_clean"], rtol=1e-13)
         assert np.array_equal(dp.pi, g["pi_clean"])
+        import matplotlib
+        matplotlib.use("Agg")
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            dp.plot_cost2go(); dp.update_cost2go_plot(); dp.plot_policy(); dp.update_policy_plot(); dp.plot_cost2go_3D()
+            ani = dp.animate_cost2go(show=False)
+        assert len(dp.J_list) == 11
+        import matplotlib.pyplot as plt
+        plt.close("all")
+        dp.J, dp.pi = g["J_clean"].copy(), g["pi_clean"].copy()
         ctl = dp.get_lookup_table_controller()
         u = np.array([ctl.c(x, 0) for x in g["ctl_x"]])
     np.testing.assert_allclose(u, g["ctl_u"], rtol=1e-12, atol=1e-12)
