@@ -1534,6 +1534,7 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
     L.xq = L.nblocks / 8u;
     L.xrem = L.nblocks % 8u;
     L.xcd_remap = getenv("PVI_NO_XCD") ? 0 : 1;
+    L.dbg = getenv("PVI_DBG") ? atoi(getenv("PVI_DBG")) : 0;
     h->lean_grid = dim3((unsigned)ntiles, 1, 1);
     int rc;
     if (L.win) dev_release(h, L.win);

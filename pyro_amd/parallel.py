@@ -60,7 +60,14 @@ class HipSlab:
         self.cur = 0
         self.p = grid_sys._device_problem(cost=cost, dtype=dtype, rows=rows, halo=(halo, halo), device=device,
                                           ext_J=[t.data_ptr() for t in self.J], ext_pi=self.pi.data_ptr())
-        self._stream = torch.cuda.current_stream(self.dev).cuda_stream
+        # One dedicated stream orders everything of this rank: sweep kernels (handed to the library as a raw
+        # hipStream_t), halo copies and collectives (torch / RCCL synchronise with the CURRENT torch stream).
+        # It must not be torch's default stream: that one has handle 0, which the C ABI reads as "use the
+        # handle's own stream" -- kernels and halo traffic would then run unordered.
+        self.tstream = torch.cuda.Stream(device=self.dev)
+        torch.cuda.set_stream(self.tstream)
+        self._stream = self.tstream.cuda_stream
+        assert self._stream != 0
 
     def terminal_cost(self):
         self.p.terminal_cost()
@@ -117,22 +124,34 @@ class ShardedValueIteration:
         d, s, h = self.dist, self.slab, self.halo
         r0, r1 = self.rows
         if self.p2p:
-            ops = []
+            lo, hi = s.store_rows
+            sends, recvs = [], []                                # (tensor view, peer)
             if self.rank > 0:                                   # lower neighbour
-                lo = s.store_rows[0]
-                ops.append(d.P2POp(d.isend, s.rows_view(r0, h), self.rank - 1))
-                ops.append(d.P2POp(d.irecv, s.rows_view(lo, r0 - lo), self.rank - 1))
+                sends.append((s.rows_view(r0, h), self.rank - 1))
+                recvs.append((s.rows_view(lo, r0 - lo), self.rank - 1))
             if self.rank < self.world - 1:                      # upper neighbour
-                hi = s.store_rows[1]
-                ops.append(d.P2POp(d.isend, s.rows_view(r1 - h, h), self.rank + 1))
-                ops.append(d.P2POp(d.irecv, s.rows_view(r1, hi - r1), self.rank + 1))
-            for w in d.batch_isend_irecv(ops):
-                w.wait()
+                sends.append((s.rows_view(r1 - h, h), self.rank + 1))
+                recvs.append((s.rows_view(r1, hi - r1), self.rank + 1))
+            staged = self._needs_host_staging(sends[0][0]) if sends else False
+            if staged:
+                # process group without device-memory transport (gloo): stage through host buffers
+                out = [(t.cpu(), peer) for t, peer in sends]
+                inn = [(self.torch.empty(t.shape, dtype=t.dtype), t, peer) for t, peer in recvs]
+                ops = [d.P2POp(d.isend, t, peer) for t, peer in out] + [d.P2POp(d.irecv, b, peer) for b, _, peer in inn]
+                for w in d.batch_isend_irecv(ops):
+                    w.wait()
+                for b, t, _ in inn:
+                    t.copy_(b)
+            else:
+                ops = [d.P2POp(d.isend, t, peer) for t, peer in sends] + [d.P2POp(d.irecv, t, peer) for t, peer in recvs]
+                for w in d.batch_isend_irecv(ops):
+                    w.wait()
         else:
             # slabs thinner than the halo: gather everybody's rows (padded to equal length)
             width = max(b - a for a, b in self.parts)
             mine = s.rows_view(r0, r1 - r0)
-            pad = self.torch.zeros(width * s.plane, dtype=mine.dtype, device=mine.device)
+            dev = "cpu" if self._needs_host_staging(mine) else mine.device
+            pad = self.torch.zeros(width * s.plane, dtype=mine.dtype, device=dev)
             pad[:mine.numel()] = mine
             bufs = [self.torch.empty_like(pad) for _ in range(self.world)]
             d.all_gather(bufs, pad)
@@ -140,12 +159,16 @@ class ShardedValueIteration:
                 if k != self.rank:
                     s.rows_view(a, b - a).copy_(bufs[k][:(b - a) * s.plane])
 
+    def _needs_host_staging(self, t):
+        """True when `t` lives on a device the process group cannot move (gloo + GPU tensors)."""
+        return bool(getattr(t, "is_cuda", False)) and str(self.dist.get_backend()) == "gloo"
+
     def _reduce_stats(self):
         st = np.asarray(self.slab.stats(), dtype=np.float64)
         if self.world > 1:
             t = self.torch.tensor([st[0], st[1], -st[2]], dtype=self.torch.float64)
             dev = getattr(self.slab, "dev", None)
-            if dev is not None:
+            if dev is not None and str(self.dist.get_backend()) != "gloo":
                 t = t.to(dev)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             t = t.cpu().numpy()

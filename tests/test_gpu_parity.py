@@ -691,3 +691,56 @@ def test_class_surface_host_edits_and_three_step_api(tmp_path):
     assert relerr(dp.J_next, J0) < 1e-15
     with pytest.raises(ValueError):
         dp.J = np.zeros(7)
+
+
+_WORLD2 = r"""
+import contextlib, io, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %r)
+from pyro_amd import configs, parallel
+rank, out = int(sys.argv[1]), sys.argv[2]
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d", rank=rank, world_size=2)
+with contextlib.redirect_stdout(io.StringIO()):
+    cfg = configs.build("%s")
+vi = parallel.ShardedValueIteration(cfg["grid_sys"], cfg["cf"], dist, dtype="float32", device=0)
+stats = [vi.sweep(1.0) for _ in range(4)]
+last = vi.run(3, 1.0, -1.0)
+J, pi = vi.gather()
+if rank == 0:
+    np.savez(out, J=J, pi=pi, stats=np.array(stats + [last]), p2p=vi.p2p, halo=vi.halo)
+dist.destroy_process_group()
+print("WORLD2-OK", rank)
+"""
+
+
+@pytest.mark.parametrize("case", ["cartpole:21,21,21,21:7:float32", "pendulum:101,101:11:float32"])
+def test_two_ranks_share_one_gpu(tmp_path, case):
+    """The sharded driver with the product HipSlab on real hardware: two processes (both on GPU 0), halo rows moved
+    by a gloo process group through host staging, statistics all-reduced -- must equal the single-handle result
+    bit for bit (same kernels, same arithmetic per node).  RCCL itself is the only part not exercised here."""
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "res.npz")
+    code = _WORLD2 % (ROOT, port, case)
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    logs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all("WORLD2-OK" in l for l in logs), "\n".join(l[-1500:] for l in logs)
+    r = np.load(out)
+    from pyro_amd import configs
+    from pyro_amd.planning import dynamicprogramming
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg = configs.build(case)
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype="float32")
+    stats, _ = dp._p.sweep(7, 1.0, -1.0)
+    assert np.array_equal(r["J"], dp._p.get_J()) and np.array_equal(r["pi"], dp._p.get_pi())
+    np.testing.assert_allclose(r["stats"][:4], stats[:4], rtol=1e-12)
+    np.testing.assert_allclose(r["stats"][4], stats[6], rtol=1e-12)
+    assert bool(r["p2p"])
