@@ -537,16 +537,23 @@ __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ 
             for (int k = 0; k < M; ++k) u[k] = P.utab[a * M + k];
             dyn.accel(u, acc);
             bool ok = pos_ok && P.aok[a], inb = pos_in;
-            long long b = base;
+            double xnv[DOF];
 #pragma unroll
             for (int i = 0; i < DOF; ++i) {
                 const int d = DOF + i;
-                const double xn = acc[i] * P.dt + x[d];
-                ok = ok && !(xn < P.lb[d]) && !(xn > P.ub[d]);
-                inb = inb && !(xn < P.glo[d]) && !(xn > P.ghi[d]);
-                ci[d] = find_interval(P.lev[d], P.dim[d], P.glo[d], P.inv_step[d], xn);
-                y[d] = (xn - P.lev[d][ci[d]]) / (P.lev[d][ci[d] + 1] - P.lev[d][ci[d]]);
-                b += ci[d] * P.strd[d];
+                xnv[i] = acc[i] * P.dt + x[d];
+                ok = ok && !(xnv[i] < P.lb[d]) && !(xnv[i] > P.ub[d]);
+                inb = inb && !(xnv[i] < P.glo[d]) && !(xnv[i] > P.ghi[d]);
+            }
+            long long b = base;
+            if (inb) {  // interval + fraction (a float64 division per axis) only where the value is used
+#pragma unroll
+                for (int i = 0; i < DOF; ++i) {
+                    const int d = DOF + i;
+                    ci[d] = find_interval(P.lev[d], P.dim[d], P.glo[d], P.inv_step[d], xnv[i]);
+                    y[d] = (xnv[i] - P.lev[d][ci[d]]) / (P.lev[d][ci[d] + 1] - P.lev[d][ci[d]]);
+                    b += ci[d] * P.strd[d];
+                }
             }
             // G (dynamicprogramming.py:534-549)
             const double g = on_target ? 0.0 : (gx + P.gu[a]);

@@ -1,0 +1,11 @@
+#!/bin/bash
+# refresh the judged profiles: counters (4 pmc passes per workload) + kernel-trace stats of the bench command
+bash tools/tools_counters.sh c2 > gpurun_out/refresh_c2.log 2>&1
+bash tools/tools_counters.sh c3 > gpurun_out/refresh_c3.log 2>&1
+cd /tmp && export TMPDIR=/tmp
+for w in c2 c3; do
+  S=$([ $w = c3 ] && echo "--steps 20 --warmup 2" || echo "")
+  rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/stats_$w -o s -- python /root/repo/bench.py --workload $w --no-cpu $S > /root/repo/gpurun_out/stats_$w.log 2>&1
+  tail -1 /root/repo/gpurun_out/stats_$w.log | cut -c1-300
+done
+ls /root/repo/gpurun_out/stats_c2 /root/repo/gpurun_out/stats_c3
