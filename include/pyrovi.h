@@ -162,6 +162,18 @@ int pvi_build_tables(pvi_handle h, int32_t row0, int32_t nrows, double* x_next, 
                 (base class DynamicProgramming.compute_backward_step, dynamicprogramming.py:195-236). */
 int pvi_set_tables(pvi_handle h, const double* x_next, const double* G, const uint8_t* ok);
 
+/* ---- interpolant of J_k ------------------------------------------------------------------------------ */
+#define PVI_INTERP_LINEAR 0          /* RegularGridInterpolator('linear', fill 0), discretizer.py:570-587 (default) */
+#define PVI_INTERP_BICUBIC_SPLINE 1  /* RectBivariateSpline(kx=ky=3, s=0), discretizer.py:590-612: refit every sweep,
+                                        x_next clamped to the grid box, no zero fill */
+/* PVI_INTERP_BICUBIC_SPLINE turns the handle into DynamicProgramming2DRectBivariateSpline
+   (dynamicprogramming.py:578-614): n == 2, whole-grid handles only, >= 4 levels per axis; works with the
+   pendulum-family in-kernel dynamics (look-up-table semantics) and with tier-B tables. */
+int pvi_set_interpolation(pvi_handle h, int32_t kind);
+/* fit the spline through the CURRENT cost-to-go and return its B-spline coefficients [x_dim0][x_dim1]
+   (RectBivariateSpline.get_coeffs() of dp.J_interpol, dynamicprogramming.py:594) */
+int pvi_spline_coefficients(pvi_handle h, double* coef);
+
 /* ---- policy consumers (SURVEY 8f "next": the step after the path) ------------------------------------ */
 /* replace the device policy, e.g. after clean_infeasible_set on the host (dynamicprogramming.py:322-334) */
 int pvi_set_pi(pvi_handle h, const int64_t* pi_rows, int32_t row0, int32_t nrows);

@@ -14,6 +14,7 @@ PVI_MAX_N, PVI_MAX_M, PVI_MAX_TRIG = 4, 2, 4
 PVI_F32, PVI_F64 = 0, 1
 DYN_TABLE, DYN_PENDULUM, DYN_CARTPOLE, DYN_TWOLINK = 0, 1, 2, 3
 COST_TABLE, COST_QUADRATIC = 0, 1
+INTERP_LINEAR, INTERP_BICUBIC_SPLINE = 0, 1
 PVI_EHALO = -5
 ABI_VERSION = 1
 
@@ -66,6 +67,8 @@ SYMBOLS = {
     "pvi_synchronize": (C.c_int, [_h]),
     "pvi_build_tables": (C.c_int, [_h, C.c_int32, C.c_int32, _dp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), _dp]),
     "pvi_set_tables": (C.c_int, [_h, _dp, _dp, C.POINTER(C.c_uint8)]),
+    "pvi_set_interpolation": (C.c_int, [_h, C.c_int32]),
+    "pvi_spline_coefficients": (C.c_int, [_h, _dp]),
     "pvi_set_pi": (C.c_int, [_h, C.POINTER(C.c_int64), C.c_int32, C.c_int32]),
     "pvi_rollout": (C.c_int, [_h, C.c_int64, _dp, C.c_int32, C.c_double, _dp, _dp, _dp]),
     "pvi_eval_f": (C.c_int, [C.c_int32, _dp, C.c_int32, C.c_int32, C.c_int64, _dp, _dp, _dp]),
@@ -317,3 +320,14 @@ class Problem:
                 raise ValueError("ok mask shape does not match the grid")
             okp = ok.ctypes.data_as(C.POINTER(C.c_uint8))
         check(lib().pvi_set_tables(self._h, _ptr(x_next), _ptr(G), okp))
+
+    def set_interpolation(self, kind):
+        """'linear' (RegularGridInterpolator, default) or 'bicubic' (RectBivariateSpline kx=ky=3, 2-D grids)."""
+        code = {"linear": INTERP_LINEAR, "bicubic": INTERP_BICUBIC_SPLINE}.get(kind, kind)
+        check(lib().pvi_set_interpolation(self._h, int(code)))
+
+    def spline_coefficients(self):
+        """B-spline coefficients of the spline through the current J, shape x_dims (get_coeffs() order)."""
+        out = np.empty(tuple(self.dims), dtype=np.float64)
+        check(lib().pvi_spline_coefficients(self._h, _ptr(out)))
+        return out

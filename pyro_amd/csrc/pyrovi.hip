@@ -1221,6 +1221,8 @@ __global__ __launch_bounds__(256) void k_sweep_table(DevP P, const double* __res
     sweep_finish(sc);
 }
 
+#include "sweep_spline.inc"
+
 // =================================================================================================
 // reference tables for a block of rows: x_next_table, x_next_isok, action_isok, G
 // (discretizer.py:342-376, :314-338; dynamicprogramming.py:517-553).  One thread per (node, action).
@@ -1469,6 +1471,8 @@ struct pvi_problem {
     size_t march_lds = 0;
     bool march_lds_attr = false;
     int march_block = 256;
+    SplineP SP;               // bicubic-spline interpolation mode (sweep_spline.inc)
+    bool spline = false;
 };
 
 template <typename T>
@@ -2108,6 +2112,22 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     const REAL* Jin = (const REAL*)h->J[src];
     REAL* Jout = (REAL*)h->J[src ^ 1];
     PI_T* pi = (PI_T*)h->pi;
+    if (h->spline) {
+        const SplineP& S = h->SP;
+        hipLaunchKernelGGL((k_spline_solve0<REAL>), grid_for(S.n1, 64), 64, 0, st, S, Jin);
+        hipLaunchKernelGGL(k_spline_solve1, grid_for(S.n0, 64), 64, 0, st, S);
+        if (h->d.dynamics_id == PVI_DYN_TABLE) {
+            if (!h->d_xnext || !h->d_G) return fail(PVI_ESTATE, "tier B sweep before pvi_set_tables");
+            hipLaunchKernelGGL((k_sweep_spline<PVI_DYN_TABLE, REAL, PI_T>), g, 256, 0, st, h->P, S, h->d_xnext, h->d_G,
+                               h->d_ok, Jin, Jout, pi, alpha, sc);
+        } else {
+            hipLaunchKernelGGL((k_sweep_spline<PVI_DYN_PENDULUM, REAL, PI_T>), g, 256, 0, st, h->P, S,
+                               (const double*)nullptr, (const double*)nullptr, (const unsigned char*)nullptr, Jin, Jout,
+                               pi, alpha, sc);
+        }
+        HIPCHK(hipGetLastError());
+        return PVI_OK;
+    }
     if constexpr (sizeof(REAL) == 4) {
         if (h->march_ok) {
             const float al = (float)alpha;
@@ -2329,6 +2349,104 @@ extern "C" int pvi_sweep_stats(pvi_handle h, double stats3[3], void* stream) {
     stats3[0] = res[0];
     stats3[1] = res[1];
     stats3[2] = res[2];
+    return PVI_OK;
+}
+
+// ---- interpolation mode ---------------------------------------------------------------------------------
+// LU factors (no pivoting: B-spline collocation matrices are totally positive) of the cubic not-a-knot
+// collocation matrix of one axis, packed per row as {l2, l1, 1/d, u1, u2}; knots as FITPACK's fpregr for s=0.
+static void spline_axis_host(const double* x, int n, std::vector<double>& t, std::vector<double>& lu) {
+    t.assign(n + 4, 0.0);
+    for (int i = 0; i < 4; ++i) {
+        t[i] = x[0];
+        t[n + i] = x[n - 1];
+    }
+    for (int i = 2; i <= n - 3; ++i) t[i + 2] = x[i];
+    std::vector<double> ab((size_t)n * 5, 0.0);  // ab[i][j - i + 2]
+    for (int i = 0; i < n; ++i) {
+        const double xv = x[i];
+        int l = 3;
+        while (l < n - 1 && xv >= t[l + 1]) ++l;  // fpbisp interval
+        double h[4] = {1.0, 0.0, 0.0, 0.0}, hh[3];
+        for (int j = 1; j <= 3; ++j) {  // fpbspl
+            for (int q = 0; q < j; ++q) hh[q] = h[q];
+            h[0] = 0.0;
+            for (int q = 0; q < j; ++q) {
+                const int li = l + q + 1, lj = li - j;
+                const double f = hh[q] / (t[li] - t[lj]);
+                h[q] = h[q] + f * (t[li] - xv);
+                h[q + 1] = f * (xv - t[lj]);
+            }
+        }
+        for (int q = 0; q < 4; ++q) {
+            const int col = l - 3 + q, off = col - i + 2;
+            if (h[q] != 0.0 && off >= 0 && off < 5) ab[(size_t)i * 5 + off] = h[q];
+        }
+    }
+    for (int k = 0; k < n; ++k)
+        for (int i = k + 1; i <= k + 2 && i < n; ++i) {
+            const double m = ab[(size_t)i * 5 + (k - i + 2)] / ab[(size_t)k * 5 + 2];
+            ab[(size_t)i * 5 + (k - i + 2)] = m;
+            for (int j = k + 1; j <= k + 2 && j < n; ++j)
+                if (j - i + 2 < 5) ab[(size_t)i * 5 + (j - i + 2)] -= m * ab[(size_t)k * 5 + (j - k + 2)];
+        }
+    lu.assign((size_t)n * 5, 0.0);
+    for (int i = 0; i < n; ++i) {
+        lu[(size_t)i * 5 + 0] = ab[(size_t)i * 5 + 0];
+        lu[(size_t)i * 5 + 1] = ab[(size_t)i * 5 + 1];
+        lu[(size_t)i * 5 + 2] = 1.0 / ab[(size_t)i * 5 + 2];
+        lu[(size_t)i * 5 + 3] = ab[(size_t)i * 5 + 3];
+        lu[(size_t)i * 5 + 4] = ab[(size_t)i * 5 + 4];
+    }
+}
+
+extern "C" int pvi_set_interpolation(pvi_handle h, int32_t kind) {
+    if (!h) return fail(PVI_EINVAL, "NULL handle");
+    if (kind == PVI_INTERP_LINEAR) {
+        h->spline = false;
+        return PVI_OK;
+    }
+    if (kind != PVI_INTERP_BICUBIC_SPLINE) return fail(PVI_EINVAL, "unknown interpolation kind %d", kind);
+    if (h->P.n != 2) return fail(PVI_EINVAL, "bicubic-spline interpolation is 2-D only (discretizer.py:599-610)");
+    if (h->P.dim[0] < 4 || h->P.dim[1] < 4) return fail(PVI_EINVAL, "a cubic spline needs at least 4 levels per axis");
+    if (h->P.store_begin != 0 || h->P.store_end != h->P.dim[0] || h->P.row_begin != 0 || h->P.row_end != h->P.dim[0])
+        return fail(PVI_EINVAL, "spline interpolation needs a whole-grid handle (the fit couples every row)");
+    if (h->d.dynamics_id != PVI_DYN_TABLE && h->d.dynamics_id != PVI_DYN_PENDULUM)
+        return fail(PVI_EINVAL, "no 2-D in-kernel dynamics with id %d", h->d.dynamics_id);
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->SP.coef) {
+        std::vector<double> t, lu, lev0(h->P.dim[0]), lev1(h->P.dim[1]);
+        int rc;
+        // (the descriptor's level pointers were only borrowed for pvi_create: read the device copies back)
+        HIPCHK(hipMemcpy(lev0.data(), h->P.lev[0], lev0.size() * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(lev1.data(), h->P.lev[1], lev1.size() * 8, hipMemcpyDeviceToHost));
+        spline_axis_host(lev0.data(), h->P.dim[0], t, lu);
+        if ((rc = dev_upload(h, t.data(), t.size(), &h->SP.tx))) return rc;
+        if ((rc = dev_upload(h, lu.data(), lu.size(), &h->SP.lu0))) return rc;
+        spline_axis_host(lev1.data(), h->P.dim[1], t, lu);
+        if ((rc = dev_upload(h, t.data(), t.size(), &h->SP.ty))) return rc;
+        if ((rc = dev_upload(h, lu.data(), lu.size(), &h->SP.lu1))) return rc;
+        if ((rc = dev_alloc(h, (size_t)h->P.dim[0] * h->P.dim[1], &h->SP.coef))) return rc;
+        h->SP.n0 = h->P.dim[0];
+        h->SP.n1 = h->P.dim[1];
+    }
+    h->spline = true;
+    return PVI_OK;
+}
+
+extern "C" int pvi_spline_coefficients(pvi_handle h, double* coef) {
+    if (!h || !coef) return fail(PVI_EINVAL, "NULL argument");
+    if (!h->spline) return fail(PVI_ESTATE, "spline interpolation is not enabled on this handle");
+    HIPCHK(hipSetDevice(h->device));
+    const SplineP& S = h->SP;
+    if (h->d.dtype == PVI_F64)
+        hipLaunchKernelGGL((k_spline_solve0<double>), grid_for(S.n1, 64), 64, 0, h->stream, S, (const double*)h->J[h->cur]);
+    else
+        hipLaunchKernelGGL((k_spline_solve0<float>), grid_for(S.n1, 64), 64, 0, h->stream, S, (const float*)h->J[h->cur]);
+    hipLaunchKernelGGL(k_spline_solve1, grid_for(S.n0, 64), 64, 0, h->stream, S);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(coef, S.coef, (size_t)S.n0 * S.n1 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return PVI_OK;
 }
 

@@ -58,6 +58,7 @@ class DynamicProgramming:
     HARD_INF = True                 # base class: an invalid action / next state costs exactly INF (:225-233)
     HISTORY_MAX_BYTES = 1 << 30     # save_time_history is dropped beyond this (J+pi per sweep)
     BATCH = 256                     # sweeps enqueued per host round trip when no history is kept
+    INTERPOLATION = "linear"        # interpolant of J_k between the nodes (discretizer.py:570-587)
 
     def __init__(self, grid_sys, cost_function, final_time=0, dtype="float64", device=0):
         self.grid_sys, self.sys = grid_sys, grid_sys.sys
@@ -89,6 +90,8 @@ class DynamicProgramming:
                                       table_inf=float(self.cf.INF))
             ok = (g.action_isok & g.x_next_isok) if self.HARD_INF else None
             self._p.set_tables(g.x_next_table, self._host_cost_table(), ok)
+        if self.INTERPOLATION != "linear":
+            self._p.set_interpolation(self.INTERPOLATION)
         self._host = {}             # cached downloads: 'J', 'pi', 'J_next'
         self._dirty = False         # host J newer than the device copy
 
@@ -387,6 +390,25 @@ class DynamicProgrammingWithLookUpTable(DynamicProgramming):
         else:
             self.__dict__["_G"] = self._host_cost_table()
         print("completed in %4.2f sec" % (time.time() - t0))
+
+
+class DynamicProgramming2DRectBivariateSpline(DynamicProgrammingWithLookUpTable):
+    """dynamicprogramming.py:578-614: the look-up-table recursion with a bicubic spline through J_k
+    (RectBivariateSpline kx = ky = 3, refit every sweep) instead of the bilinear interpolant; x_next is
+    clamped to the grid box by the spline evaluation, nothing is zero-filled.  2-D grids only."""
+
+    INTERPOLATION = "bicubic"
+
+    def __init__(self, grid_sys, cost_function, final_time=0, dtype="float64", device=0):
+        if grid_sys.sys.n != 2:
+            raise NotImplementedError                   # discretizer.py:599-610
+        super().__init__(grid_sys, cost_function, final_time, dtype=dtype, device=device)
+        self.interpol_method = "bicubic"
+
+    @property
+    def J_interpol(self):
+        """The interpolant of the current J_next as a SciPy object (host side, for inspection / plots)."""
+        return self.grid_sys.compute_bivariatespline_2D_interpolation_function(self.J_next, kx=3, ky=3)
 
 
 class PolicyEvaluator(DynamicProgramming):

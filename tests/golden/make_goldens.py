@@ -452,7 +452,36 @@ def case_rollout():
     save("rollout_pendulum_21x21x5", **out)
 
 
-CASES = dict(f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
+def case_spline():
+    """DynamicProgramming2DRectBivariateSpline (dynamicprogramming.py:578-614): bicubic FITPACK spline refit of J
+    every sweep, evaluated at x_next CLAMPED to the grid box (no zero fill).  Pendulum 21x21x5 and 41x31x7 (dt 0.1)."""
+    out = {}
+    for tag, (xd, ud, dt) in dict(a=((21, 21), (5,), 0.05), b=((41, 31), (7,), 0.1)).items():
+        s, g, q = _pendulum_problem(xd, ud, dt=dt)
+        if tag == "a":
+            out.update(_meta(s, g, q))
+        with quiet():
+            dp = dynamicprogramming.DynamicProgramming2DRectBivariateSpline(g, q)
+            dp.save_time_history = False
+            stats = []
+            for k in range(1, 9):
+                dp.initialize_backward_step()
+                if k in (1, 2, 8):
+                    out["%s_coef_%d" % (tag, k)] = np.asarray(dp.J_interpol.get_coeffs()).copy()
+                dp.compute_backward_step()
+                delta = dp.finalize_backward_step()
+                d = dp.J - dp.J_next
+                stats.append([dp.J.max(), d.max(), d.min(), delta])
+                if k in (1, 2, 8):
+                    out["%s_J_%d" % (tag, k)] = dp.J.copy(); out["%s_pi_%d" % (tag, k)] = dp.pi.copy()
+                    Q = np.sort(dp.Q, axis=1)
+                    out["%s_gap_%d" % (tag, k)] = Q[:, 1] - Q[:, 0]      # margin of the argmin (tie detector)
+            out["%s_stats" % tag] = np.array(stats)
+            out["%s_knots_x" % tag], out["%s_knots_y" % tag] = dp.J_interpol.get_knots()
+    save("spline_pendulum", **out)
+
+
+CASES = dict(spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
              policy_eval=case_policy_eval, cost_kat=case_cost_kat, grid_kat=case_grid_kat,
              pendulum_small=case_pendulum_small, config1=case_config1, lowdef=case_lowdef,
              pendulum_demo=case_pendulum_demo, cartpole_small=case_cartpole_small,

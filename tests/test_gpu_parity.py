@@ -744,3 +744,111 @@ def test_two_ranks_share_one_gpu(tmp_path, case):
     np.testing.assert_allclose(r["stats"][:4], stats[:4], rtol=1e-12)
     np.testing.assert_allclose(r["stats"][4], stats[6], rtol=1e-12)
     assert bool(r["p2p"])
+
+
+# ------------------------------------------------------------------------------- bicubic-spline class
+def _spline_case(g, tag, xd, ud, dt):
+    lv = O.make_levels(g["x_lb"], g["x_ub"], xd)
+    ul = O.make_levels(g["u_lb"], g["u_ub"], ud)
+    return O.Problem(lv, ul, dt, O.DYN_PENDULUM, O.pendulum_consts(), g["Q"], g["R"], g["S"], g["xbar"], g["ubar"],
+                     float(g["INF"]), float(g["EPS"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tier", ["fused", "table"])
+def test_spline_value_iteration_matches_reference_golden(tier):
+    """DynamicProgramming2DRectBivariateSpline (dynamicprogramming.py:578-614): coefficients of the refit and
+    J / pi after 1, 2, 8 sweeps against the reference's own run; float64, tolerance 1e-11 relative (the fit is
+    a linear solve: FITPACK uses Givens QR, the kernel a banded LU -- equal up to rounding, cond ~ 4)."""
+    from pyro_amd import _native
+    g = load("spline_pendulum")
+    for tag, xd, ud, dt in (("a", (21, 21), (5,), 0.05), ("b", (41, 31), (7,), 0.1)):
+        p = _spline_case(g, tag, xd, ud, dt)
+        if tier == "fused":
+            h = native_problem(p)
+            h.terminal_cost()
+        else:
+            xn, _, _, G = O.cells(p, np.arange(p.nodes_n))
+            h = _native.Problem(p.levels, p.u_levels, p.x_lb, p.x_ub, p.u_lb, p.u_ub, p.dt, dynamics_id=_native.DYN_TABLE)
+            h.set_tables(xn, G)
+            h.set_J(O.terminal_cost(p))
+        h.set_interpolation("bicubic")
+        for k in range(1, 9):
+            if k in (1, 2, 8):
+                C = h.spline_coefficients()
+                ref = g["%s_coef_%d" % (tag, k)]
+                assert np.abs(C.ravel() - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+            st = h.sweep(1, 1.0, -1.0)[0][-1]
+            assert np.allclose(st, g[tag + "_stats"][k - 1], rtol=1e-11)
+            if k in (1, 2, 8):
+                J, pi = h.get_J(), h.get_pi()
+                assert relerr(J, g["%s_J_%d" % (tag, k)]) < 1e-11
+                clear = g["%s_gap_%d" % (tag, k)] > 1e-8
+                assert np.array_equal(pi[clear], g["%s_pi_%d" % (tag, k)][clear])
+        h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,udims", [((4, 4), (3,)), ((5, 130), (4,)), ((131, 67), (9,)), ((200, 64), (2,))])
+def test_spline_sweeps_match_oracle(dims, udims):
+    """Ragged sizes (minimum 4 levels, lines that do not fill the 64-wide solve tiles), alpha < 1, f64 and f32."""
+    p, _ = _custom_problem("pendulum", dims, udims, dt=0.08, seed=5)
+    xn, _, _, G = O.cells(p, np.arange(p.nodes_n))
+    for dtype, tol in (("float64", 1e-11), ("float32", 2e-6)):
+        h = native_problem(p, dtype=dtype)
+        h.set_interpolation("bicubic")
+        h.terminal_cost()
+        J = O.terminal_cost(p)
+        if dtype == "float32":
+            J = J.astype(np.float32).astype(np.float64)
+        for k in range(4):
+            Jn, pi, Q = O.sweep_spline(p.levels, xn, G, J, alpha=0.97)
+            h.sweep(1, 0.97, -1.0)
+            Jd = h.get_J()
+            assert relerr(Jd, Jn) < tol
+            Qs = np.sort(Q, axis=1)
+            clear = (Qs[:, 1] - Qs[:, 0]) > 1e-4 * np.abs(Qs[:, 0]).max() if Q.shape[1] > 1 else np.ones(len(Jn), bool)
+            assert np.array_equal(h.get_pi()[clear], pi[clear])
+            J = Jd                                  # follow the device iterate (f32 storage rounds)
+        h.close()
+
+
+@pytest.mark.gpu
+def test_spline_mode_errors_and_class_surface():
+    from pyro_amd import _native
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import cartpole, pendulum
+    from pyro_amd.planning import discretizer, dynamicprogramming
+    g = load("spline_pendulum")
+    # n != 2 and fewer than 4 levels are refused
+    p4, _ = _custom_problem("cartpole", (5, 5, 5, 5), (3,))
+    h = native_problem(p4)
+    with pytest.raises(RuntimeError):
+        h.set_interpolation("bicubic")
+    h.close()
+    p3, _ = _custom_problem("pendulum", (3, 9), (3,))
+    h = native_problem(p3)
+    with pytest.raises(RuntimeError):
+        h.set_interpolation("bicubic")
+    h.close()
+    with contextlib.redirect_stdout(io.StringIO()):
+        with pytest.raises(NotImplementedError):
+            s4 = cartpole.CartPole()
+            dynamicprogramming.DynamicProgramming2DRectBivariateSpline(
+                discretizer.GridDynamicSystem(s4, [5, 5, 5, 5], [3]), costfunction.QuadraticCostFunction.from_sys(s4))
+        sys_ = pendulum.SinglePendulum()
+        qcf = costfunction.QuadraticCostFunction.from_sys(sys_)
+        qcf.xbar = np.array([-3.14, 0]); qcf.INF = 300
+        grid_sys = discretizer.GridDynamicSystem(sys_, [21, 21], [5])
+        dp = dynamicprogramming.DynamicProgramming2DRectBivariateSpline(grid_sys, qcf)
+        dp.save_time_history = False
+        dp.compute_steps(8)
+    assert dp.k == 8 and dp.interpol_method == "bicubic"
+    assert relerr(dp.J, g["a_J_8"]) < 1e-11
+    assert np.abs(np.asarray(dp.J_interpol.get_coeffs()) - g["a_coef_8"]).max() < 1e-9 * np.abs(g["a_coef_8"]).max()
+    # switching back to the bilinear interpolant restores the plain recursion
+    g0 = load("pendulum_21x21x5")
+    dp._p.set_interpolation("linear")
+    dp._p.terminal_cost()
+    dp._p.sweep(1, 1.0, -1.0)
+    assert relerr(dp._p.get_J(), g0["J_1"]) < 1e-14

@@ -301,3 +301,49 @@ def test_rollout_golden():
     np.testing.assert_allclose(U, g["U"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(X, g["X"], rtol=1e-9, atol=1e-9)
     assert (g["U"][2, 5:] == 0).all()          # the trajectory that leaves the grid gets u = 0 (fill value)
+
+
+# ------------------------------------------------------------------------------- bicubic-spline class
+def test_spline_restatement_matches_scipy():
+    """oracle spline_* (FITPACK regrid/bispev restated) against scipy.interpolate.RectBivariateSpline itself."""
+    from scipy.interpolate import RectBivariateSpline
+    rng = np.random.default_rng(3)
+    for n0, n1 in [(4, 4), (5, 7), (21, 17), (64, 33)]:
+        x = np.linspace(-2.0, 3.0, n0)
+        y = np.linspace(0.5, 9.0, n1)
+        Z = rng.normal(size=(n0, n1))
+        S = RectBivariateSpline(x, y, Z, bbox=[None, None, None, None], kx=3, ky=3)
+        tx, ty, C = O.spline_fit([x, y], Z)
+        assert np.array_equal(tx, S.get_knots()[0]) and np.array_equal(ty, S.get_knots()[1])
+        assert np.abs(C.ravel() - S.get_coeffs()).max() < 1e-12
+        P = rng.uniform([-4, -1], [5, 11], size=(500, 2))            # inside and outside the box (clamped)
+        P[:4] = [[x[0], y[0]], [x[-1], y[-1]], [x[1], y[-2]], [x[-1], y[2]]]
+        assert np.abs(O.spline_eval(tx, ty, C, P) - S(P[:, 0], P[:, 1], grid=False)).max() < 1e-12
+    with pytest.raises(ValueError):
+        O.spline_knots(np.linspace(0, 1, 3))
+
+
+def test_spline_value_iteration_golden():
+    """DynamicProgramming2DRectBivariateSpline run by the reference (dynamicprogramming.py:578-614)."""
+    g = load("spline_pendulum")
+    for tag, xd, ud, dt in (("a", (21, 21), (5,), 0.05), ("b", (41, 31), (7,), 0.1)):
+        lv = O.make_levels(g["x_lb"], g["x_ub"], xd)
+        ul = O.make_levels(g["u_lb"], g["u_ub"], ud)
+        p = O.Problem(lv, ul, dt, O.DYN_PENDULUM, O.pendulum_consts(), g["Q"], g["R"], g["S"], g["xbar"], g["ubar"],
+                      float(g["INF"]), float(g["EPS"]))
+        xn, _, _, G = O.cells(p, np.arange(p.nodes_n))
+        J = O.terminal_cost(p)
+        assert np.array_equal(O.spline_knots(lv[0]), g[tag + "_knots_x"])
+        for k in range(1, 9):
+            if k in (1, 2, 8):
+                C = O.spline_fit(lv, J.reshape(xd))[2]
+                assert np.abs(C.ravel() - g["%s_coef_%d" % (tag, k)]).max() <= 1e-12 * max(1.0, np.abs(C).max())
+            Jn, pi, _ = O.sweep_spline(lv, xn, G, J)
+            st, delta = O.sweep_stats(Jn, J)
+            assert np.allclose([*st, delta], g[tag + "_stats"][k - 1], rtol=1e-11)
+            if k in (1, 2, 8):
+                assert np.abs(Jn - g["%s_J_%d" % (tag, k)]).max() <= 1e-11 * np.abs(Jn).max()
+                clear = g["%s_gap_%d" % (tag, k)] > 1e-8          # argmin decided by more than rounding
+                assert np.array_equal(pi[clear], g["%s_pi_%d" % (tag, k)][clear])
+                assert (pi != g["%s_pi_%d" % (tag, k)]).mean() < 0.02
+            J = Jn
