@@ -1953,6 +1953,11 @@ extern "C" int pvi_pi_itemsize(pvi_handle h) { return h ? h->pi_size : 0; }
 
 extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
     if (!h || !buf || n <= 0) return fail(PVI_EINVAL, "bad argument");
+    if (h->spline) {
+        snprintf(buf, (size_t)n, "path=spline-%s chunk0=%d warm0=%d chunk1=%d warm1=%d",
+                 h->d.dynamics_id == PVI_DYN_TABLE ? "table" : "fused", h->SP.chunk0, h->SP.warm0, h->SP.chunk1, h->SP.warm1);
+        return PVI_OK;
+    }
     const char* path = h->d.dtype == PVI_F64 ? "exact-f64"
                        : h->march_ok ? "march"
                        : h->lean_ok ? "lean"
@@ -2104,6 +2109,17 @@ extern "C" int pvi_device_pi(pvi_handle h, void** p) {
     return PVI_OK;
 }
 
+// spline refit of the cost-to-go J: four substitution passes (forward/backward x two axes)
+template <typename REAL>
+static void spline_fit_launch(pvi_problem* h, const REAL* J, hipStream_t st) {
+    const SplineP& S = h->SP;
+    const dim3 g0(grid_for(S.n1, 64), (S.n0 + S.chunk0 - 1) / S.chunk0), g1(grid_for(S.n0, 64), (S.n1 + S.chunk1 - 1) / S.chunk1);
+    hipLaunchKernelGGL((k_spline_axis0<REAL, false>), g0, 64, 0, st, S, J, S.work);
+    hipLaunchKernelGGL((k_spline_axis0<double, true>), g0, 64, 0, st, S, (const double*)S.work, S.coef);
+    hipLaunchKernelGGL((k_spline_axis1<false>), g1, 64, 0, st, S, (const double*)S.coef, S.work);
+    hipLaunchKernelGGL((k_spline_axis1<true>), g1, 64, 0, st, S, (const double*)S.work, S.coef);
+}
+
 // ---- sweep launch -----------------------------------------------------------------------------------
 template <typename REAL, typename PI_T>
 static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st, SweepCtl sc) {
@@ -2114,8 +2130,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     PI_T* pi = (PI_T*)h->pi;
     if (h->spline) {
         const SplineP& S = h->SP;
-        hipLaunchKernelGGL((k_spline_solve0<REAL>), grid_for(S.n1, 64), 64, 0, st, S, Jin);
-        hipLaunchKernelGGL(k_spline_solve1, grid_for(S.n0, 64), 64, 0, st, S);
+        spline_fit_launch<REAL>(h, Jin, st);
         if (h->d.dynamics_id == PVI_DYN_TABLE) {
             if (!h->d_xnext || !h->d_G) return fail(PVI_ESTATE, "tier B sweep before pvi_set_tables");
             hipLaunchKernelGGL((k_sweep_spline<PVI_DYN_TABLE, REAL, PI_T>), g, 256, 0, st, h->P, S, h->d_xnext, h->d_G,
@@ -2355,7 +2370,8 @@ extern "C" int pvi_sweep_stats(pvi_handle h, double stats3[3], void* stream) {
 // ---- interpolation mode ---------------------------------------------------------------------------------
 // LU factors (no pivoting: B-spline collocation matrices are totally positive) of the cubic not-a-knot
 // collocation matrix of one axis, packed per row as {l2, l1, 1/d, u1, u2}; knots as FITPACK's fpregr for s=0.
-static void spline_axis_host(const double* x, int n, std::vector<double>& t, std::vector<double>& lu) {
+static void spline_axis_host(const double* x, int n, std::vector<double>& t, std::vector<double>& lu,
+                             std::vector<double>& rt, double* rho) {
     t.assign(n + 4, 0.0);
     for (int i = 0; i < 4; ++i) {
         t[i] = x[0];
@@ -2398,6 +2414,31 @@ static void spline_axis_host(const double* x, int n, std::vector<double>& t, std
         lu[(size_t)i * 5 + 3] = ab[(size_t)i * 5 + 3];
         lu[(size_t)i * 5 + 4] = ab[(size_t)i * 5 + 4];
     }
+    // how fast the two recurrences forget their initial state (per step), over the rows a warm-up can cross
+    // (interior rows only: a warm-up that would start within 4 rows of an end starts AT the end instead, exactly)
+    double r = 0.0;
+    for (int i = 4; i < n - 4; ++i) {
+        r = std::max(r, fabs(lu[(size_t)i * 5 + 0]) + fabs(lu[(size_t)i * 5 + 1]));
+        r = std::max(r, (fabs(lu[(size_t)i * 5 + 3]) + fabs(lu[(size_t)i * 5 + 4])) * fabs(lu[(size_t)i * 5 + 2]));
+    }
+    *rho = r;
+    // reciprocal knot differences of the fpbspl recursion at interval l: (j,i) = (1,0) (2,0) (2,1) (3,0) (3,1) (3,2)
+    rt.assign((size_t)(n + 4) * 6, 0.0);
+    for (int l = 3; l <= n - 1; ++l) {
+        int k = 0;
+        for (int j = 1; j <= 3; ++j)
+            for (int i = 0; i < j; ++i, ++k) {
+                const int li = l + i + 1, lj = li - j;
+                rt[(size_t)l * 6 + k] = 1.0 / (t[li] - t[lj]);
+            }
+    }
+}
+
+// warm-up length after which a start-up error of the recurrence is below 1e-20 relative (0: do not chunk)
+static int spline_warmup(double rho, int limit) {
+    if (!(rho < 0.9)) return 0;
+    const int w = (int)ceil(log(1e-20) / log(rho)) + 2;
+    return w <= limit ? w : 0;
 }
 
 extern "C" int pvi_set_interpolation(pvi_handle h, int32_t kind) {
@@ -2415,18 +2456,30 @@ extern "C" int pvi_set_interpolation(pvi_handle h, int32_t kind) {
         return fail(PVI_EINVAL, "no 2-D in-kernel dynamics with id %d", h->d.dynamics_id);
     HIPCHK(hipSetDevice(h->device));
     if (!h->SP.coef) {
-        std::vector<double> t, lu, lev0(h->P.dim[0]), lev1(h->P.dim[1]);
+        std::vector<double> t, lu, rt, lev0(h->P.dim[0]), lev1(h->P.dim[1]);
+        double rho0 = 1.0, rho1 = 1.0;
         int rc;
         // (the descriptor's level pointers were only borrowed for pvi_create: read the device copies back)
         HIPCHK(hipMemcpy(lev0.data(), h->P.lev[0], lev0.size() * 8, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(lev1.data(), h->P.lev[1], lev1.size() * 8, hipMemcpyDeviceToHost));
-        spline_axis_host(lev0.data(), h->P.dim[0], t, lu);
+        spline_axis_host(lev0.data(), h->P.dim[0], t, lu, rt, &rho0);
         if ((rc = dev_upload(h, t.data(), t.size(), &h->SP.tx))) return rc;
         if ((rc = dev_upload(h, lu.data(), lu.size(), &h->SP.lu0))) return rc;
-        spline_axis_host(lev1.data(), h->P.dim[1], t, lu);
+        if ((rc = dev_upload(h, rt.data(), rt.size(), &h->SP.rtx))) return rc;
+        spline_axis_host(lev1.data(), h->P.dim[1], t, lu, rt, &rho1);
         if ((rc = dev_upload(h, t.data(), t.size(), &h->SP.ty))) return rc;
         if ((rc = dev_upload(h, lu.data(), lu.size(), &h->SP.lu1))) return rc;
+        if ((rc = dev_upload(h, rt.data(), rt.size(), &h->SP.rty))) return rc;
+        if ((rc = dev_alloc(h, (size_t)h->P.dim[0] * h->P.dim[1], &h->SP.work))) return rc;
         if ((rc = dev_alloc(h, (size_t)h->P.dim[0] * h->P.dim[1], &h->SP.coef))) return rc;
+        // chunked substitution: more parallelism than one thread per grid line.  PVI_SPLINE_CHUNK=0 disables.
+        const char* ev = getenv("PVI_SPLINE_CHUNK");
+        const int want = ev ? atoi(ev) : 64;
+        const int w0 = spline_warmup(rho0, 64), w1 = spline_warmup(rho1, 64);
+        h->SP.chunk0 = (want > 0 && w0 > 0 && h->P.dim[0] > 2 * want) ? want : h->P.dim[0];
+        h->SP.warm0 = w0;
+        h->SP.chunk1 = (want > 0 && w1 > 0 && h->P.dim[1] > 2 * want) ? (want + 63) / 64 * 64 : h->P.dim[1];
+        h->SP.warm1 = 64;
         h->SP.n0 = h->P.dim[0];
         h->SP.n1 = h->P.dim[1];
     }
@@ -2440,10 +2493,9 @@ extern "C" int pvi_spline_coefficients(pvi_handle h, double* coef) {
     HIPCHK(hipSetDevice(h->device));
     const SplineP& S = h->SP;
     if (h->d.dtype == PVI_F64)
-        hipLaunchKernelGGL((k_spline_solve0<double>), grid_for(S.n1, 64), 64, 0, h->stream, S, (const double*)h->J[h->cur]);
+        spline_fit_launch<double>(h, (const double*)h->J[h->cur], h->stream);
     else
-        hipLaunchKernelGGL((k_spline_solve0<float>), grid_for(S.n1, 64), 64, 0, h->stream, S, (const float*)h->J[h->cur]);
-    hipLaunchKernelGGL(k_spline_solve1, grid_for(S.n0, 64), 64, 0, h->stream, S);
+        spline_fit_launch<float>(h, (const float*)h->J[h->cur], h->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(coef, S.coef, (size_t)S.n0 * S.n1 * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

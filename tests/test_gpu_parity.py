@@ -789,14 +789,18 @@ def test_spline_value_iteration_matches_reference_golden(tier):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dims,udims", [((4, 4), (3,)), ((5, 130), (4,)), ((131, 67), (9,)), ((200, 64), (2,))])
+@pytest.mark.parametrize("dims,udims", [((4, 4), (3,)), ((5, 130), (4,)), ((131, 67), (9,)), ((200, 64), (2,)),
+                                        ((300, 521), (3,)), ((257, 259), (2,))])
 def test_spline_sweeps_match_oracle(dims, udims):
-    """Ragged sizes (minimum 4 levels, lines that do not fill the 64-wide solve tiles), alpha < 1, f64 and f32."""
+    """Ragged sizes (minimum 4 levels, lines that do not fill the 64-wide solve tiles, lines long enough to be cut
+    into chunks with a warm-up), alpha < 1, f64 and f32."""
     p, _ = _custom_problem("pendulum", dims, udims, dt=0.08, seed=5)
     xn, _, _, G = O.cells(p, np.arange(p.nodes_n))
     for dtype, tol in (("float64", 1e-11), ("float32", 2e-6)):
         h = native_problem(p, dtype=dtype)
         h.set_interpolation("bicubic")
+        if min(dims) > 128:                        # the substitution passes are cut into chunks with a warm-up
+            assert "chunk0=64" in h.describe() and "chunk1=64" in h.describe()
         h.terminal_cost()
         J = O.terminal_cost(p)
         if dtype == "float32":
