@@ -322,10 +322,25 @@ struct Interp<float, N> {
 // =================================================================================================
 // block reduction of the three sweep statistics -> encoded atomicMax
 // =================================================================================================
+// wave-wide maximum of a double, result in every lane.  The six steps move the two halves with DPP (vector-ALU
+// register moves: row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast 15 / 31) instead of ds_bpermute, which
+// occupies the LDS pipe for ~15 clk per dword on gfx950; the total lands in lane 63 and is broadcast from there.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_max_step(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return fmax(v, __hiloint2double(hi2, lo2));
+}
 __device__ inline double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
-    return v;
+    v = dpp_max_step<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_max_step<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_max_step<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_max_step<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of each row holds the row maximum
+    v = dpp_max_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_max_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave maximum
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
 
 __device__ inline int wave_min_i(int v) {
@@ -1603,7 +1618,9 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
 static int lean_setup(pvi_problem* h) {
     const DevP& P = h->P;
     LeanP& L = h->LP;
+    const float* actc = L.actc;  // uploaded by pvi_create together with the float4 action table
     memset(&L, 0, sizeof(L));
+    L.actc = actc;
     h->lean_ok = false;
     if (!h->fast_ok || getenv("PVI_NO_LEAN")) return PVI_OK;
     const int DOF = P.dof, M = P.m;
@@ -1855,6 +1872,16 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
             act[a] = make_float4((float)utab[a * d->m], d->m > 1 ? (float)utab[a * d->m + 1] : 0.f,
                                  (float)(gu[a] * d->dt), aok[a] ? 1.f : 0.f);
         if ((rc = dev_upload(h, act.data(), act.size(), &h->F.act))) return bail(rc);
+        {   // the same constants packed for scalar loads (sweep_lean.inc lean_act_group): groups of 4 actions
+            const int per = d->m == 1 ? 2 : 4;
+            std::vector<float> actc((size_t)(((A + 3) & ~3ll) + 4) * per, 0.f);
+            for (long long a = 0; a < A; ++a) {
+                actc[a * per] = act[a].x;
+                if (per == 2) actc[a * per + 1] = act[a].z;
+                else { actc[a * per + 1] = act[a].y; actc[a * per + 2] = act[a].z; }
+            }
+            if ((rc = dev_upload(h, actc.data(), actc.size(), &h->LP.actc))) return bail(rc);
+        }
         h->F.guard = 1e-3f;
         if (const char* e = getenv("PVI_GUARD")) h->F.guard = (float)atof(e);  // experiments only
         long long threads = h->owned;
@@ -2154,7 +2181,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->march_lds)); \
             h->march_lds_attr = true;                                                                               \
         }                                                                                                           \
-        hipLaunchKernelGGL(kfn, dim3(sc.nblocks), h->march_block, h->march_lds, st, h->P, h->LP, h->MP, h->F.act, Jin, \
+        hipLaunchKernelGGL(kfn, dim3(sc.nblocks), h->march_block, h->march_lds, st, h->P, h->LP, h->MP, h->F.act, h->LP.actc, Jin, \
                            Jout, pi, al, sc);                                                                       \
     }
             if (h->d.dynamics_id == PVI_DYN_CARTPOLE)
@@ -2175,7 +2202,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lean_lds)); \
             h->lean_lds_attr = true;                                                                                \
         }                                                                                                           \
-        hipLaunchKernelGGL(kfn, h->lean_grid, h->lean_block, h->lean_lds, st, h->P, h->LP, h->F.act, Jin, Jout, pi, al, \
+        hipLaunchKernelGGL(kfn, h->lean_grid, h->lean_block, h->lean_lds, st, h->P, h->LP, h->F.act, h->LP.actc, Jin, Jout, pi, al, \
                            sc);                                                                                     \
     }
 #define LEAN(DYN)              \
