@@ -81,8 +81,24 @@ def cpu_baseline(cfg, budget_s=20.0):
                 sweeps_per_sec=v / cells_per_sweep), None, 0
 
 
-VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0   # wave64 VALU instructions / s: one per quad-cycle per SIMD (measured:
-                                          # SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU on gfx950), 256 CUs x 4 SIMDs, 2.4 GHz
+N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9          # 256 CUs x 4 SIMDs, 2.4 GHz
+VALU_CLK, LDS_CLK = 2.33, 15.0             # cheapest issue cost per wave64 instruction, measured by tools/valubench.hip
+
+
+def issue_roofline(ctr, kern_ms, cells):
+    """What actually bounds the sweep: SIMD instruction issue.  On gfx950 the vector-ALU, LDS and scalar streams
+    of a SIMD add up instead of overlapping (tools/valubench.hip: 64 v_fma + 8 ds_read2_b32 take 153 + 120 clk,
+    not max); cheapest costs per wave64 instruction: VALU 2.33 clk (v_fma; v_cmp / v_cndmask / v_cvt 4, v_pk 4.5),
+    ds_read2_b32 15 clk.  `frac` = instruction counts (rocprofv3 PMC, profiles/counters.json) priced at those
+    cheapest costs / SIMD cycles the kernel was resident: the share of the kernel time that is issue at the
+    hardware's best rate; the rest is dearer instruction kinds, scalar work and exposed latency."""
+    simd_clk = kern_ms * 1e-3 * CLOCK_HZ
+    acc = (ctr["valu_insts_per_launch"] * VALU_CLK + ctr.get("lds_insts_per_launch", 0.0) * LDS_CLK) / N_SIMD
+    return {"bound": "simd-issue", "achieved": acc, "peak": simd_clk, "unit": "clk per SIMD", "frac": acc / simd_clk,
+            "model": "VALU %.2f clk + LDS %.0f clk per wave64 instruction, additive" % (VALU_CLK, LDS_CLK),
+            "valu_insts_per_cell": ctr["valu_insts_per_launch"] * 64.0 / cells,
+            "lds_insts_per_cell": ctr.get("lds_insts_per_launch", 0.0) * 64.0 / cells,
+            "salu_insts_per_cell": ctr.get("salu_insts_per_launch", 0.0) * 64.0 / cells}
 
 
 def load_counters(workload):
@@ -145,13 +161,8 @@ def run_single(args):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": ctr.get("hbm_bytes_per_launch"),
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
-                     "note": "nominal: the sweep is VALU-issue bound (A actions per node on 9 B of traffic), see roofline_valu"},
-        "roofline_valu": None if not ctr.get("valu_insts_per_launch") else {
-            "bound": "valu-issue", "achieved": ctr["valu_insts_per_launch"] / (kern_ms * 1e-3) / 1e9,
-            "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave64-instr/s",
-            "frac": ctr["valu_insts_per_launch"] / (kern_ms * 1e-3) / VALU_ISSUE_PEAK,
-            "valu_insts_per_launch": ctr["valu_insts_per_launch"],
-            "valu_insts_per_cell": ctr["valu_insts_per_launch"] * 64.0 / (N * A)},
+                     "note": "nominal: the sweep is instruction-issue bound (A actions per node on 9 B of traffic), see roofline_issue"},
+        "roofline_issue": None if not ctr.get("valu_insts_per_launch") else issue_roofline(ctr, kern_ms, N * A),
         "flops_frac_f32_vector_peak": (N * A / (kern_ms * 1e-3)) * flops_cell / (VALU_PEAK_F32_TFLOPS * 1e12),
         "last_stats": [float(v) for v in stats[-1]],
         "kernel_path": p.describe(),

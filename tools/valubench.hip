@@ -40,25 +40,25 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float s) {
 template <int MODE>
 void run(const char* name, double instr_per_iter, int wpb) {
     float* d;
-    hipMalloc(&d, 2048 * 1024 * 4);
+    (void)hipMalloc(&d, 2048 * 1024 * 4);
     const int iters = 4000;
     for (int blocks_per_cu = 1; blocks_per_cu <= 8; blocks_per_cu *= 2) {
         const int blocks = 256 * blocks_per_cu;
         hipEvent_t a, b;
-        hipEventCreate(&a); hipEventCreate(&b);
+        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
         k<MODE><<<blocks, 64 * wpb>>>(d, 10, 0.999f);
-        hipDeviceSynchronize();
-        hipEventRecord(a);
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(a);
         k<MODE><<<blocks, 64 * wpb>>>(d, iters, 0.999f);
-        hipEventRecord(b);
-        hipEventSynchronize(b);
-        float ms; hipEventElapsedTime(&ms, a, b);
+        (void)hipEventRecord(b);
+        (void)hipEventSynchronize(b);
+        float ms; (void)hipEventElapsedTime(&ms, a, b);
         const double waves_per_simd = blocks_per_cu * wpb / 4.0;
         const double instr_per_simd = waves_per_simd * iters * instr_per_iter;
         printf("%-28s waves/SIMD %4.1f  %.3f ms  -> %.2f clk @2.4GHz per counted wave-instr per SIMD\n", name, waves_per_simd, ms,
                ms * 1e-3 * 2.4e9 / instr_per_simd);
     }
-    hipFree(d);
+    (void)hipFree(d);
 }
 
 // VALU and LDS work in one loop: does the time add up or overlap?  NF fmas (8 chains) + NL ds_read2_b32 per iteration
@@ -111,7 +111,52 @@ void runmix() {
     (void)hipFree(d);
 }
 
+// scalar-ALU issue cost: 64 independent-ish s_add_i32 per iteration next to NF v_fma (does scalar work add as well?)
+template <int NF>
+__global__ __launch_bounds__(256) void ksalu(float* out, int iters, float s, int seed) {
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (float)(threadIdx.x + i) * 0.001f;
+    int r0 = seed, r1 = seed + 1, r2 = seed + 2, r3 = seed + 3;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            asm volatile("s_add_i32 %0, %0, 1\n s_add_i32 %1, %1, 3\n s_add_i32 %2, %2, 5\n s_add_i32 %3, %3, 7"
+                         : "+s"(r0), "+s"(r1), "+s"(r2), "+s"(r3));
+#pragma unroll
+        for (int u = 0; u < NF / 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = __builtin_fmaf(a[i], s, 0.5f);
+    }
+    float acc = (float)(r0 + r1 + r2 + r3);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += a[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+template <int NF>
+void runsalu() {
+    float* d;
+    (void)hipMalloc(&d, 2048 * 1024 * 4);
+    const int iters = 4000, blocks = 256 * 8;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    ksalu<NF><<<blocks, 256>>>(d, 10, 0.999f, 1);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(a);
+    ksalu<NF><<<blocks, 256>>>(d, iters, 0.999f, 1);
+    (void)hipEventRecord(b);
+    (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    printf("salu: 64 s_add_i32 + %3d v_fma per iteration, 8 waves/SIMD: %.1f clk @2.4GHz per iteration per SIMD-wave\n", NF,
+           ms * 1e-3 * 2.4e9 / (8.0 * iters));
+    (void)hipFree(d);
+}
+
 int main() {
+    runsalu<0>();
+    runsalu<64>();
+    runsalu<128>();
     runmix<64, 0>();
     runmix<0, 8>();
     runmix<64, 8>();
