@@ -374,6 +374,46 @@ __device__ inline void block_stats_at(double* red, double j, double dmax, double
     }
 }
 
+// float32 kernels: the three statistics are float32 values (max J exactly; delta = J_new - J_old rounded once to
+// float32, 6e-8 relative), reduced as order-preserving int32 keys -- one DPP-fused v_max_i32 per step, no
+// canonicalisation, no LDS-pipe traffic -- and widened to the float64 slots only by the three publishing threads.
+__device__ __forceinline__ int f32_key(float f) {
+    const int b = __float_as_int(f);
+    return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float f32_unkey(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_imax_step(int v) {
+    return max(v, __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ int wave_max_key(int v) {
+    v = dpp_imax_step<0x111, 0xf>(v);
+    v = dpp_imax_step<0x112, 0xf>(v);
+    v = dpp_imax_step<0x114, 0xf>(v);
+    v = dpp_imax_step<0x118, 0xf>(v);
+    v = dpp_imax_step<0x142, 0xa>(v);
+    v = dpp_imax_step<0x143, 0xc>(v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// `red`: 48 ints of LDS scratch
+__device__ inline void block_stats_f32_at(int* red, float j, float dmax, float ndmin, unsigned long long* slot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    const int kj = wave_max_key(f32_key(j)), kd = wave_max_key(f32_key(dmax)), kn = wave_max_key(f32_key(ndmin));
+    if (lane == 0) {
+        red[wave] = kj;
+        red[16 + wave] = kd;
+        red[32 + wave] = kn;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        int v = red[16 * threadIdx.x];
+        for (int w = 1; w < nw; ++w) v = max(v, red[16 * threadIdx.x + w]);
+        const unsigned long long old =
+            atomicMax(&slot[4 * (blockIdx.x & (STAT_SHARDS - 1)) + threadIdx.x], enc_f64((double)f32_unkey(v)));
+        asm volatile("" ::"v"(old));  // consume the return value: the atomic has been performed
+    }
+}
+
 __device__ inline void block_stats(double j, double dmax, double ndmin, unsigned long long* slot) {
     __shared__ double red[3][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -1637,9 +1677,10 @@ static int lean_setup(pvi_problem* h) {
     if (DOF == 2)
         hipLaunchKernelGGL(k_lean_pairs, grid_for((long long)P.dim[1] * P.dim[3]), 256, 0, h->stream, P, 1, L.pt1);
     HIPCHK(hipGetLastError());
-    // lanes per node for small grids
+    // lanes per node for small grids: as many as still fit ONE round of resident waves (1024 SIMDs x 8 waves x 64
+    // lanes); a second round costs more than the extra parallelism brings (201x201x201: 27 -> 23 us)
     int ls = 0;
-    while ((h->owned << ls) < (1ll << 19) && (2 << ls) <= 16 && (4 << ls) <= P.A) ++ls;
+    while ((h->owned << (ls + 1)) <= (1ll << 19) && (2 << ls) <= 16 && (4 << ls) <= P.A) ++ls;
     if (const char* e = getenv("PVI_LSPLIT")) ls = atoi(e);
     L.lsplit = ls;
     const int spb = std::max(16, 256 >> ls);  // nodes per workgroup
