@@ -1213,36 +1213,88 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(DevP P, TileP F, const floa
 
 // =================================================================================================
 // tier B: table-driven sweep for arbitrary sys.f / cf.g (dynamicprogramming.py:564-570 verbatim:
-// Q = G + alpha * J_interp(x_next_table)).  x_next [node][A][N] f64, G [node][A] f64.
+// Q = G + alpha * J_interp(x_next_table)).  x_next [node][A][N] f64, G [node][A] f64: N*8 + 8 bytes per cell, read
+// exactly once per sweep -- this tier is HBM-bound, so the tables are streamed with fully coalesced loads:
+// a workgroup owns `npb` consecutive nodes, its lanes walk the nodes' cells in memory order (lane = cell), write
+// Q to LDS, and one thread per node then scans its A values for the first minimum (np.argmin).  Action counts too
+// large for the LDS row are processed in chunks of `achunk` actions.
 // =================================================================================================
-template <int N, typename REAL, typename PI_T>
+template <int N, typename REAL, typename PI_T, bool LEVLDS>
 __global__ __launch_bounds__(256) void k_sweep_table(DevP P, const double* __restrict__ xnext,
                                                      const double* __restrict__ Gt,
                                                      const unsigned char* __restrict__ okt,
                                                      const REAL* __restrict__ Jin,
                                                      REAL* __restrict__ Jout, PI_T* __restrict__ pi, double alpha,
-                                                     SweepCtl sc) {
+                                                     SweepCtl sc, int npb, int achunk, int qs_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double qs_raw[];
+    REAL* qs = (REAL*)qs_raw;
     if (sc.ctrl->done) return;
-    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // grid levels: LDS copies behind the Q rows when they fit (lev_lds), else read from global memory
+    const double* lev[N];
+    {
+        double* dst = qs_raw + qs_doubles;
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+            if constexpr (LEVLDS) {
+                for (int i = threadIdx.x; i < P.dim[d]; i += blockDim.x) dst[i] = P.lev[d][i];
+                lev[d] = dst;
+                dst += P.dim[d];
+            } else {
+                lev[d] = P.lev[d];
+            }
+        }
+        if constexpr (LEVLDS) __syncthreads();
+    }
     const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
-    double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
-    if (o < owned) {
-        const long long self = o + (long long)(P.row_begin - P.store_begin) * P.plane;
-        REAL best = (REAL)0;
-        int arg = 0;
-        const REAL alpha_r = (REAL)alpha;
-        for (int a = 0; a < P.A; ++a) {
-            const double* xn = xnext + ((long long)o * P.A + a) * N;
+    const long long n0 = (long long)blockIdx.x * npb;
+    const int nn = (int)min((long long)npb, owned - n0);
+    const REAL alpha_r = (REAL)alpha;
+    REAL best = (REAL)0;
+    int arg = 0;
+    for (int a0 = 0; a0 < P.A; a0 += achunk) {
+        const int ac = min(achunk, P.A - a0);
+        const int ncell = nn * ac;
+        // the next cell's table entries are requested before the current cell is evaluated (one memory round trip
+        // per cell would otherwise sit in front of ~150 dependent instructions)
+        struct CellIn {
+            double x[N], g;
+            unsigned char ok;
+        };
+        auto fetch = [&](int lc, CellIn& c) {
+            const int ln = lc / ac, a = a0 + (lc - ln * ac);
+            const long long cell = (n0 + ln) * P.A + a;  // one chunk: consecutive lanes = consecutive cells in memory
+            if constexpr (N == 2) {
+                const double2 t = *(const double2*)(xnext + cell * 2);
+                c.x[0] = t.x;
+                c.x[1] = t.y;
+            } else if constexpr (N == 4) {
+                const double4 t = *(const double4*)(xnext + cell * 4);
+                c.x[0] = t.x;
+                c.x[1] = t.y;
+                c.x[2] = t.z;
+                c.x[3] = t.w;
+            } else {
+#pragma unroll
+                for (int d = 0; d < N; ++d) c.x[d] = xnext[cell * N + d];
+            }
+            c.g = Gt[cell];
+            c.ok = okt ? okt[cell] : (unsigned char)1;
+        };
+        CellIn cur, nxt;
+        if ((int)threadIdx.x < ncell) fetch(threadIdx.x, cur);
+        for (int lc = threadIdx.x; lc < ncell; lc += blockDim.x) {
+            if (lc + (int)blockDim.x < ncell) fetch(lc + blockDim.x, nxt);
             bool inb = true;
             int ci[N];
             double y[N];
             long long b = 0;
 #pragma unroll
             for (int d = 0; d < N; ++d) {
-                const double v = xn[d];
+                const double v = cur.x[d];
                 inb = inb && !(v < P.glo[d]) && !(v > P.ghi[d]);
-                ci[d] = find_interval(P.lev[d], P.dim[d], P.glo[d], P.inv_step[d], v);
-                y[d] = (v - P.lev[d][ci[d]]) / (P.lev[d][ci[d] + 1] - P.lev[d][ci[d]]);
+                ci[d] = find_interval(lev[d], P.dim[d], P.glo[d], P.inv_step[d], v);
+                const double l0 = lev[d][ci[d]];
+                y[d] = (v - l0) / (lev[d][ci[d] + 1] - l0);
                 int c = ci[d];
                 if (d == 0) {
                     if (inb && (c < P.store_begin || c + 1 >= P.store_end)) atomicOr(&sc.ctrl->halo_err, 1);
@@ -1250,7 +1302,7 @@ __global__ __launch_bounds__(256) void k_sweep_table(DevP P, const double* __res
                 }
                 b += c * P.strd[d];
             }
-            const REAL G = (REAL)Gt[(long long)o * P.A + a];
+            const REAL G = (REAL)cur.g;
             const REAL Jn = inb ? Interp<REAL, N>::eval(Jin, P.strd, b, y) : (REAL)0;
             REAL q;
             if (sizeof(REAL) == 8)
@@ -1259,12 +1311,27 @@ __global__ __launch_bounds__(256) void k_sweep_table(DevP P, const double* __res
                 q = fmaf(alpha_r, Jn, G);
             // base-class semantics (dynamicprogramming.py:195-236): an invalid action / next state costs
             // exactly INF, not INF + alpha*J as in the look-up-table class (:567)
-            if (okt && !okt[(long long)o * P.A + a]) q = (REAL)P.INF;
-            if (a == 0 || q < best) {
-                best = q;
-                arg = a;
+            if (!cur.ok) q = (REAL)P.INF;
+            qs[lc] = q;
+            cur = nxt;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nn) {
+            const REAL* row = qs + threadIdx.x * ac;
+            for (int k = 0; k < ac; ++k) {
+                const REAL q = row[k];
+                if ((a0 == 0 && k == 0) || q < best) {
+                    best = q;
+                    arg = a0 + k;
+                }
             }
         }
+        __syncthreads();
+    }
+    double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
+    if ((int)threadIdx.x < nn) {
+        const long long o = n0 + threadIdx.x;
+        const long long self = o + (long long)(P.row_begin - P.store_begin) * P.plane;
         Jout[self] = best;
         pi[o] = (PI_T)arg;
         const double jn = (double)best, d = jn - (double)Jin[self];
@@ -2317,19 +2384,30 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             break;
         case PVI_DYN_TABLE:
             if (!h->d_xnext || !h->d_G) return fail(PVI_ESTATE, "tier B sweep before pvi_set_tables");
-            switch (h->P.n) {
-                case 2:
-                    hipLaunchKernelGGL((k_sweep_table<2, REAL, PI_T>), g, 256, 0, st, h->P, h->d_xnext, h->d_G, h->d_ok, Jin,
-                                       Jout, pi, alpha, sc);
-                    break;
-                case 3:
-                    hipLaunchKernelGGL((k_sweep_table<3, REAL, PI_T>), g, 256, 0, st, h->P, h->d_xnext, h->d_G, h->d_ok, Jin,
-                                       Jout, pi, alpha, sc);
-                    break;
-                default:
-                    hipLaunchKernelGGL((k_sweep_table<4, REAL, PI_T>), g, 256, 0, st, h->P, h->d_xnext, h->d_G, h->d_ok, Jin,
-                                       Jout, pi, alpha, sc);
-                    break;
+            {
+                // nodes per workgroup / actions per LDS chunk: ~2048 cells of Q (<= 16 KB) per pass
+                const int A = h->A;
+                const int npb = A >= 2048 ? 1 : std::max(1, std::min(256, 2048 / A));
+                const int achunk = A >= 2048 ? 2048 : A;
+                const int qs_doubles = (int)(((size_t)npb * achunk * sizeof(REAL) + 7) / 8);
+                int nlev = 0;
+                for (int d = 0; d < h->P.n; ++d) nlev += h->P.dim[d];
+                const int lev_lds = nlev * 8 <= 24 * 1024;
+                const size_t lds = (size_t)(qs_doubles + (lev_lds ? nlev : 0)) * 8;
+                const unsigned gt = (unsigned)((h->owned + npb - 1) / npb);
+                sc.nblocks = gt;
+#define TABLE(NN, LL)                                                                                                   \
+    hipLaunchKernelGGL((k_sweep_table<NN, REAL, PI_T, LL>), gt, 256, lds, st, h->P, h->d_xnext, h->d_G, h->d_ok, Jin, Jout, \
+                       pi, alpha, sc, npb, achunk, qs_doubles)
+                switch (h->P.n * 2 + lev_lds) {
+                    case 4: TABLE(2, false); break;
+                    case 5: TABLE(2, true); break;
+                    case 6: TABLE(3, false); break;
+                    case 7: TABLE(3, true); break;
+                    case 8: TABLE(4, false); break;
+                    default: TABLE(4, true); break;
+                }
+#undef TABLE
             }
             break;
         default:
