@@ -529,12 +529,29 @@ __global__ void k_terminal_cost(DevP P, REAL* __restrict__ J) {
 // the fused sweep, tier A (in-kernel dynamics), one thread per node, actions looped in registers.
 // v0 gather path: J_k read straight through L1/L2.
 // =================================================================================================
-template <int DYN, typename REAL, typename PI_T>
+template <int DYN, typename REAL, typename PI_T, bool LEVLDS>
 __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ Jin, REAL* __restrict__ Jout,
                                                PI_T* __restrict__ pi, double alpha, SweepCtl sc) {
     using D = Dyn<DYN>;
     constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M;
     if (sc.ctrl->done) return;
+    // grid levels: LDS copies when they fit (they are read several times per cell), else global memory
+    extern __shared__ __attribute__((aligned(16))) double lev_lds[];
+    const double* lev[N];
+    {
+        double* dst = lev_lds;
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+            if constexpr (LEVLDS) {
+                for (int i = threadIdx.x; i < P.dim[d]; i += blockDim.x) dst[i] = P.lev[d][i];
+                lev[d] = dst;
+                dst += P.dim[d];
+            } else {
+                lev[d] = P.lev[d];
+            }
+        }
+        if constexpr (LEVLDS) __syncthreads();
+    }
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
     double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
@@ -545,7 +562,7 @@ __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ 
         long long self = (long long)(idx[0] - P.store_begin) * P.strd[0];
 #pragma unroll
         for (int d = 0; d < N; ++d) {
-            x[d] = P.lev[d][idx[d]];
+            x[d] = lev[d][idx[d]];
             dx[d] = x[d] - P.xbar[d];
             if (d > 0) self += idx[d] * P.strd[d];
         }
@@ -563,8 +580,8 @@ __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ 
             const double xn = x[DOF + i] * P.dt + x[i];
             pos_ok = pos_ok && !(xn < P.lb[i]) && !(xn > P.ub[i]);
             pos_in = pos_in && !(xn < P.glo[i]) && !(xn > P.ghi[i]);
-            ci[i] = find_interval(P.lev[i], P.dim[i], P.glo[i], P.inv_step[i], xn);
-            y[i] = (xn - P.lev[i][ci[i]]) / (P.lev[i][ci[i] + 1] - P.lev[i][ci[i]]);
+            ci[i] = find_interval(lev[i], P.dim[i], P.glo[i], P.inv_step[i], xn);
+            y[i] = (xn - lev[i][ci[i]]) / (lev[i][ci[i] + 1] - lev[i][ci[i]]);
         }
         if (pos_in) {
             int r0 = ci[0];
@@ -605,8 +622,8 @@ __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ 
 #pragma unroll
                 for (int i = 0; i < DOF; ++i) {
                     const int d = DOF + i;
-                    ci[d] = find_interval(P.lev[d], P.dim[d], P.glo[d], P.inv_step[d], xnv[i]);
-                    y[d] = (xnv[i] - P.lev[d][ci[d]]) / (P.lev[d][ci[d] + 1] - P.lev[d][ci[d]]);
+                    ci[d] = find_interval(lev[d], P.dim[d], P.glo[d], P.inv_step[d], xnv[i]);
+                    y[d] = (xnv[i] - lev[d][ci[d]]) / (lev[d][ci[d] + 1] - lev[d][ci[d]]);
                     b += ci[d] * P.strd[d];
                 }
             }
@@ -2369,19 +2386,19 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             return PVI_OK;
         }
     }
+    int nlev_all = 0;
+    for (int d = 0; d < h->P.n; ++d) nlev_all += h->P.dim[d];
+    const bool lev_in_lds = nlev_all * 8 <= 32 * 1024;
+    const size_t lev_bytes = lev_in_lds ? (size_t)nlev_all * 8 : 0;
+#define EXACT(DYN)                                                                                                     \
+    if (lev_in_lds)                                                                                                    \
+        hipLaunchKernelGGL((k_sweep<DYN, REAL, PI_T, true>), g, 256, lev_bytes, st, h->P, Jin, Jout, pi, alpha, sc);   \
+    else                                                                                                               \
+        hipLaunchKernelGGL((k_sweep<DYN, REAL, PI_T, false>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha, sc);
     switch (h->d.dynamics_id) {
-        case PVI_DYN_PENDULUM:
-            hipLaunchKernelGGL((k_sweep<PVI_DYN_PENDULUM, REAL, PI_T>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha,
-                               sc);
-            break;
-        case PVI_DYN_CARTPOLE:
-            hipLaunchKernelGGL((k_sweep<PVI_DYN_CARTPOLE, REAL, PI_T>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha,
-                               sc);
-            break;
-        case PVI_DYN_TWOLINK:
-            hipLaunchKernelGGL((k_sweep<PVI_DYN_TWOLINK, REAL, PI_T>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha,
-                               sc);
-            break;
+        case PVI_DYN_PENDULUM: EXACT(PVI_DYN_PENDULUM) break;
+        case PVI_DYN_CARTPOLE: EXACT(PVI_DYN_CARTPOLE) break;
+        case PVI_DYN_TWOLINK: EXACT(PVI_DYN_TWOLINK) break;
         case PVI_DYN_TABLE:
             if (!h->d_xnext || !h->d_G) return fail(PVI_ESTATE, "tier B sweep before pvi_set_tables");
             {
@@ -2413,6 +2430,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         default:
             return fail(PVI_EINVAL, "unknown dynamics_id");
     }
+#undef EXACT
     HIPCHK(hipGetLastError());
     return PVI_OK;
 }
