@@ -531,7 +531,9 @@ __global__ void k_terminal_cost(DevP P, REAL* __restrict__ J) {
 // =================================================================================================
 template <int DYN, typename REAL, typename PI_T, bool LEVLDS>
 __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ Jin, REAL* __restrict__ Jout,
-                                               PI_T* __restrict__ pi, double alpha, SweepCtl sc) {
+                                               PI_T* __restrict__ pi, double alpha, SweepCtl sc,
+                                               const double* __restrict__ utab, const double* __restrict__ gutab,
+                                               const int* __restrict__ aoktab) {
     using D = Dyn<DYN>;
     constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M;
     if (sc.ctrl->done) return;
@@ -606,9 +608,10 @@ __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ 
         for (int a = 0; a < P.A; ++a) {
             double u[M], acc[DOF];
 #pragma unroll
-            for (int k = 0; k < M; ++k) u[k] = P.utab[a * M + k];
+            for (int k = 0; k < M; ++k) u[k] = utab[a * M + k];
             dyn.accel(u, acc);
-            bool ok = pos_ok && P.aok[a], inb = pos_in;
+            const int aok_a = aoktab[a];  // unconditional: a wave-uniform scalar load
+            bool ok = pos_ok && aok_a != 0, inb = pos_in;
             double xnv[DOF];
 #pragma unroll
             for (int i = 0; i < DOF; ++i) {
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ 
                 }
             }
             // G (dynamicprogramming.py:534-549)
-            const double g = on_target ? 0.0 : (gx + P.gu[a]);
+            const double g = on_target ? 0.0 : (gx + gutab[a]);
             const REAL G = ok ? (REAL)(g * P.dt) : (REAL)P.INF;
             const REAL Jn = inb ? Interp<REAL, N>::eval(Jin, P.strd, b, y) : (REAL)0;
             REAL q;
@@ -1610,6 +1613,7 @@ struct pvi_problem {
     size_t march_lds = 0;
     bool march_lds_attr = false;
     int march_block = 256;
+    const int* aok32 = nullptr;  // isavalidinput per action as int32 (scalar loads in the exact kernel)
     SplineP SP;               // bicubic-spline interpolation mode (sweep_spline.inc)
     bool spline = false;
 };
@@ -1991,6 +1995,10 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
     if ((rc = dev_upload(h, utab.data(), utab.size(), &P.utab))) return bail(rc);
     if ((rc = dev_upload(h, gu.data(), gu.size(), &P.gu))) return bail(rc);
     if ((rc = dev_upload(h, aok.data(), aok.size(), &P.aok))) return bail(rc);
+    {
+        std::vector<int> aok32(aok.begin(), aok.end());
+        if ((rc = dev_upload(h, aok32.data(), aok32.size(), &h->aok32))) return bail(rc);
+    }
     {   // f32 fast path: per-action {u0, u1, gu*dt, isavalidinput}
         std::vector<float4> act((size_t)A);
         for (long long a = 0; a < A; ++a)
@@ -2392,9 +2400,11 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     const size_t lev_bytes = lev_in_lds ? (size_t)nlev_all * 8 : 0;
 #define EXACT(DYN)                                                                                                     \
     if (lev_in_lds)                                                                                                    \
-        hipLaunchKernelGGL((k_sweep<DYN, REAL, PI_T, true>), g, 256, lev_bytes, st, h->P, Jin, Jout, pi, alpha, sc);   \
+        hipLaunchKernelGGL((k_sweep<DYN, REAL, PI_T, true>), g, 256, lev_bytes, st, h->P, Jin, Jout, pi, alpha, sc,    \
+                           h->P.utab, h->P.gu, h->aok32);                                                              \
     else                                                                                                               \
-        hipLaunchKernelGGL((k_sweep<DYN, REAL, PI_T, false>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha, sc);
+        hipLaunchKernelGGL((k_sweep<DYN, REAL, PI_T, false>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha, sc, h->P.utab,   \
+                           h->P.gu, h->aok32);
     switch (h->d.dynamics_id) {
         case PVI_DYN_PENDULUM: EXACT(PVI_DYN_PENDULUM) break;
         case PVI_DYN_CARTPOLE: EXACT(PVI_DYN_CARTPOLE) break;
