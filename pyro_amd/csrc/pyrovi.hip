@@ -2294,11 +2294,11 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         if (h->d.dynamics_id == PVI_DYN_TABLE) {
             if (!h->d_xnext || !h->d_G) return fail(PVI_ESTATE, "tier B sweep before pvi_set_tables");
             hipLaunchKernelGGL((k_sweep_spline<PVI_DYN_TABLE, REAL, PI_T>), g, 256, 0, st, h->P, S, h->d_xnext, h->d_G,
-                               h->d_ok, Jin, Jout, pi, alpha, sc);
+                               h->d_ok, Jin, Jout, pi, alpha, sc, h->P.utab, h->P.gu, h->aok32);
         } else {
             hipLaunchKernelGGL((k_sweep_spline<PVI_DYN_PENDULUM, REAL, PI_T>), g, 256, 0, st, h->P, S,
                                (const double*)nullptr, (const double*)nullptr, (const unsigned char*)nullptr, Jin, Jout,
-                               pi, alpha, sc);
+                               pi, alpha, sc, h->P.utab, h->P.gu, h->aok32);
         }
         HIPCHK(hipGetLastError());
         return PVI_OK;
