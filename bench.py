@@ -170,7 +170,32 @@ def run_single(args):
     if cpu is not None:
         out["cpu_baseline"] = cpu
         out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
+    if getattr(args, "with_sharded_reference", False):
+        out["sharded_workload_1gpu"] = sharded_reference()
     print(json.dumps(out))
+
+
+def sharded_reference(name="c4", sweeps=5):
+    """The N > 1 bench lines run a different workload than the N = 1 line (BASELINE configs[3]: cart-pole 151^4 x 31,
+    axis-0 slabs; configs[1] is 44 us of work per sweep and cannot amortise a halo exchange).  Its 1-GPU rate is the
+    denominator of the strong-scaling speed-up, so it is measured here as well (and again by rank 0 of every N > 1 run:
+    `value_1gpu_same_workload`)."""
+    from pyro_amd import configs
+    from pyro_amd.planning import dynamicprogramming
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg = configs.build(name)
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype=cfg["dtype"])
+    p, g = dp._p, cfg["grid_sys"]
+    p.sweep(2, 1.0, -1.0)
+    p.synchronize()
+    t0 = time.perf_counter()
+    p.sweep(sweeps, 1.0, -1.0)
+    p.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": "%s: %s" % (cfg["name"], cfg["description"]), "value": g.nodes_n * g.actions_n * sweeps / dt,
+           "unit": "cells/s", "ms_per_step": dt / sweeps * 1e3, "steps": sweeps}
+    p.close()
+    return out
 
 
 def main():
@@ -186,6 +211,7 @@ def main():
     if args.gpus > 1 or world > 1 or os.environ.get("PVI_FORCE_PARALLEL"):
         from pyro_amd import parallel_bench
         return parallel_bench.run(args)
+    args.with_sharded_reference = args.workload is None and not args.no_cpu   # the default driver run
     args.workload = args.workload or "c2"
     big = args.workload in ("c3", "c4", "c5")
     args.steps = args.steps if args.steps is not None else (20 if big else 200)

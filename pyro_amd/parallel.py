@@ -39,9 +39,13 @@ def halo_rows(grid_sys):
 
 
 class HipSlab:
-    """One rank's slab on its GPU.  J lives in torch tensors so RCCL can move halo rows in place."""
+    """One rank's slab on its GPU.  J lives in torch tensors so RCCL can move halo rows in place.
 
-    def __init__(self, grid_sys, cost, dtype, rows, halo, device):
+    With `split=True` the owned rows are driven by up to three library handles over the SAME buffers -- the `halo`
+    rows next to each neighbour ("boundary") and the rest ("interior") -- so that a sweep can run
+    boundary kernels -> [halo exchange || interior kernel]: the rows the neighbours wait for are produced first."""
+
+    def __init__(self, grid_sys, cost, dtype, rows, halo, device, split=False, has_lower=False, has_upper=False):
         import torch
         from pyro_amd import _native
         self.torch = torch
@@ -58,8 +62,26 @@ class HipSlab:
         A = int(np.prod(grid_sys.u_grid_dim))
         self.pi = torch.zeros(nown, dtype=torch.uint8 if A <= 256 else torch.int16, device=self.dev)
         self.cur = 0
-        self.p = grid_sys._device_problem(cost=cost, dtype=dtype, rows=rows, halo=(halo, halo), device=device,
-                                          ext_J=[t.data_ptr() for t in self.J], ext_pi=self.pi.data_ptr())
+        # row ranges of the handles: boundary pieces first, the interior last
+        r0, r1 = rows
+        lo_b = (r0, min(r0 + halo, r1)) if (split and has_lower) else None
+        up_b = (max(r1 - halo, lo_b[1] if lo_b else r0), r1) if (split and has_upper) else None
+        if up_b is not None and up_b[0] >= up_b[1]:
+            up_b = None
+        i0 = lo_b[1] if lo_b else r0
+        i1 = up_b[0] if up_b else r1
+        self.boundary = [b for b in (lo_b, up_b) if b is not None]
+        self.interior = (i0, i1) if i1 > i0 else None
+        pieces = self.boundary + ([self.interior] if self.interior else [])
+
+        def make(piece):
+            a, b = piece
+            return grid_sys._device_problem(
+                cost=cost, dtype=dtype, rows=(a, b), halo=(a - self.store_rows[0], self.store_rows[1] - b), device=device,
+                ext_J=[t.data_ptr() for t in self.J], ext_pi=self.pi.data_ptr() + (a - r0) * self.plane * self.pi.element_size())
+        self.handles = [make(pc) for pc in pieces]
+        self.n_boundary = len(self.boundary)
+        self.p = self.handles[-1]
         # One dedicated stream orders everything of this rank: sweep kernels (handed to the library as a raw
         # hipStream_t), halo copies and collectives (torch / RCCL synchronise with the CURRENT torch stream).
         # It must not be torch's default stream: that one has handle 0, which the C ABI reads as "use the
@@ -68,17 +90,33 @@ class HipSlab:
         torch.cuda.set_stream(self.tstream)
         self._stream = self.tstream.cuda_stream
         assert self._stream != 0
+        self.cstream = torch.cuda.Stream(device=self.dev)      # halo traffic of the overlapped schedule
 
     def terminal_cost(self):
-        self.p.terminal_cost()
+        self.handles[0].terminal_cost()                 # every handle stores the whole slab: one fill is enough
+        self.torch.cuda.synchronize(self.dev)
+
+    def _launch(self, handles, alpha):
+        for h in handles:
+            h.sweep_async(alpha, self._stream)
 
     def sweep(self, alpha):
-        self.p.sweep_async(alpha, self._stream)
+        self._launch(self.handles, alpha)
         self.cur ^= 1
         assert self.p.device_J(0) == self.J[self.cur].data_ptr()
 
+    # overlapped schedule: boundary kernels, then (elsewhere) the exchange, concurrently the interior kernel
+    def sweep_boundary(self, alpha):
+        self._launch(self.handles[:self.n_boundary], alpha)
+        self.cur ^= 1
+
+    def sweep_interior(self, alpha):
+        self._launch(self.handles[self.n_boundary:], alpha)
+        assert self.p.device_J(0) == self.J[self.cur].data_ptr()
+
     def stats(self):
-        return self.p.sweep_stats(self._stream)
+        st = np.array([h.sweep_stats(self._stream) for h in self.handles])
+        return np.array([st[:, 0].max(), st[:, 1].max(), st[:, 2].min()])
 
     def rows_view(self, row0, nrows):
         o = (row0 - self.store_rows[0]) * self.plane
@@ -91,13 +129,14 @@ class HipSlab:
         return self.pi.cpu().numpy().astype(np.int64)
 
     def describe(self):
-        return self.p.describe()
+        return "%s pieces=%s" % (self.p.describe(), self.boundary + ([self.interior] if self.interior else []))
 
 
 class ShardedValueIteration:
     """Drives one slab per rank; `dist` is torch.distributed (already initialised)."""
 
-    def __init__(self, grid_sys, cost_function, dist, dtype="float32", device=0, slab_factory=None, halo=None):
+    def __init__(self, grid_sys, cost_function, dist, dtype="float32", device=0, slab_factory=None, halo=None,
+                 overlap=True):
         import torch
         self.torch, self.dist = torch, dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
@@ -111,9 +150,14 @@ class ShardedValueIteration:
         # the +-1 neighbour exchange needs every neighbour slab to be at least `halo` thick
         self.p2p = all(b - a >= self.halo for a, b in self.parts) or self.world == 1
         cost = cost_function.device_cost() if hasattr(cost_function, "device_cost") else cost_function
-        factory = slab_factory or HipSlab
         store_halo = self.halo if self.p2p else n0          # fall-back: every rank stores the whole grid
-        self.slab = factory(grid_sys, cost, dtype, self.rows, store_halo, device)
+        # boundary-first schedule (halo exchange overlapped with the interior kernel): product slabs, p2p exchange
+        self.overlap = bool(overlap) and slab_factory is None and self.p2p and self.world > 1
+        if slab_factory is None:
+            self.slab = HipSlab(grid_sys, cost, dtype, self.rows, store_halo, device, split=self.overlap,
+                                has_lower=self.rank > 0, has_upper=self.rank < self.world - 1)
+        else:
+            self.slab = slab_factory(grid_sys, cost, dtype, self.rows, store_halo, device)
         self.k = 0
         self.slab.terminal_cost()
 
@@ -178,8 +222,20 @@ class ShardedValueIteration:
     def sweep(self, alpha=1.0, want_stats=True):
         """One Bellman backup of the whole grid; returns (max J, max d, min d, delta) of the grid, or None
         when want_stats is False (no host synchronisation at all: kernel + halo exchange are just enqueued)."""
-        self.slab.sweep(alpha)
-        self.exchange()
+        s = self.slab
+        if self.overlap:
+            # rows the neighbours wait for first; their exchange runs on a second stream next to the interior kernel
+            s.sweep_boundary(alpha)
+            ev = self.torch.cuda.Event()
+            ev.record(s.tstream)
+            s.sweep_interior(alpha)
+            with self.torch.cuda.stream(s.cstream):
+                s.cstream.wait_event(ev)
+                self.exchange()
+            s.tstream.wait_stream(s.cstream)            # the next sweep reads the halo rows
+        else:
+            s.sweep(alpha)
+            self.exchange()
         self.k += 1
         return self._reduce_stats() if want_stats else None
 

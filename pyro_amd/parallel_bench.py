@@ -20,7 +20,7 @@ def run(args):
     os.environ.setdefault("MASTER_PORT", "29511")
     torch.cuda.set_device(local)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    name = args.workload or "c3"
+    name = args.workload or "c4"
     steps = args.steps if args.steps is not None else 20
     warmup = args.warmup if args.warmup is not None else 2
     with contextlib.redirect_stdout(io.StringIO()):
@@ -68,7 +68,9 @@ def run(args):
             "dtype": "f32" if w == 4 else "f64", "data": "synthetic",
             "config": {"workload": "%s: %s" % (cfg["name"], cfg["description"]), "nodes": N, "actions": A,
                        "cells_per_sweep": N * A, "dt": g.dt, "alpha": 1.0,
-                       "parallelism": "axis-0 slabs x%d, halo %d rows, %s" % (world, vi.halo, "p2p send/recv" if vi.p2p else "all-gather")},
+                       "parallelism": "axis-0 slabs x%d, halo %d rows, %s%s" % (
+                           world, vi.halo, "p2p send/recv" if vi.p2p else "all-gather",
+                           ", exchange overlapped with the interior kernel" if vi.overlap else "")},
             "sweeps_per_sec": steps / dt,
             "roofline": {"bound": "hbm", "achieved": alg * steps / dt / 1e9, "peak": 8000.0 * world, "unit": "GB/s",
                          "frac": alg * steps / dt / 1e9 / (8000.0 * world), "traffic": None,

@@ -701,25 +701,31 @@ import torch.distributed as dist
 sys.path.insert(0, %r)
 from pyro_amd import configs, parallel
 rank, out = int(sys.argv[1]), sys.argv[2]
-dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d", rank=rank, world_size=2)
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d", rank=rank, world_size=%d)
 with contextlib.redirect_stdout(io.StringIO()):
     cfg = configs.build("%s")
-vi = parallel.ShardedValueIteration(cfg["grid_sys"], cfg["cf"], dist, dtype="float32", device=0)
+vi = parallel.ShardedValueIteration(cfg["grid_sys"], cfg["cf"], dist, dtype="float32", device=0, overlap=%s)
 stats = [vi.sweep(1.0) for _ in range(4)]
 last = vi.run(3, 1.0, -1.0)
 J, pi = vi.gather()
 if rank == 0:
     np.savez(out, J=J, pi=pi, stats=np.array(stats + [last]), p2p=vi.p2p, halo=vi.halo)
+np.save(out + ".pieces%%d.npy" %% rank, len(vi.slab.handles))
 dist.destroy_process_group()
 print("WORLD2-OK", rank)
 """
 
 
-@pytest.mark.parametrize("case", ["cartpole:21,21,21,21:7:float32", "pendulum:101,101:11:float32"])
-def test_two_ranks_share_one_gpu(tmp_path, case):
+@pytest.mark.parametrize("case,world,overlap", [("cartpole:21,21,21,21:7:float32", 2, True),
+                                                ("cartpole:21,21,21,21:7:float32", 2, False),
+                                                ("pendulum:101,101:11:float32", 2, True),
+                                                ("cartpole:21,21,21,21:7:float32", 3, True)])
+def test_two_ranks_share_one_gpu(tmp_path, case, world, overlap):
     """The sharded driver with the product HipSlab on real hardware: two processes (both on GPU 0), halo rows moved
     by a gloo process group through host staging, statistics all-reduced -- must equal the single-handle result
-    bit for bit (same kernels, same arithmetic per node).  RCCL itself is the only part not exercised here."""
+    bit for bit (same kernels, same arithmetic per node).  overlap=True is the boundary-first schedule: separate
+    handles for the rows next to the neighbour and for the interior over the same buffers, the exchange on a second
+    stream while the interior kernel runs.  RCCL itself is the only part not exercised here."""
     import socket
     import subprocess
     import sys
@@ -728,9 +734,9 @@ def test_two_ranks_share_one_gpu(tmp_path, case):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "res.npz")
-    code = _WORLD2 % (ROOT, port, case)
+    code = _WORLD2 % (ROOT, port, world, case, overlap)
     procs = [subprocess.Popen([sys.executable, "-c", code, str(r), out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-             for r in range(2)]
+             for r in range(world)]
     logs = [p.communicate(timeout=900)[0] for p in procs]
     assert all("WORLD2-OK" in l for l in logs), "\n".join(l[-1500:] for l in logs)
     r = np.load(out)
@@ -744,6 +750,8 @@ def test_two_ranks_share_one_gpu(tmp_path, case):
     np.testing.assert_allclose(r["stats"][:4], stats[:4], rtol=1e-12)
     np.testing.assert_allclose(r["stats"][4], stats[6], rtol=1e-12)
     assert bool(r["p2p"])
+    pieces = [int(np.load(out + ".pieces%d.npy" % k)) for k in range(world)]
+    assert pieces == ([1] * world if not overlap else [2] + [3] * (world - 2) + [2])
 
 
 # ------------------------------------------------------------------------------- bicubic-spline class
