@@ -1675,6 +1675,7 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
     L.nty = (L.V0 + tv0 - 1) / tv0;
     L.TV0 = (L.V0 + L.nty - 1) / L.nty;
     L.tv1_magic = ((1 << 20) + L.TV1 - 1) / L.TV1;
+    L.half = L.npt == 2 ? ((L.TV0 + 1) / 2) * L.TV1 : L.TV0 * L.TV1;
     L.posdim1 = DOF == 2 ? P.dim[1] : 1;
     L.pd_magic = magic32((unsigned)L.posdim1);
     L.vplane = (long long)L.V0 * L.V1;
@@ -1796,14 +1797,19 @@ static int lean_setup(pvi_problem* h) {
         shapes[ns][0] = std::max(1, spb / 32); shapes[ns++][1] = 32;
         shapes[ns][0] = std::max(1, spb / 16); shapes[ns++][1] = 16;
     }
+    // two nodes per thread (2-D, uniform action walk; tiles twice as tall for the same workgroup size) halve the
+    // per-wave fixed work and fit 1001^2 into one round of resident waves (A = 1: 21 -> 15 us), but the two
+    // register-resident node contexts cost the action loop more than that (C2 43.7 -> 49 us at 71 VGPRs / 7 waves,
+    // 55 us squeezed to 63 VGPRs): opt-in for experiments, PVI_NPT=2
+    L.npt = (DOF == 1 && ls == 0 && getenv("PVI_NPT") && atoi(getenv("PVI_NPT")) == 2) ? 2 : 1;
     for (int k = 0; k < ns; ++k) {
-        rc = lean_try(h, shapes[k][0], shapes[k][1], budget);
+        rc = lean_try(h, shapes[k][0] * L.npt, shapes[k][1], budget);
         if (rc < 0) return rc;
         if (rc == 2) break;
         if (rc == 0) {
-            const int threads = ((L.TV0 * L.TV1) << L.lsplit);
+            const int threads = L.npt == 2 ? L.half : ((L.TV0 * L.TV1) << L.lsplit);
             h->lean_block = ((threads + 63) / 64) * 64;
-            if (h->lean_block > 512) continue;
+            if (h->lean_block > (L.npt == 2 ? 256 : 512)) continue;
             h->lean_ok = true;
             h->lean_lds_attr = false;
             if (L.tb_tile) {  // tB lives per tile: the per-node copy is not needed any more
@@ -2328,9 +2334,9 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         if (h->lean_ok) {
             const float al = (float)alpha;
             sc.nblocks = h->lean_grid.x;
-#define LEAN3(DYN, U)                                                                                               \
+#define LEAN3(DYN, U, NP)                                                                                           \
     {                                                                                                               \
-        auto kfn = k_sweep_lean<DYN, PI_T, U>;                                                                      \
+        auto kfn = k_sweep_lean<DYN, PI_T, U, NP>;                                                                  \
         if (!h->lean_lds_attr && h->lean_lds > 48 * 1024) {                                                         \
             HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lean_lds)); \
             h->lean_lds_attr = true;                                                                                \
@@ -2340,11 +2346,16 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     }
 #define LEAN(DYN)              \
     if (h->LP.lsplit == 0)     \
-        LEAN3(DYN, true)       \
+        LEAN3(DYN, true, 1)    \
     else                       \
-        LEAN3(DYN, false)
+        LEAN3(DYN, false, 1)
             switch (h->d.dynamics_id) {
-                case PVI_DYN_PENDULUM: LEAN(PVI_DYN_PENDULUM) break;
+                case PVI_DYN_PENDULUM:
+                    if (h->LP.npt == 2)
+                        LEAN3(PVI_DYN_PENDULUM, true, 2)
+                    else
+                        LEAN(PVI_DYN_PENDULUM)
+                    break;
                 case PVI_DYN_CARTPOLE: LEAN(PVI_DYN_CARTPOLE) break;
                 default: LEAN(PVI_DYN_TWOLINK) break;
             }
