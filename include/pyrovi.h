@@ -45,6 +45,15 @@ extern "C" {
 #define PVI_DYN_PENDULUM 1  /* pyro/dynamic/pendulum.py:16 SinglePendulum, :283 InvertedPendulum */
 #define PVI_DYN_CARTPOLE 2  /* pyro/dynamic/cartpole.py:322 CartPole */
 #define PVI_DYN_TWOLINK 3   /* pyro/dynamic/manipulator.py:795 TwoLinkManipulator, pendulum.py:340 DoublePendulum */
+/* Any MechanicalSystem (mechanical.py:222-263: ddq = inv(H)(B u - C dq - g - d), x = [q; dq]) through per-node tables
+   evaluated once by the host -- O(N) calls of the system's own H, C, B, g, d instead of the O(N*A) of the look-up
+   tables: the acceleration is affine in u,  ddq = a0(q, dq) + Bn(q) u  with
+     trig[0] = a0 = inv(H)(-C dq - g - d)   [all grid nodes, C order][dof]
+     trig[1] = Bn = inv(H) B                [position nodes, C order][dof][m]
+   (float64).  dyn_params is unused.  NODE_dxm: dof = d, m inputs. */
+#define PVI_DYN_NODE_1x1 4  /* e.g. pyro/dynamic/mountaincar.py:22 MountainCar */
+#define PVI_DYN_NODE_2x1 5  /* e.g. pendulum.py Acrobot (dof 2, one actuator) */
+#define PVI_DYN_NODE_2x2 6
 
 /* cost evaluated in-kernel */
 #define PVI_COST_TABLE 0      /* G supplied by the host */

@@ -13,6 +13,7 @@ import numpy as np
 PVI_MAX_N, PVI_MAX_M, PVI_MAX_TRIG = 4, 2, 4
 PVI_F32, PVI_F64 = 0, 1
 DYN_TABLE, DYN_PENDULUM, DYN_CARTPOLE, DYN_TWOLINK = 0, 1, 2, 3
+DYN_NODE_1x1, DYN_NODE_2x1, DYN_NODE_2x2 = 4, 5, 6        # any MechanicalSystem through per-node tables
 COST_TABLE, COST_QUADRATIC = 0, 1
 INTERP_LINEAR, INTERP_BICUBIC_SPLINE = 0, 1
 PVI_EHALO = -5
@@ -159,6 +160,7 @@ class Problem:
             raise ValueError("dtype must be float32 or float64")
         d.dtype = PVI_F64 if self.dtype == np.dtype("float64") else PVI_F32
         d.dynamics_id = int(dynamics_id)
+        self.dynamics_id = int(dynamics_id)
         for i, v in enumerate(dyn_params):
             d.dyn_params[i] = float(v)
         for i, t in enumerate(trig):

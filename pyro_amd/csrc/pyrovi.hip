@@ -217,6 +217,56 @@ struct Dyn<PVI_DYN_TWOLINK> {
     }
 };
 
+// Any mechanical system through per-node tables (include/pyrovi.h PVI_DYN_NODE_*): ddq = a0(q, dq) + Bn(q) u with
+// a0 = inv(H)(-C dq - g - d) per grid node and Bn = inv(H) B per position node, evaluated by the host with the
+// system's own H, C, B, g, d (mechanical.py:222-234).  tr[0:DOF] = a0, tr[DOF:] = Bn (row major).
+template <int DOF_, int M_>
+struct DynNode {
+    static constexpr int DOF = DOF_, M = M_;
+    double a0[DOF], Bn[DOF][M];
+    __device__ void init(const double*, const double*, const double* tr) {
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) {
+            a0[i] = tr[i];
+#pragma unroll
+            for (int k = 0; k < M; ++k) Bn[i][k] = tr[DOF + i * M + k];
+        }
+    }
+    __device__ static void trig_from_tables(const DevP& P, const int* idx, double* tr) {
+        long long node = idx[0], pos = idx[0];
+#pragma unroll
+        for (int d = 1; d < 2 * DOF; ++d) node = node * P.dim[d] + idx[d];
+#pragma unroll
+        for (int d = 1; d < DOF; ++d) pos = pos * P.dim[d] + idx[d];
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) tr[i] = P.trig[0][node * DOF + i];
+#pragma unroll
+        for (int j = 0; j < DOF * M; ++j) tr[DOF + j] = P.trig[1][pos * (DOF * M) + j];
+    }
+    __device__ void accel(const double* u, double* a) const {
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) {
+            double s = Bn[i][0] * u[0];
+            if (M == 2) s = s + Bn[i][M - 1] * u[M - 1];
+            a[i] = a0[i] + s;
+        }
+    }
+    __device__ void affine(double* a, double (*B)[M]) const {
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) {
+            a[i] = a0[i];
+#pragma unroll
+            for (int k = 0; k < M; ++k) B[i][k] = Bn[i][k];
+        }
+    }
+};
+template <>
+struct Dyn<PVI_DYN_NODE_1x1> : DynNode<1, 1> {};
+template <>
+struct Dyn<PVI_DYN_NODE_2x1> : DynNode<2, 1> {};
+template <>
+struct Dyn<PVI_DYN_NODE_2x2> : DynNode<2, 2> {};
+
 // =================================================================================================
 // cost (costfunction.py:151-204): rows of M.dx first, then the outer dot, all left to right
 // =================================================================================================
@@ -597,7 +647,7 @@ __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ 
         }
         if (halo_bad) atomicOr(&sc.ctrl->halo_err, 1);
 
-        double tr[4];
+        double tr[8];
         D::trig_from_tables(P, idx, tr);
         D dyn;
         dyn.init(P.c, x, tr);
@@ -747,7 +797,7 @@ __global__ __launch_bounds__(256) void k_sweep_fast(DevP P, FastP F, const float
             bp[c] = b;
             wp[c] = w;
         }
-        double tr[4], a64[DOF], B64[DOF][M];
+        double tr[8], a64[DOF], B64[DOF][M];
         D::trig_from_tables(P, idx, tr);
         D dyn;
         dyn.init(P.c, x, tr);
@@ -782,7 +832,7 @@ __global__ __launch_bounds__(256) void k_sweep_fast(DevP P, FastP F, const float
             bool inb = pos_in && (m >= 0.f);
             if (pos_in && fabsf(m) < F.guard) {
                 // rare: within the guard band of a bound -> exact float64 classification
-                double x[N], tr[4], u[M], acc[DOF];
+                double x[N], tr[8], u[M], acc[DOF];
 #pragma unroll
                 for (int d = 0; d < N; ++d) x[d] = P.lev[d][idx[d]];
                 D::trig_from_tables(P, idx, tr);
@@ -903,7 +953,7 @@ __device__ __forceinline__ void run_actions(const DevP& P, const float4* __restr
     double x[N];
     D dyn;
     if (EXACT) {
-        double tr[4];
+        double tr[8];
 #pragma unroll
         for (int d = 0; d < N; ++d) x[d] = P.lev[d][idx[d]];
         D::trig_from_tables(P, idx, tr);
@@ -1060,7 +1110,7 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(DevP P, TileP F, const floa
             for (int i = 0; i < DOF; ++i) w *= ((c >> (DOF - 1 - i)) & 1) ? yp[i] : (1.f - yp[i]);
             L.wp[c] = w;
         }
-        double tr[4], a64[DOF], B64[DOF][M];
+        double tr[8], a64[DOF], B64[DOF][M];
         D::trig_from_tables(P, idx, tr);
         D dyn;
         dyn.init(P.c, x, tr);
@@ -1383,7 +1433,7 @@ __global__ void k_build_tables(DevP P, long long node0, long long nnodes, double
     Q.row_begin = 0;
     int idx[N];
     decode_node<N>(Q, node0 + ln, idx);
-    double x[N], dx[N], tr[4], u[M], acc[DOF];
+    double x[N], dx[N], tr[8], u[M], acc[DOF];
 #pragma unroll
     for (int d = 0; d < N; ++d) {
         x[d] = P.lev[d][idx[d]];
@@ -1425,7 +1475,7 @@ __global__ void k_eval_f(const double* __restrict__ c16, long long B, const doub
     constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M;
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    double c[16], x[N], u[M], tr[4], acc[DOF];
+    double c[16], x[N], u[M], tr[8], acc[DOF];
 #pragma unroll
     for (int i = 0; i < 16; ++i) c[i] = c16[i];
 #pragma unroll
@@ -1506,7 +1556,7 @@ __global__ void k_rollout(DevP P, const PI_T* __restrict__ pi, long long B, cons
             for (int k = 0; k < M; ++k) Ut[(b * npts + i) * M + k] = u[k];
         }
         if (i + 1 < npts) {
-            double tr[4], acc[DOF], xn[N];
+            double tr[8], acc[DOF], xn[N];
             D::trig_from_state(x, tr);
             D dyn;
             dyn.init(P.c, x, tr);
@@ -1710,6 +1760,15 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
         case PVI_DYN_CARTPOLE:
             hipLaunchKernelGGL((k_lean_setup<PVI_DYN_CARTPOLE>), h->lean_grid, sthreads, 0, h->stream, P, L, h->F.act);
             break;
+        case PVI_DYN_NODE_1x1:
+            hipLaunchKernelGGL((k_lean_setup<PVI_DYN_NODE_1x1>), h->lean_grid, sthreads, 0, h->stream, P, L, h->F.act);
+            break;
+        case PVI_DYN_NODE_2x1:
+            hipLaunchKernelGGL((k_lean_setup<PVI_DYN_NODE_2x1>), h->lean_grid, sthreads, 0, h->stream, P, L, h->F.act);
+            break;
+        case PVI_DYN_NODE_2x2:
+            hipLaunchKernelGGL((k_lean_setup<PVI_DYN_NODE_2x2>), h->lean_grid, sthreads, 0, h->stream, P, L, h->F.act);
+            break;
         default:
             hipLaunchKernelGGL((k_lean_setup<PVI_DYN_TWOLINK>), h->lean_grid, sthreads, 0, h->stream, P, L, h->F.act);
             break;
@@ -1861,11 +1920,16 @@ extern "C" int pvi_device_count(int* count) {
     return PVI_OK;
 }
 
+static inline bool is_node_dyn(int dyn) { return dyn >= PVI_DYN_NODE_1x1 && dyn <= PVI_DYN_NODE_2x2; }
+
 static int dyn_shape(int dyn, int* n, int* m) {
     switch (dyn) {
         case PVI_DYN_PENDULUM: *n = 2; *m = 1; return 0;
         case PVI_DYN_CARTPOLE: *n = 4; *m = 1; return 0;
         case PVI_DYN_TWOLINK: *n = 4; *m = 2; return 0;
+        case PVI_DYN_NODE_1x1: *n = 2; *m = 1; return 0;
+        case PVI_DYN_NODE_2x1: *n = 4; *m = 1; return 0;
+        case PVI_DYN_NODE_2x2: *n = 4; *m = 2; return 0;
     }
     return -1;
 }
@@ -2036,7 +2100,7 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
             box_is_grid = box_is_grid && d->x_lb[i] == P.glo[i] && d->x_ub[i] == P.ghi[i];
         h->fast_ok = d->dtype == PVI_F32 && d->dynamics_id != PVI_DYN_TABLE && box_is_grid &&
                      h->stored < 0x7fffffffLL && !getenv("PVI_NO_FAST");
-        h->tile_ok = h->fast_ok && !getenv("PVI_NO_TILE");
+        h->tile_ok = h->fast_ok && !getenv("PVI_NO_TILE") && !is_node_dyn(d->dynamics_id);
         h->T.guard = h->F.guard;
         h->T.lsplit = ls;
         // LDS window budget / workgroup size: 2-D windows are small (4 workgroups per CU); 4-D windows
@@ -2073,6 +2137,14 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
                 for (int j = 0; j < d->x_dim[1]; ++j)
                     t[(size_t)i * d->x_dim[1] + j] = std::sin(d->x_level[0][i] + d->x_level[1][j]);
         if ((rc = dev_upload(h, t.data(), t.size(), &P.trig[3]))) return bail(rc);
+    } else if (is_node_dyn(d->dynamics_id)) {
+        if (!d->trig[0] || !d->trig[1]) return bail(fail(PVI_EINVAL, "PVI_DYN_NODE_* needs the a0 / Bn tables in trig[0], trig[1]"));
+        const int dof = d->n / 2;
+        size_t nodes = 1, pos = 1;
+        for (int i = 0; i < d->n; ++i) nodes *= (size_t)d->x_dim[i];
+        for (int i = 0; i < dof; ++i) pos *= (size_t)d->x_dim[i];
+        if ((rc = dev_upload(h, d->trig[0], nodes * dof, &P.trig[0]))) return bail(rc);
+        if ((rc = dev_upload(h, d->trig[1], pos * dof * d->m, &P.trig[1]))) return bail(rc);
     }
 
     const size_t esz = d->dtype == PVI_F64 ? 8 : 4;
@@ -2128,7 +2200,8 @@ extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
                        : h->march_ok ? "march"
                        : h->lean_ok ? "lean"
                        : h->tile_ok ? "tile"
-                       : h->fast_ok ? "fast" : (h->d.dynamics_id == PVI_DYN_TABLE ? "table" : "exact-f32");
+                       : (h->fast_ok && !is_node_dyn(h->d.dynamics_id)) ? "fast"
+                       : (h->d.dynamics_id == PVI_DYN_TABLE ? "table" : "exact-f32");
     snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d note=%s", path,
              h->LP.TV0, h->LP.TV1, h->lean_grid.x, h->lean_grid.y, h->lean_grid.z, h->lean_block, h->lean_pw1,
              h->lean_lds, h->lean_ok ? h->LP.lsplit : h->F.lsplit, h->LP.tb_tile, h->lean_why);
@@ -2357,6 +2430,9 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
                         LEAN(PVI_DYN_PENDULUM)
                     break;
                 case PVI_DYN_CARTPOLE: LEAN(PVI_DYN_CARTPOLE) break;
+                case PVI_DYN_NODE_1x1: LEAN(PVI_DYN_NODE_1x1) break;
+                case PVI_DYN_NODE_2x1: LEAN(PVI_DYN_NODE_2x1) break;
+                case PVI_DYN_NODE_2x2: LEAN(PVI_DYN_NODE_2x2) break;
                 default: LEAN(PVI_DYN_TWOLINK) break;
             }
 #undef LEAN
@@ -2386,7 +2462,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             HIPCHK(hipGetLastError());
             return PVI_OK;
         }
-        if (h->fast_ok) {
+        if (h->fast_ok && !is_node_dyn(h->d.dynamics_id)) {
             const unsigned gf = grid_for(h->owned << h->F.lsplit);
             const float al = (float)alpha;
             sc.nblocks = gf;
@@ -2420,6 +2496,9 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         case PVI_DYN_PENDULUM: EXACT(PVI_DYN_PENDULUM) break;
         case PVI_DYN_CARTPOLE: EXACT(PVI_DYN_CARTPOLE) break;
         case PVI_DYN_TWOLINK: EXACT(PVI_DYN_TWOLINK) break;
+        case PVI_DYN_NODE_1x1: EXACT(PVI_DYN_NODE_1x1) break;
+        case PVI_DYN_NODE_2x1: EXACT(PVI_DYN_NODE_2x1) break;
+        case PVI_DYN_NODE_2x2: EXACT(PVI_DYN_NODE_2x2) break;
         case PVI_DYN_TABLE:
             if (!h->d_xnext || !h->d_G) return fail(PVI_ESTATE, "tier B sweep before pvi_set_tables");
             {
@@ -2727,6 +2806,18 @@ extern "C" int pvi_build_tables(pvi_handle h, int32_t row0, int32_t nrows, doubl
                 hipLaunchKernelGGL((k_build_tables<PVI_DYN_CARTPOLE>), g, 256, 0, h->stream, h->P, node0 + s, c, dx, dxo,
                                    dao, dG);
                 break;
+            case PVI_DYN_NODE_1x1:
+                hipLaunchKernelGGL((k_build_tables<PVI_DYN_NODE_1x1>), g, 256, 0, h->stream, h->P, node0 + s, c, dx, dxo,
+                                   dao, dG);
+                break;
+            case PVI_DYN_NODE_2x1:
+                hipLaunchKernelGGL((k_build_tables<PVI_DYN_NODE_2x1>), g, 256, 0, h->stream, h->P, node0 + s, c, dx, dxo,
+                                   dao, dG);
+                break;
+            case PVI_DYN_NODE_2x2:
+                hipLaunchKernelGGL((k_build_tables<PVI_DYN_NODE_2x2>), g, 256, 0, h->stream, h->P, node0 + s, c, dx, dxo,
+                                   dao, dG);
+                break;
             default:
                 hipLaunchKernelGGL((k_build_tables<PVI_DYN_TWOLINK>), g, 256, 0, h->stream, h->P, node0 + s, c, dx, dxo,
                                    dao, dG);
@@ -2805,7 +2896,8 @@ extern "C" int pvi_set_pi(pvi_handle h, const int64_t* pr, int32_t row0, int32_t
 extern "C" int pvi_rollout(pvi_handle h, int64_t B, const double* X0, int32_t npts, double dt, double* X_traj,
                            double* U_traj, double* X_end) {
     if (!h || !X0) return fail(PVI_EINVAL, "NULL argument");
-    if (h->d.dynamics_id == PVI_DYN_TABLE) return fail(PVI_ESTATE, "rollouts need in-kernel dynamics");
+    if (h->d.dynamics_id == PVI_DYN_TABLE || is_node_dyn(h->d.dynamics_id))
+        return fail(PVI_ESTATE, "rollouts need closed-form in-kernel dynamics (the node tables only cover the grid nodes)");
     if (h->P.store_begin != 0 || h->P.store_end != h->P.dim[0] || h->P.row_begin != 0 || h->P.row_end != h->P.dim[0])
         return fail(PVI_ESTATE, "rollouts need a whole-grid handle");
     if (B <= 0 || npts < 1) return PVI_OK;
@@ -2851,7 +2943,7 @@ extern "C" int pvi_eval_f(int32_t dyn, const double* params, int32_t n, int32_t 
                           const double* U, double* dX) {
     if (!params || !X || !U || !dX) return fail(PVI_EINVAL, "NULL argument");
     int en, em;
-    if (dyn_shape(dyn, &en, &em)) return fail(PVI_EINVAL, "unknown dynamics_id %d", dyn);
+    if (dyn_shape(dyn, &en, &em) || is_node_dyn(dyn)) return fail(PVI_EINVAL, "no closed-form dynamics with id %d", dyn);
     if (en != n || em != m) return fail(PVI_EINVAL, "dynamics %d needs n=%d m=%d", dyn, en, em);
     if (B <= 0) return PVI_OK;
     double *dc = nullptr, *dXd = nullptr, *dU = nullptr, *dO = nullptr;

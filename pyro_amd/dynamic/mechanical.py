@@ -69,3 +69,41 @@ class MechanicalSystem(system.ContinuousDynamicSystem):
 
     def kinetic_energy(self, q, dq):
         return 0.5 * dq @ (self.H(q) @ dq)
+
+    # ---- in-kernel evaluation of ANY mechanical system (include/pyrovi.h PVI_DYN_NODE_*) --------------------
+    # ddq is affine in u:  ddq = a0(q, dq) + Bn(q) u,  a0 = ddq(q, dq, 0),  Bn = inv(H) B.  The two tables cost
+    # O(N) evaluations of the model terms (the reference's look-up tables cost O(N*A) calls of f); the sweeps then
+    # run in the fused kernels like the closed-form systems.  Subclasses with closed-form kernels override both.
+    _NODE_IDS = {(1, 1): 4, (2, 1): 5, (2, 2): 6}          # _native.DYN_NODE_1x1 / 2x1 / 2x2
+
+    def device_dynamics(self):
+        key = (self.dof, self.m)
+        if type(self).f is not MechanicalSystem.f or key not in self._NODE_IDS or self.n != 2 * self.dof:
+            return None
+        # the u-dependence must be exactly B(q) u (a subclass may have redefined ddq): spot check
+        rng = np.random.default_rng(0)
+        for _ in range(3):
+            x = rng.uniform(self.x_lb, self.x_ub)
+            u = rng.uniform(self.u_lb, self.u_ub)
+            q, dq = self.x2q(x)
+            lin = self.ddq(q, dq, np.zeros(self.m)) + np.linalg.inv(self.H(q)) @ (self.B(q) @ u)
+            if not np.allclose(self.ddq(q, dq, u), lin, rtol=1e-10, atol=1e-12):
+                return None
+        return self._NODE_IDS[key], ()
+
+    def device_trig(self, x_level):
+        """(a0 [N, dof], Bn [Nq, dof, m]) over the grid levels, C order (last axis fastest)."""
+        dof, m = self.dof, self.m
+        qdims = [len(l) for l in x_level[:dof]]
+        vdims = [len(l) for l in x_level[dof:]]
+        nq, nv = int(np.prod(qdims)), int(np.prod(vdims))
+        a0 = np.empty((nq, nv, dof))
+        Bn = np.empty((nq, dof, m))
+        zero = np.zeros(m)
+        for iq, qi in enumerate(np.ndindex(*qdims)):
+            q = np.array([x_level[k][qi[k]] for k in range(dof)])
+            Bn[iq] = np.linalg.inv(self.H(q)) @ self.B(q)
+            for iv, vi in enumerate(np.ndindex(*vdims)):
+                dq = np.array([x_level[dof + k][vi[k]] for k in range(dof)])
+                a0[iq, iv] = self.ddq(q, dq, zero)
+        return a0.reshape(nq * nv, dof), Bn

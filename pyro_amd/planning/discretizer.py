@@ -117,7 +117,14 @@ class GridDynamicSystem:
             dyn_id, params, trig = _native.DYN_TABLE, (), ()
         else:
             dyn_id, params = dd
-            trig = s.device_trig(self.x_level)
+            if "_trig" not in self.__dict__:        # (per-node tables of generic mechanical systems are O(N) Python)
+                if dyn_id >= _native.DYN_NODE_1x1:
+                    t0 = time.time()
+                    print("Computing per-node dynamics tables..  ", end="")
+                self.__dict__["_trig"] = s.device_trig(self.x_level)
+                if dyn_id >= _native.DYN_NODE_1x1:
+                    print("completed in %4.2f sec" % (time.time() - t0))
+            trig = self.__dict__["_trig"]
         if dyn_id != _native.DYN_TABLE and cost is None:
             cost = _null_cost(s.n, s.m)
         return _native.Problem(self.x_level, self.u_level, s.x_lb, s.x_ub, s.u_lb, s.u_ub, self.dt, dtype=dtype,

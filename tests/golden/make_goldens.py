@@ -481,7 +481,40 @@ def case_spline():
     save("spline_pendulum", **out)
 
 
-CASES = dict(spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
+def case_mountaincar():
+    """MountainCar (mountaincar.py:22) as in mountain_car_with_valueiteration_quadratic.py, reduced to 41x41x5:
+    a Manipulator with position-dependent H, C, B, g -- the generic mechanical tier (per-node tables)."""
+    from pyro.dynamic import mountaincar
+    with quiet():
+        s = mountaincar.MountainCar()
+        s.x_ub = np.array([+0.2, +2.0]); s.x_lb = np.array([-1.7, -2.0])
+        s.u_ub[0] = +0.2; s.u_lb[0] = -0.2
+        g = discretizer.GridDynamicSystem(s, [41, 41], [5])
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+        q.xbar = np.array([0.0, 0.0]); q.INF = 30
+        q.R[0, 0] = 10.0; q.S[0, 0] = 10.0; q.S[1, 1] = 10.0
+        out = _meta(s, g, q)
+        rng = np.random.default_rng(4)
+        X = rng.uniform(s.x_lb, s.x_ub, size=(64, 2)); U = rng.uniform(s.u_lb, s.u_ub, size=(64, 1))
+        out.update(f_X=X, f_U=U, f_dX=np.array([s.f(X[i], U[i]) for i in range(64)]))
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, q)
+        dp.save_time_history = False
+        out.update(x_next_table=g.x_next_table, x_next_isok=g.x_next_isok, G=dp.G, J0=dp.J.copy())
+        stats = []
+        for k in range(1, 21):
+            dp.initialize_backward_step(); dp.compute_backward_step()
+            delta = dp.finalize_backward_step()
+            d = dp.J - dp.J_next
+            stats.append([dp.J.max(), d.max(), d.min(), delta])
+            if k in (1, 5, 20):
+                out["J_%d" % k] = dp.J.copy(); out["pi_%d" % k] = dp.pi.copy()
+                Q = np.sort(dp.Q, axis=1)
+                out["gap_%d" % k] = Q[:, 1] - Q[:, 0]
+        out["stats"] = np.array(stats)
+    save("mountaincar_41x41x5", **out)
+
+
+CASES = dict(mountaincar=case_mountaincar, spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
              policy_eval=case_policy_eval, cost_kat=case_cost_kat, grid_kat=case_grid_kat,
              pendulum_small=case_pendulum_small, config1=case_config1, lowdef=case_lowdef,
              pendulum_demo=case_pendulum_demo, cartpole_small=case_cartpole_small,

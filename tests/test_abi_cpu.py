@@ -167,3 +167,41 @@ def test_grid_plot_passthroughs():
     assert np.array_equal(g4.get_2D_slice_of_grid(Z, 3, 1), Z[idx[0], :, idx[2], :].T)
     import matplotlib.pyplot as plt
     plt.close("all")
+
+
+# ------------------------------------------------------------------ generic mechanical systems (per-node tables)
+def test_mountaincar_mirror_and_node_tables_match_reference_golden():
+    """pyro/dynamic/mountaincar.py MountainCar: f bit for bit, and the affine tables (a0, Bn) of the generic mechanical
+    tier reproduce the reference's x_next_table to rounding."""
+    from pyro_amd import _native
+    from pyro_amd.dynamic import mountaincar
+    g = np.load(os.path.join(GOLDEN, "mountaincar_41x41x5.npz"))
+    s = mountaincar.MountainCar()
+    dX = np.array([s.f(x, u) for x, u in zip(g["f_X"], g["f_U"])])
+    assert np.array_equal(dX, g["f_dX"])
+    assert s.device_dynamics() == (_native.DYN_NODE_1x1, ())
+    s.x_ub, s.x_lb, s.u_ub, s.u_lb = g["x_ub"], g["x_lb"], g["u_ub"], g["u_lb"]
+    lev = [np.linspace(g["x_lb"][i], g["x_ub"][i], 41) for i in range(2)]
+    ul = np.linspace(g["u_lb"][0], g["u_ub"][0], 5)
+    a0, Bn = s.device_trig(lev)
+    assert a0.shape == (41 * 41, 1) and Bn.shape == (41, 1, 1)
+    acc = a0[:, 0][:, None] + Bn.reshape(41)[np.arange(41 * 41) // 41][:, None] * ul[None, :]
+    X1 = np.tile(lev[1], 41)
+    assert np.abs(acc * 0.05 + X1[:, None] - g["x_next_table"][:, :, 1]).max() < 1e-14
+
+
+def test_node_tier_is_refused_when_ddq_is_not_affine_in_u():
+    from pyro_amd.dynamic import mechanical
+
+    class Saturating(mechanical.MechanicalSystem):
+        def ddq(self, q, dq, u, t=0):
+            return np.tanh(u) - dq
+
+    class Plain(mechanical.MechanicalSystem):
+        def g(self, q):
+            return 3.0 * np.sin(q)
+
+    assert Saturating(1).device_dynamics() is None
+    assert Plain(1).device_dynamics() is not None and Plain(2).device_dynamics() is not None
+    assert Plain(2, actuators=1).device_dynamics() is not None
+    assert mechanical.MechanicalSystem(3).device_dynamics() is None

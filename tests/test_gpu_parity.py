@@ -864,3 +864,107 @@ def test_spline_mode_errors_and_class_surface():
     dp._p.terminal_cost()
     dp._p.sweep(1, 1.0, -1.0)
     assert relerr(dp._p.get_J(), g0["J_1"]) < 1e-14
+
+
+# ------------------------------------------------------------------------------- generic mechanical tier
+def _mountaincar_dp(g, dtype, cls=None):
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import mountaincar
+    from pyro_amd.planning import discretizer, dynamicprogramming
+    s = mountaincar.MountainCar()
+    s.x_ub, s.x_lb = np.array([+0.2, +2.0]), np.array([-1.7, -2.0])
+    s.u_ub[0], s.u_lb[0] = +0.2, -0.2
+    grid = discretizer.GridDynamicSystem(s, [41, 41], [5])
+    q = costfunction.QuadraticCostFunction.from_sys(s)
+    q.xbar = np.array([0.0, 0.0]); q.INF = 30
+    q.R[0, 0] = 10.0; q.S[0, 0] = 10.0; q.S[1, 1] = 10.0
+    dp = (cls or dynamicprogramming.DynamicProgrammingWithLookUpTable)(grid, q, dtype=dtype)
+    dp.save_time_history = False
+    return dp
+
+
+@pytest.mark.gpu
+def test_mountaincar_runs_fused_through_node_tables_and_matches_reference():
+    """mountain_car_with_valueiteration_quadratic.py at 41x41x5: a Manipulator with position-dependent H, C, B, g.
+    The classes pick the fused tier (per-node a0 / Bn tables, O(N) host work) and reproduce the reference's J after
+    1, 5, 20 sweeps; float64 to 1e-12 (the affine form rounds x_next differently by <= 1 ulp), float32 to 1e-5."""
+    g = load("mountaincar_41x41x5")
+    for dtype, tol in (("float64", 1e-12), ("float32", REL_F32)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            dp = _mountaincar_dp(g, dtype)
+            assert dp.tier == "fused"
+            assert ("exact-f64" if dtype == "float64" else "lean") in dp._p.describe()
+            if dtype == "float64":
+                assert np.abs(dp.grid_sys.x_next_table - g["x_next_table"]).max() < 1e-14
+                assert np.array_equal(dp.grid_sys.x_next_isok, g["x_next_isok"])
+                assert relerr(dp.G, g["G"]) < 1e-14
+            done = 0
+            for k in (1, 5, 20):
+                dp.compute_steps(k - done)
+                done = k
+                assert relerr(dp.J, g["J_%d" % k]) < tol, (dtype, k)
+                clear = g["gap_%d" % k] > (1e-9 if dtype == "float64" else 1e-3)
+                assert np.array_equal(dp.pi[clear], g["pi_%d" % k][clear])
+        if dtype == "float64":
+            assert np.allclose([dp.J.max()], g["stats"][19][0], rtol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dof,act", [(1, 1), (2, 1), (2, 2)])
+def test_generic_mechanical_systems_node_tier_equals_table_tier(dof, act):
+    """Any MechanicalSystem subclass: the node tier (PVI_DYN_NODE_1x1 / 2x1 / 2x2) against the table tier built from the
+    same system's f by the reference's loops -- float64 J within 1e-11, float32 (lean kernel) within 1e-5."""
+    from pyro_amd import _native
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import mechanical
+    from pyro_amd.planning import discretizer, dynamicprogramming
+
+    class Robot(mechanical.MechanicalSystem):        # configuration-dependent inertia, Coriolis, gravity, damping
+        def H(self, q):
+            if self.dof == 1:
+                return np.array([[1.5 + 0.5 * np.cos(q[0])]])
+            return np.array([[2.0 + 0.6 * np.cos(q[1]), 0.4 + 0.3 * np.cos(q[1])], [0.4 + 0.3 * np.cos(q[1]), 0.9]])
+
+        def C(self, q, dq):
+            if self.dof == 1:
+                return np.array([[-0.25 * np.sin(q[0]) * dq[0]]])
+            h = 0.3 * np.sin(q[1])
+            return np.array([[-h * dq[1], -h * (dq[0] + dq[1])], [h * dq[0], 0.0]])
+
+        def g(self, q):
+            return 2.0 * np.sin(q)
+
+        def d(self, q, dq):
+            return 0.2 * dq
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = Robot(dof, actuators=act)
+        s.x_ub, s.x_lb = np.full(2 * dof, 1.5), np.full(2 * dof, -1.5)
+        s.u_ub, s.u_lb = np.full(act, 3.0), np.full(act, -3.0)
+        dims = [15, 13] if dof == 1 else [7, 6, 7, 6]
+        grid = discretizer.GridDynamicSystem(s, dims, [5] if act == 1 else [3, 3], dt=0.08)
+        cf = costfunction.QuadraticCostFunction.from_sys(s)
+        cf.INF = 60.0
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(grid, cf)
+        assert dp.tier == "fused" and dp._p.dynamics_id == {(1, 1): _native.DYN_NODE_1x1, (2, 1): _native.DYN_NODE_2x1,
+                                                              (2, 2): _native.DYN_NODE_2x2}[(dof, act)]
+        dp.save_time_history = False
+        dp.compute_steps(6)
+        # table tier from the same system through the reference's own loops (host f, host g)
+        xn, ok = grid._host_xnext_table()
+        X, U = grid.state_from_node_id, grid.input_from_action_id
+        G = np.full((grid.nodes_n, grid.actions_n), float(cf.INF))
+        for n_, a_ in zip(*np.nonzero(ok)):
+            G[n_, a_] = cf.g(X[n_], U[a_], 0) * grid.dt
+        J = np.array([cf.h(x, 0) for x in X], dtype=float)
+        for _ in range(6):
+            J, pi, Q = O.sweep_lut(grid.x_level, xn, G, J)
+        assert relerr(dp.J, J) < 1e-11
+        Qs = np.sort(Q, axis=1)
+        clear = (Qs[:, 1] - Qs[:, 0]) > 1e-9
+        assert np.array_equal(dp.pi[clear], pi[clear])
+        dp32 = dynamicprogramming.DynamicProgrammingWithLookUpTable(grid, cf, dtype="float32")
+        dp32.save_time_history = False
+        dp32.compute_steps(6)
+        assert "lean" in dp32._p.describe() or "exact-f32" in dp32._p.describe()
+        assert relerr(dp32.J, J) < REL_F32
