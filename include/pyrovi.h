@@ -58,6 +58,8 @@ extern "C" {
 /* cost evaluated in-kernel */
 #define PVI_COST_TABLE 0      /* G supplied by the host */
 #define PVI_COST_QUADRATIC 1  /* pyro/analysis/costfunction.py:101 QuadraticCostFunction */
+#define PVI_COST_TIME 2       /* costfunction.py:287 TimeCostFunction: g = 1 (0 inside the target ball), h = 0;
+                                 uses xbar, EPS, INF, ontarget_check; Q, R, S, ubar are ignored */
 
 typedef struct pvi_problem* pvi_handle;
 

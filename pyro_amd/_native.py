@@ -14,7 +14,7 @@ PVI_MAX_N, PVI_MAX_M, PVI_MAX_TRIG = 4, 2, 4
 PVI_F32, PVI_F64 = 0, 1
 DYN_TABLE, DYN_PENDULUM, DYN_CARTPOLE, DYN_TWOLINK = 0, 1, 2, 3
 DYN_NODE_1x1, DYN_NODE_2x1, DYN_NODE_2x2 = 4, 5, 6        # any MechanicalSystem through per-node tables
-COST_TABLE, COST_QUADRATIC = 0, 1
+COST_TABLE, COST_QUADRATIC, COST_TIME = 0, 1, 2
 INTERP_LINEAR, INTERP_BICUBIC_SPLINE = 0, 1
 PVI_EHALO = -5
 ABI_VERSION = 1
@@ -167,7 +167,12 @@ class Problem:
             if t is not None:
                 a = _f64(t); self._keep.append(a)
                 d.trig[i] = _ptr(a)
-        if cost is not None:
+        if cost is not None and cost.get("kind") == "time":
+            d.cost_id = COST_TIME
+            d.xbar[:d.n] = [float(v) for v in cost["xbar"]]
+            d.EPS, d.INF = float(cost["EPS"]), float(cost["INF"])
+            d.ontarget_check = int(bool(cost.get("ontarget_check", True)))
+        elif cost is not None:
             d.cost_id = COST_QUADRATIC
             n, m = d.n, d.m
             for name, k in (("Q", n), ("S", n), ("R", m)):

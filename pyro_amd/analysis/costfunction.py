@@ -87,6 +87,13 @@ class TimeCostFunction(CostFunction):
             return 0
         return 1
 
+    def device_cost(self):
+        """Parameters of the in-kernel evaluation (PVI_COST_TIME)."""
+        if type(self) is not TimeCostFunction:          # subclasses change g/h -> table tier
+            return None
+        return dict(kind="time", xbar=np.asarray(self.xbar, dtype=float), EPS=self.EPS, INF=self.INF,
+                    ontarget_check=self.ontarget_check)
+
 
 class QuadraticCostFunctionWithDomainCheck(QuadraticCostFunction):
     """Quadratic cost that returns INF for states the system rejects (costfunction.py:339-416).

@@ -1958,7 +1958,8 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
         if (dyn_shape(d->dynamics_id, &n, &m)) return fail(PVI_EINVAL, "unknown dynamics_id %d", d->dynamics_id);
         if (n != d->n || m != d->m)
             return fail(PVI_EINVAL, "dynamics %d needs n=%d m=%d, got n=%d m=%d", d->dynamics_id, n, m, d->n, d->m);
-        if (d->cost_id != PVI_COST_QUADRATIC) return fail(PVI_EINVAL, "in-kernel dynamics need cost_id QUADRATIC");
+        if (d->cost_id != PVI_COST_QUADRATIC && d->cost_id != PVI_COST_TIME)
+            return fail(PVI_EINVAL, "in-kernel dynamics need cost_id QUADRATIC or TIME");
     }
     long long plane = 1, A = 1;
     for (int i = 0; i < d->n; ++i) {
@@ -2040,6 +2041,10 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
     // row-major n x n -> dense n x n at the front of the 16-slot arrays
     memcpy(P.Q, d->Q, sizeof(double) * d->n * d->n);
     memcpy(P.S, d->S, sizeof(double) * d->n * d->n);
+    if (d->cost_id == PVI_COST_TIME) {
+        memset(P.Q, 0, sizeof(P.Q));
+        memset(P.S, 0, sizeof(P.S));
+    }
     P.EPS = d->EPS;
     P.INF = d->INF;
     P.ontarget = d->ontarget_check;
@@ -2059,7 +2064,9 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
             du[k] = u - d->ubar[k];
             ok = ok && !(u < d->u_lb[k]) && !(u > d->u_ub[k]);  // system.py:208-215
         }
-        gu[a] = quad_form_host(d->R, du, d->m);
+        // TimeCostFunction (costfunction.py:318-334): g = 1 outside the target ball -- the constant rides in the
+        // per-action term, the state term and the terminal cost are zero (Q = S = 0 below)
+        gu[a] = d->cost_id == PVI_COST_TIME ? 1.0 : quad_form_host(d->R, du, d->m);
         aok[a] = ok;
     }
     if ((rc = dev_upload(h, utab.data(), utab.size(), &P.utab))) return bail(rc);
@@ -2233,7 +2240,8 @@ static int terminal_cost_t(pvi_problem* h) {
 
 extern "C" int pvi_terminal_cost(pvi_handle h) {
     if (!h) return fail(PVI_EINVAL, "NULL handle");
-    if (h->d.cost_id != PVI_COST_QUADRATIC) return fail(PVI_ESTATE, "terminal cost needs cost_id QUADRATIC");
+    if (h->d.cost_id != PVI_COST_QUADRATIC && h->d.cost_id != PVI_COST_TIME)
+        return fail(PVI_ESTATE, "terminal cost needs an in-kernel cost (QUADRATIC or TIME)");
     HIPCHK(hipSetDevice(h->device));
     return h->d.dtype == PVI_F64 ? terminal_cost_t<double>(h) : terminal_cost_t<float>(h);
 }

@@ -514,7 +514,35 @@ def case_mountaincar():
     save("mountaincar_41x41x5", **out)
 
 
-CASES = dict(mountaincar=case_mountaincar, spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
+def case_mintime():
+    """simple_pendulum_with_valueiteration_minimum_time.py reduced to 61x61x3: InvertedPendulum, bounds +-6,
+    TimeCostFunction (g = 1 outside the EPS ball around xbar, h = 0), INF 10, EPS 0.1."""
+    with quiet():
+        s = pendulum.InvertedPendulum()
+        s.x_ub = np.array([+6.0, +6.0]); s.x_lb = np.array([-6.0, -6.0])
+        g = discretizer.GridDynamicSystem(s, [61, 61], [3])
+        tcf = costfunction.TimeCostFunction(np.array([0.0, 0.0]))
+        tcf.INF = 10.0; tcf.EPS = 0.1
+        out = dict(x_lb=s.x_lb, x_ub=s.x_ub, u_lb=s.u_lb, u_ub=s.u_ub, dims=g.x_grid_dim, udims=g.u_grid_dim, dt=g.dt,
+                   xbar=tcf.xbar, INF=tcf.INF, EPS=tcf.EPS)
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, tcf)
+        dp.save_time_history = False
+        out.update(G=dp.G, J0=dp.J.copy())
+        stats = []
+        for k in range(1, 41):
+            dp.initialize_backward_step(); dp.compute_backward_step()
+            delta = dp.finalize_backward_step()
+            d = dp.J - dp.J_next
+            stats.append([dp.J.max(), d.max(), d.min(), delta])
+            if k in (1, 10, 40):
+                out["J_%d" % k] = dp.J.copy(); out["pi_%d" % k] = dp.pi.copy()
+                Q = np.sort(dp.Q, axis=1)
+                out["gap_%d" % k] = Q[:, 1] - Q[:, 0]
+        out["stats"] = np.array(stats)
+    save("mintime_invpendulum_61x61x3", **out)
+
+
+CASES = dict(mintime=case_mintime, mountaincar=case_mountaincar, spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
              policy_eval=case_policy_eval, cost_kat=case_cost_kat, grid_kat=case_grid_kat,
              pendulum_small=case_pendulum_small, config1=case_config1, lowdef=case_lowdef,
              pendulum_demo=case_pendulum_demo, cartpole_small=case_cartpole_small,

@@ -968,3 +968,33 @@ def test_generic_mechanical_systems_node_tier_equals_table_tier(dof, act):
         dp32.compute_steps(6)
         assert "lean" in dp32._p.describe() or "exact-f32" in dp32._p.describe()
         assert relerr(dp32.J, J) < REL_F32
+
+
+@pytest.mark.gpu
+def test_minimum_time_cost_runs_fused_and_matches_reference():
+    """simple_pendulum_with_valueiteration_minimum_time.py (reduced): TimeCostFunction evaluated in-kernel
+    (PVI_COST_TIME): G and J after 1, 10, 40 sweeps against the reference's run; exact in f64 (the costs are 0 / dt /
+    INF and the dynamics are the closed-form pendulum)."""
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import pendulum
+    from pyro_amd.planning import discretizer, dynamicprogramming
+    g = load("mintime_invpendulum_61x61x3")
+    for dtype, tol in (("float64", 1e-13), ("float32", REL_F32)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            s = pendulum.InvertedPendulum()
+            s.x_ub, s.x_lb = np.array([+6.0, +6.0]), np.array([-6.0, -6.0])
+            grid = discretizer.GridDynamicSystem(s, [61, 61], [3])
+            tcf = costfunction.TimeCostFunction(np.array([0.0, 0.0]))
+            tcf.INF, tcf.EPS = 10.0, 0.1
+            dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(grid, tcf, dtype=dtype)
+            dp.save_time_history = False
+            assert dp.tier == "fused"
+            if dtype == "float64":
+                assert np.array_equal(dp.G, g["G"]) and np.array_equal(dp.J, g["J0"])
+            done = 0
+            for k in (1, 10, 40):
+                dp.compute_steps(k - done)
+                done = k
+                assert relerr(dp.J, g["J_%d" % k]) < tol, (dtype, k)
+                clear = g["gap_%d" % k] > (1e-9 if dtype == "float64" else 1e-3)
+                assert np.array_equal(dp.pi[clear], g["pi_%d" % k][clear])
