@@ -2107,7 +2107,10 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
             box_is_grid = box_is_grid && d->x_lb[i] == P.glo[i] && d->x_ub[i] == P.ghi[i];
         h->fast_ok = d->dtype == PVI_F32 && d->dynamics_id != PVI_DYN_TABLE && box_is_grid &&
                      h->stored < 0x7fffffffLL && !getenv("PVI_NO_FAST");
-        h->tile_ok = h->fast_ok && !getenv("PVI_NO_TILE") && !is_node_dyn(d->dynamics_id);
+        // the per-sweep bounding-box tile kernel predates the lean kernel; where the lean window does not fit LDS its
+        // window does not pay either (two-link 101^4 x 121 f32: tile 167 ms, fast 35 ms): opt-in, PVI_TILE=1
+        h->tile_ok = h->fast_ok && getenv("PVI_TILE") && atoi(getenv("PVI_TILE")) && !getenv("PVI_NO_TILE") &&
+                     !is_node_dyn(d->dynamics_id);
         h->T.guard = h->F.guard;
         h->T.lsplit = ls;
         // LDS window budget / workgroup size: 2-D windows are small (4 workgroups per CU); 4-D windows

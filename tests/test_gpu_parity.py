@@ -369,9 +369,9 @@ def test_f32_kernel_variants_agree(name, monkeypatch):
         ref, _ = O.sweep(p, ref, alpha)
     outs = {}
     for tag, env in [("lean", {}), ("lean_split", {"PVI_LSPLIT": "2"}), ("lean_nosplit", {"PVI_LSPLIT": "0"}),
-                     ("tile", {"PVI_NO_LEAN": "1"}), ("fast", {"PVI_NO_LEAN": "1", "PVI_NO_TILE": "1"}),
+                     ("tile", {"PVI_NO_LEAN": "1", "PVI_TILE": "1"}), ("fast", {"PVI_NO_LEAN": "1"}),
                      ("exact32", {"PVI_NO_FAST": "1"})]:
-        for k in ("PVI_LSPLIT", "PVI_NO_LEAN", "PVI_NO_TILE", "PVI_NO_FAST"):
+        for k in ("PVI_LSPLIT", "PVI_NO_LEAN", "PVI_TILE", "PVI_NO_FAST"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

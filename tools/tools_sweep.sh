@@ -10,4 +10,4 @@ for l in sys.stdin:
 for b in 128 256 512; do for k in 16 32 64; do PVI_BLOCK=$b PVI_LDS_KB=$k run c2; done; done
 for s in 2 3 4 5; do PVI_LSPLIT=$s run c2p; done
 for b in 256 512 1024; do for k in 64 96 150; do PVI_BLOCK=$b PVI_LDS_KB=$k run c3 "--steps 5 --warmup 1"; done; done
-PVI_NO_TILE=1 run c3 "--steps 5 --warmup 1"
+run c3 "--steps 5 --warmup 1"
