@@ -1,0 +1,55 @@
+"""Randomised consistency run on the GPU: float32 kernels (lean / fast / exact32, whatever the dispatcher picks) against
+the float64 exact kernel on random small problems (dims, action counts, bounds, dt, alpha, cost weights).
+usage: tools_fuzz.py [n_cases] [seed]"""
+import sys, contextlib, io
+sys.path.insert(0, "/root/repo")
+import numpy as np
+from pyro_amd.analysis import costfunction
+from pyro_amd.dynamic import pendulum, cartpole, manipulator
+from pyro_amd.planning import discretizer, dynamicprogramming
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+worst, fails = 0.0, 0
+for case in range(n_cases):
+    kind = rng.choice(["pendulum", "inverted", "cartpole", "doublependulum", "twolink"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        if kind in ("pendulum", "inverted"):
+            s = pendulum.SinglePendulum() if kind == "pendulum" else pendulum.InvertedPendulum()
+            dims = [int(rng.integers(4, 140)), int(rng.integers(4, 140))]
+            udims = [int(rng.integers(1, 70))]
+        else:
+            s = {"cartpole": cartpole.CartPole, "doublependulum": pendulum.DoublePendulum,
+                 "twolink": manipulator.TwoLinkManipulator}[kind]()
+            dims = [int(rng.integers(3, 14)) for _ in range(4)]
+            udims = [int(rng.integers(1, 30))] if s.m == 1 else [int(rng.integers(1, 7)), int(rng.integers(1, 7))]
+        scale = rng.uniform(0.3, 1.5, size=s.n)
+        s.x_ub, s.x_lb = s.x_ub * scale, s.x_lb * scale * rng.uniform(0.5, 1.0, size=s.n)
+        s.u_ub, s.u_lb = s.u_ub * rng.uniform(0.2, 2.0), s.u_lb * rng.uniform(0.2, 2.0)
+        dt = float(rng.choice([0.01, 0.05, 0.1, 0.2]))
+        grid = discretizer.GridDynamicSystem(s, dims, udims, dt=dt)
+        cf = costfunction.QuadraticCostFunction.from_sys(s)
+        cf.xbar = rng.uniform(s.x_lb, s.x_ub) * 0.5
+        cf.INF = float(rng.choice([50.0, 300.0, 1000.0]))
+        cf.EPS = float(rng.choice([1e-3, 0.3]))
+        cf.R = cf.R * rng.uniform(0.1, 5.0)
+        cf.S = cf.S + np.eye(s.n) * rng.uniform(0.0, 5.0)
+        alpha = float(rng.choice([1.0, 0.97]))
+        nsw = int(rng.integers(1, 12))
+        res = {}
+        for dtype in ("float64", "float32"):
+            dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(grid, cf, dtype=dtype)
+            dp.save_time_history = False
+            dp.alpha = alpha
+            dp.compute_steps(nsw)
+            res[dtype] = (dp.J.copy(), dp.pi.copy(), dp._p.describe().split()[0])
+            dp._p.close()
+    J64, J32 = res["float64"][0], res["float32"][0]
+    err = np.abs(J32 - J64).max() / max(np.abs(J64).max(), 1e-300)
+    worst = max(worst, err)
+    bad = err > 1e-5
+    fails += bad
+    print("%3d %-14s dims %-18s A %-8s dt %.2f a %.2f sw %2d  %s  err %.2e %s" %
+          (case, kind, dims, udims, dt, alpha, nsw, res["float32"][2], err, "FAIL" if bad else ""), flush=True)
+print("worst rel err %.3e, failures %d / %d" % (worst, fails, n_cases))
+sys.exit(1 if fails else 0)
