@@ -730,7 +730,7 @@ struct FastP {
 template <int DYN, typename PI_T, bool UNIFORM>
 __global__ __launch_bounds__(256) void k_sweep_fast(DevP P, FastP F, const float* __restrict__ Jin,
                                                     float* __restrict__ Jout, PI_T* __restrict__ pi, float alpha,
-                                                    SweepCtl sc) {
+                                                    SweepCtl sc, const float4* __restrict__ actp) {
     using D = Dyn<DYN>;
     constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M, NP = 1 << DOF;
     if (sc.ctrl->done) return;
@@ -819,7 +819,7 @@ __global__ __launch_bounds__(256) void k_sweep_fast(DevP P, FastP F, const float
     int arg = 0x7fffffff;
     if (live) {
         for (int a = part; a < P.A; a += split) {
-            const float4 act = F.act[a];
+            const float4 act = actp[a];  // (a restrict kernel argument: scalar loads when a is wave-uniform)
             float rel[DOF], m = INFINITY;
 #pragma unroll
             for (int i = 0; i < DOF; ++i) {
@@ -2479,9 +2479,9 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             sc.nblocks = gf;
 #define FAST(DYN)                                                                                                  \
     if (h->F.lsplit == 0)                                                                                          \
-        hipLaunchKernelGGL((k_sweep_fast<DYN, PI_T, true>), gf, 256, 0, st, h->P, h->F, Jin, Jout, pi, al, sc);                                                                                  \
+        hipLaunchKernelGGL((k_sweep_fast<DYN, PI_T, true>), gf, 256, 0, st, h->P, h->F, Jin, Jout, pi, al, sc, h->F.act);                                                                                  \
     else                                                                                                           \
-        hipLaunchKernelGGL((k_sweep_fast<DYN, PI_T, false>), gf, 256, 0, st, h->P, h->F, Jin, Jout, pi, al, sc);
+        hipLaunchKernelGGL((k_sweep_fast<DYN, PI_T, false>), gf, 256, 0, st, h->P, h->F, Jin, Jout, pi, al, sc, h->F.act);
             switch (h->d.dynamics_id) {
                 case PVI_DYN_PENDULUM: FAST(PVI_DYN_PENDULUM) break;
                 case PVI_DYN_CARTPOLE: FAST(PVI_DYN_CARTPOLE) break;
