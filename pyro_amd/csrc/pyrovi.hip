@@ -304,6 +304,25 @@ __device__ inline int find_interval(const double* lev, int N, double lo, double 
     return i;
 }
 
+// the same interval together with its two end levels (the fraction needs them): one loop, one pair of level reads
+// per trip -- a single trip on linspace grids unless the float estimate is off by one
+__device__ inline int find_interval_lv(const double* lev, int N, double lo, double inv_step, double x, double& l0,
+                                       double& l1) {
+    double t = floor((x - lo) * inv_step);
+    int i = (t < 0.0) ? 0 : (t > (double)(N - 2) ? N - 2 : (int)t);
+    for (;;) {
+        l0 = lev[i];
+        l1 = lev[i + 1];
+        if (i > 0 && x < l0)
+            --i;
+        else if (i < N - 2 && x >= l1)
+            ++i;
+        else
+            break;
+    }
+    return i;
+}
+
 // float64: bit-for-bit the oracle's order.  2-D follows evaluate_linear_2d, n>2 _evaluate_linear.
 template <int N>
 __device__ inline double interp_f64(const double* __restrict__ J, const long long* strd, long long base,
@@ -675,8 +694,9 @@ __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ 
 #pragma unroll
                 for (int i = 0; i < DOF; ++i) {
                     const int d = DOF + i;
-                    ci[d] = find_interval(lev[d], P.dim[d], P.glo[d], P.inv_step[d], xnv[i]);
-                    y[d] = (xnv[i] - lev[d][ci[d]]) / (lev[d][ci[d] + 1] - lev[d][ci[d]]);
+                    double l0, l1;
+                    ci[d] = find_interval_lv(lev[d], P.dim[d], P.glo[d], P.inv_step[d], xnv[i], l0, l1);
+                    y[d] = (xnv[i] - l0) / (l1 - l0);
                     b += ci[d] * P.strd[d];
                 }
             }
@@ -1362,9 +1382,9 @@ __global__ __launch_bounds__(256) void k_sweep_table(DevP P, const double* __res
             for (int d = 0; d < N; ++d) {
                 const double v = cur.x[d];
                 inb = inb && !(v < P.glo[d]) && !(v > P.ghi[d]);
-                ci[d] = find_interval(lev[d], P.dim[d], P.glo[d], P.inv_step[d], v);
-                const double l0 = lev[d][ci[d]];
-                y[d] = (v - l0) / (lev[d][ci[d] + 1] - l0);
+                double l0, l1;
+                ci[d] = find_interval_lv(lev[d], P.dim[d], P.glo[d], P.inv_step[d], v, l0, l1);
+                y[d] = (v - l0) / (l1 - l0);
                 int c = ci[d];
                 if (d == 0) {
                     if (inb && (c < P.store_begin || c + 1 >= P.store_end)) atomicOr(&sc.ctrl->halo_err, 1);
