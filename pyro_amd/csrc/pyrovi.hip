@@ -327,24 +327,30 @@ __device__ inline int find_interval_lv(const double* lev, int N, double lo, doub
 template <int N>
 __device__ inline double interp_f64(const double* __restrict__ J, const long long* strd, long long base,
                                     const double* y) {
+    // the two corners along the last axis are neighbours in memory (stride 1): one 16-byte load per pair
+    // (8-byte aligned -- global memory takes that), i.e. 2^(N-1) vector loads instead of 2^N
+    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
     if (N == 2) {
-        const double v00 = J[base], v01 = J[base + strd[1]];
-        const double v10 = J[base + strd[0]], v11 = J[base + strd[0] + strd[1]];
+        const d2u r0 = *(const d2u*)(J + base), r1 = *(const d2u*)(J + base + strd[0]);
+        const double v00 = r0.x, v01 = r0.y, v10 = r1.x, v11 = r1.y;
         const double a0 = 1.0 - y[0], a1 = 1.0 - y[1];
         return v00 * a0 * a1 + v01 * a0 * y[1] + v10 * y[0] * a1 + v11 * y[0] * y[1];
     }
     double val = 0.0;
 #pragma unroll
-    for (int corner = 0; corner < (1 << N); ++corner) {
+    for (int pair = 0; pair < (1 << (N - 1)); ++pair) {
         double w = 1.0;
         long long off = base;
 #pragma unroll
-        for (int d = 0; d < N; ++d) {
-            const int bit = (corner >> (N - 1 - d)) & 1;
+        for (int d = 0; d < N - 1; ++d) {
+            const int bit = (pair >> (N - 2 - d)) & 1;
             w = w * (bit ? y[d] : (1.0 - y[d]));
             off += bit ? strd[d] : 0;
         }
-        val = val + J[off] * w;
+        const d2u r = *(const d2u*)(J + off);
+        // corner order of _evaluate_linear: the last axis varies fastest (bit 0), weights multiplied axis by axis
+        val = val + r.x * (w * (1.0 - y[N - 1]));
+        val = val + r.y * (w * y[N - 1]);
     }
     return val;
 }
@@ -354,12 +360,15 @@ template <int N>
 __device__ inline float interp_f32(const float* __restrict__ J, const long long* strd, long long base,
                                    const float* y) {
     float v[1 << N];
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 #pragma unroll
-    for (int corner = 0; corner < (1 << N); ++corner) {
+    for (int pair = 0; pair < (1 << (N - 1)); ++pair) {  // the last-axis neighbours share one 8-byte load
         long long off = base;
 #pragma unroll
-        for (int d = 0; d < N; ++d) off += ((corner >> (N - 1 - d)) & 1) ? strd[d] : 0;
-        v[corner] = J[off];
+        for (int d = 0; d < N - 1; ++d) off += ((pair >> (N - 2 - d)) & 1) ? strd[d] : 0;
+        const f2u r = *(const f2u*)(J + off);
+        v[2 * pair] = r.x;
+        v[2 * pair + 1] = r.y;
     }
 #pragma unroll
     for (int d = N - 1; d >= 0; --d) {
