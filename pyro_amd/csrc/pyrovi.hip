@@ -1739,6 +1739,8 @@ static void dev_release(pvi_problem* h, void* p) {
     (void)hipFree(p);
 }
 
+static int launch_sweep(pvi_problem* h, int src, double alpha, hipStream_t st, int k, double tol);
+
 static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats) {
     const DevP& P = h->P;
     LeanP& L = h->LP;
@@ -1890,6 +1892,56 @@ static int lean_setup(pvi_problem* h) {
     // register-resident node contexts cost the action loop more than that (C2 43.7 -> 49 us at 71 VGPRs / 7 waves,
     // 55 us squeezed to 63 VGPRs): opt-in for experiments, PVI_NPT=2
     L.npt = (DOF == 1 && ls == 0 && getenv("PVI_NPT") && atoi(getenv("PVI_NPT")) == 2) ? 2 : 1;
+    // 4-D: the best tile shape depends on how the grid divides (101^4: 15x34 beats 10x51 by 8 %, 151^4: 19x26 beats
+    // 16x31 by 7 %) -- time the candidates (widths V1/k, as many rows as fit 512 threads) with two real sweeps each and
+    // keep the fastest.  Results do not depend on the shape (same arithmetic per node).  PVI_TUNE=0 switches it off.
+    if (DOF == 2 && ls == 0 && !(getenv("PVI_TV0") && getenv("PVI_TV1")) && !(getenv("PVI_TUNE") && !atoi(getenv("PVI_TUNE")))) {
+        const int V1 = P.dim[3];
+        float best_ms = 1e30f;
+        int best[2] = {0, 0};
+        for (int k = 1; k <= 8; ++k) {
+            const int w = (V1 + k - 1) / k;
+            if (w > 64 && k < 8) continue;
+            if (w < 16) break;
+            const int t0 = std::max(1, std::min(L.V0 ? L.V0 : P.dim[2], 512 / w));
+            rc = lean_try(h, t0, w, budget);
+            if (rc < 0) return rc;
+            if (rc == 2) break;
+            if (rc != 0) continue;
+            const int threads = L.TV0 * L.TV1;
+            h->lean_block = ((threads + 63) / 64) * 64;
+            if (h->lean_block > 512) continue;
+            h->lean_ok = true;
+            h->lean_lds_attr = false;
+            float ms = 0.f;
+            for (int rep = 0; rep < 3 && rc == 0; ++rep) {  // one warm-up, two timed
+                if (rep == 1) HIPCHK(hipEventRecord(h->ev0, h->stream));
+                hipLaunchKernelGGL(k_reset_stats, 1, STAT_WORDS, 0, h->stream, h->slots, STAT_WORDS);
+                hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, h->stream, h->ctrl);
+                rc = launch_sweep(h, h->cur, 1.0, h->stream, 0, -1.0);
+            }
+            h->lean_ok = false;
+            if (rc) return rc;
+            HIPCHK(hipEventRecord(h->ev1, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+            if (ms < best_ms) {
+                best_ms = ms;
+                best[0] = L.TV0;
+                best[1] = L.TV1;
+            }
+        }
+        if (best[0]) {
+            ns = 0;
+            shapes[ns][0] = best[0];
+            shapes[ns++][1] = best[1];
+        }
+        // the timed sweeps wrote garbage into the second J buffer, pi and the control block: clear what a caller
+        // could observe before the first pvi_terminal_cost / pvi_set_J
+        HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream));
+        HIPCHK(hipMemsetAsync(h->pi, 0, (size_t)h->owned * h->pi_size, h->stream));
+        HIPCHK(hipMemsetAsync(h->J[h->cur ^ 1], 0, (size_t)h->stored * (h->d.dtype == PVI_F64 ? 8 : 4), h->stream));
+    }
     for (int k = 0; k < ns; ++k) {
         rc = lean_try(h, shapes[k][0] * L.npt, shapes[k][1], budget);
         if (rc < 0) return rc;
