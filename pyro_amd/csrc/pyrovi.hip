@@ -1687,6 +1687,8 @@ struct pvi_problem {
     size_t lean_lds = 0;
     bool lean_lds_attr = false;
     char lean_why[160] = "";
+    int lean_reach = 0;       // largest |velocity displacement| of an in-box cell, grid cells
+    int lean_opmag = 0;       // largest |ta| + sum |tB u| (cells): operand magnitude of the float32 displacement
     MarchP MP;                // 4-D march variant of the lean path
     bool march_ok = false;
     size_t march_lds = 0;
@@ -1805,9 +1807,11 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
             break;
     }
     HIPCHK(hipGetLastError());
-    int summary[4];
+    int summary[8];
     HIPCHK(hipMemcpyAsync(summary, L.summary, sizeof(summary), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->lean_reach = summary[4];
+    h->lean_opmag = summary[5];
     if (summary[3]) {
         snprintf(h->lean_why, sizeof(h->lean_why), "%s", (summary[3] & 2) ? "an action fails isavalidinput" : "halo too small");
         return (summary[3] & 1) ? 2 : 1;
@@ -1850,7 +1854,7 @@ static int lean_setup(pvi_problem* h) {
     if ((rc = dev_alloc(h, (size_t)h->owned, &L.flag))) return rc;
     if ((rc = dev_alloc(h, (size_t)P.dim[0] * P.dim[DOF], &L.pt0))) return rc;
     if (DOF == 2 && (rc = dev_alloc(h, (size_t)P.dim[1] * P.dim[3], &L.pt1))) return rc;
-    if ((rc = dev_alloc(h, 4, &L.summary))) return rc;
+    if ((rc = dev_alloc(h, 8, &L.summary))) return rc;
     L.guard = h->F.guard;
     hipLaunchKernelGGL(k_lean_pairs, grid_for((long long)P.dim[0] * P.dim[DOF]), 256, 0, h->stream, P, 0, L.pt0);
     if (DOF == 2)
@@ -1958,6 +1962,16 @@ static int lean_setup(pvi_problem* h) {
             }
             break;
         }
+    }
+    // float32 accuracy guard: the displacement rel = ta + sum tB u is formed from float32 copies of ta and tB.  When
+    // those operands are hundreds of cells and cancel (light links with strong actuators: the default two-link arm has
+    // |ta| + |tB u| up to 3800 cells), their rounding alone moves the fraction by > 1e-5 cells and J by > 1e-5
+    // relative (tools/tools_fuzz.py).  Such problems run the kernel with float64 dynamics and float32 storage instead.
+    if (h->lean_opmag > 256 && !getenv("PVI_ALLOW_F32_CANCEL")) {
+        snprintf(h->lean_why, sizeof(h->lean_why), "float32 displacement operands reach %d cells: float64 dynamics", h->lean_opmag);
+        h->lean_ok = false;
+        h->fast_ok = false;
+        h->tile_ok = false;
     }
     h->march_ok = false;
     // the march variant is opt-in (PVI_MARCH=1): measured within 3 % of the tiled lean kernel on 101^4
@@ -2293,9 +2307,9 @@ extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
                        : h->tile_ok ? "tile"
                        : (h->fast_ok && !is_node_dyn(h->d.dynamics_id)) ? "fast"
                        : (h->d.dynamics_id == PVI_DYN_TABLE ? "table" : "exact-f32");
-    snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d note=%s", path,
-             h->LP.TV0, h->LP.TV1, h->lean_grid.x, h->lean_grid.y, h->lean_grid.z, h->lean_block, h->lean_pw1,
-             h->lean_lds, h->lean_ok ? h->LP.lsplit : h->F.lsplit, h->LP.tb_tile, h->lean_why);
+    snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d reach=%d opmag=%d note=%s",
+             path, h->LP.TV0, h->LP.TV1, h->lean_grid.x, h->lean_grid.y, h->lean_grid.z, h->lean_block, h->lean_pw1,
+             h->lean_lds, h->lean_ok ? h->LP.lsplit : h->F.lsplit, h->LP.tb_tile, h->lean_reach, h->lean_opmag, h->lean_why);
     return PVI_OK;
 }
 

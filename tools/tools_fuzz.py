@@ -42,7 +42,8 @@ for case in range(n_cases):
             dp.save_time_history = False
             dp.alpha = alpha
             dp.compute_steps(nsw)
-            res[dtype] = (dp.J.copy(), dp.pi.copy(), dp._p.describe().split()[0])
+            d_ = dp._p.describe().split()
+            res[dtype] = (dp.J.copy(), dp.pi.copy(), d_[0] + " " + " ".join(w for w in d_ if w.startswith(("reach", "opmag"))))
             dp._p.close()
     J64, J32 = res["float64"][0], res["float32"][0]
     err = np.abs(J32 - J64).max() / max(np.abs(J64).max(), 1e-300)
@@ -50,6 +51,22 @@ for case in range(n_cases):
     bad = err > 1e-5
     fails += bad
     print("%3d %-14s dims %-18s A %-8s dt %.2f a %.2f sw %2d  %s  err %.2e %s" %
-          (case, kind, dims, udims, dt, alpha, nsw, res["float32"][2], err, "FAIL" if bad else ""), flush=True)
+          (case, kind, dims, udims, dt, alpha, nsw, res["float32"][2] + " " + [w for w in dp._p.describe().split() if w.startswith(("reach", "opmag"))][0] if False else res["float32"][2], err, "FAIL" if bad else ""), flush=True)
+    if bad:                                         # where, and what does the f64-dynamics / f32-storage kernel say?
+        import os
+        os.environ["PVI_NO_FAST"] = "1"
+        with contextlib.redirect_stdout(io.StringIO()):
+            dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(grid, cf, dtype="float32")
+            dp.save_time_history = False
+            dp.alpha = alpha
+            dp.compute_steps(nsw)
+        del os.environ["PVI_NO_FAST"]
+        Jx = dp.J.copy()
+        dp._p.close()
+        top = np.argsort(-np.abs(J32 - J64))[:4]
+        print("    x_lb", np.round(s.x_lb, 3), "x_ub", np.round(s.x_ub, 3), "u", np.round(s.u_lb, 2), np.round(s.u_ub, 2), "INF", cf.INF)
+        for i in top:
+            print("    node %6d idx %s  J64 %.9g  J32 %.9g  exact32 %.9g  pi64 %d pi32 %d" %
+                  (i, np.unravel_index(i, dims), J64[i], J32[i], Jx[i], res["float64"][1][i], res["float32"][1][i]))
 print("worst rel err %.3e, failures %d / %d" % (worst, fails, n_cases))
 sys.exit(1 if fails else 0)
