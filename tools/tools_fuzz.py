@@ -21,7 +21,7 @@ for case in range(n_cases):
         else:
             s = {"cartpole": cartpole.CartPole, "doublependulum": pendulum.DoublePendulum,
                  "twolink": manipulator.TwoLinkManipulator}[kind]()
-            dims = [int(rng.integers(3, 14)) for _ in range(4)]
+            dims = [int(rng.integers(3, int(__import__('os').environ.get('FUZZ_4D_MAX', '14')))) for _ in range(4)]
             udims = [int(rng.integers(1, 30))] if s.m == 1 else [int(rng.integers(1, 7)), int(rng.integers(1, 7))]
         scale = rng.uniform(0.3, 1.5, size=s.n)
         s.x_ub, s.x_lb = s.x_ub * scale, s.x_lb * scale * rng.uniform(0.5, 1.0, size=s.n)
