@@ -1826,6 +1826,7 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
         if (atoi(e) == 1 && DOF == 2) rs = summary[1] + 1 + (((L.TV1 - summary[1] - 1) % 32 + 32) % 32);
         if (atoi(e) == 2) rs = 32 * ((summary[1] + 31) / 32) + 1;
     }
+    if (const char* e = getenv("PVI_RS")) rs = std::max(rs, atoi(e));  // experiments: explicit row pitch
     const long long need = (long long)summary[0] * rs + 128;
     if (need <= lds_budget_floats) {
         L.RS = rs;
