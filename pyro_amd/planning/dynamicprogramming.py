@@ -272,12 +272,26 @@ class DynamicProgramming:
         """(not in the reference) B closed-loop Euler trajectories of the current policy on the GPU: what
         `(dp.get_lookup_table_controller() + sys).compute_trajectory(tf, n, 'euler')` does for one x0
         (controller.py:328-355, simulation.py:298-324).  Returns t [n], X [B,n,sys.n], U [B,n,sys.m]."""
-        if self.tier != "fused":
-            raise NotImplementedError("batched rollouts need in-kernel dynamics")
-        self._p.set_pi(self.pi)                 # the host policy may have been edited (clean_infeasible_set)
         dt = (tf + 0.0) / (n - 1)
-        X, U = self._p.rollout(X0, n, dt)
-        return np.linspace(0, tf, n), X, U
+        t = np.linspace(0, tf, n)
+        closed_form = self.tier == "fused" and self._p.dynamics_id in (_native.DYN_PENDULUM, _native.DYN_CARTPOLE,
+                                                                        _native.DYN_TWOLINK)
+        if closed_form:
+            self._p.set_pi(self.pi)             # the host policy may have been edited (clean_infeasible_set)
+            X, U = self._p.rollout(X0, n, dt)
+            return t, X, U
+        # systems without a closed-form kernel (table tier, per-node tables): the reference's own loop --
+        # u = ctl.c(x, t), x <- x + f(x, u, t) dt (controller.py:328-355, simulation.py:298-324) -- on the host
+        ctl = self.get_lookup_table_controller()
+        X0 = np.atleast_2d(np.asarray(X0, dtype=float))
+        X = np.empty((X0.shape[0], n, self.sys.n))
+        U = np.empty((X0.shape[0], n, self.sys.m))
+        for b, x in enumerate(X0):
+            for i in range(n):
+                u = np.atleast_1d(ctl.c(x, t[i]))
+                X[b, i], U[b, i] = x, u
+                x = x + np.asarray(self.sys.f(x, u, t[i]), dtype=float) * dt
+        return t, X, U
 
     def save_latest(self, name="test_data"):
         """Writes J_next (not J), as the reference does (:481-485)."""

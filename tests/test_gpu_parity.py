@@ -998,3 +998,21 @@ def test_minimum_time_cost_runs_fused_and_matches_reference():
                 assert relerr(dp.J, g["J_%d" % k]) < tol, (dtype, k)
                 clear = g["gap_%d" % k] > (1e-9 if dtype == "float64" else 1e-3)
                 assert np.array_equal(dp.pi[clear], g["pi_%d" % k][clear])
+
+
+@pytest.mark.gpu
+def test_closed_loop_rollout_of_a_node_tier_system_falls_back_to_the_host_loop():
+    """No closed form in the kernels (MountainCar): simulate_closed_loop runs the reference's controller + Euler loop on
+    the host with the GPU-computed policy."""
+    g = load("mountaincar_41x41x5")
+    with contextlib.redirect_stdout(io.StringIO()):
+        dp = _mountaincar_dp(g, "float64")
+        dp.compute_steps(60)
+        dp.clean_infeasible_set()
+        t, X, U = dp.simulate_closed_loop(np.array([[-1.0, 0.0], [-0.5, 0.3]]), tf=20.0, n=2001)
+    assert X.shape == (2, 2001, 2) and U.shape == (2, 2001, 1) and t.shape == (2001,)
+    assert np.all(np.abs(U) <= 0.2 + 1e-12)
+    ctl = dp.get_lookup_table_controller()
+    assert np.allclose(U[0, 0], ctl.c(np.array([-1.0, 0.0]), 0))
+    assert np.allclose(X[0, 1], X[0, 0] + dp.sys.f(X[0, 0], U[0, 0], 0) * (20.0 / 2000))
+    assert np.all(np.isfinite(X)) and np.all(X[:, :, 0] > -1.8) and np.all(X[:, :, 0] < 0.3)
