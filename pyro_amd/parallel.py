@@ -61,6 +61,7 @@ class HipSlab:
         self.J = [torch.zeros(nst, dtype=tdt, device=self.dev) for _ in range(2)]
         A = int(np.prod(grid_sys.u_grid_dim))
         self.pi = torch.zeros(nown, dtype=torch.uint8 if A <= 256 else torch.int16, device=self.dev)
+        torch.cuda.synchronize(self.dev)        # the fills ran on torch's stream; the library works on its own streams
         self.cur = 0
         # row ranges of the handles: boundary pieces first, the interior last
         r0, r1 = rows
