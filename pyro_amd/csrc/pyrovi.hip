@@ -1864,7 +1864,12 @@ static int lean_setup(pvi_problem* h) {
     // lanes per node for small grids: as many as still fit ONE round of resident waves (1024 SIMDs x 8 waves x 64
     // lanes); a second round costs more than the extra parallelism brings (201x201x201: 27 -> 23 us)
     int ls = 0;
-    while ((h->owned << (ls + 1)) <= (1ll << 19) && (2 << ls) <= 16 && (4 << ls) <= P.A) ++ls;
+    // (measured: 401^2 x 101 is best at 4 lanes per node -- 1.2 rounds, 25 actions per lane; 201^2 x 201 loses at 16
+    //  lanes with 12 actions per lane: allow a quarter round more while a lane keeps >= 16 actions)
+    while (((h->owned << (ls + 1)) <= (1ll << 19) ||
+            ((h->owned << (ls + 1)) <= 655360 && P.A / (2 << ls) >= 16)) &&
+           (2 << ls) <= 16 && (4 << ls) <= P.A)
+        ++ls;
     if (const char* e = getenv("PVI_LSPLIT")) ls = atoi(e);
     L.lsplit = ls;
     const int spb = std::max(16, 256 >> ls);  // nodes per workgroup
