@@ -28,6 +28,10 @@ extern "C" {
 #define PVI_MAX_M 2 /* input dimensions: 1, 2 (discretizer.py:271-306) */
 #define PVI_MAX_TRIG 4
 
+/* pvi_desc.flags */
+#define PVI_FLAG_EXT_J_SLACK 1 /* the ext_J buffers have >= 64 readable bytes behind the stored rows (lets the 4-D
+                                  window fill use 16-byte loads that may run past the end of a row) */
+
 /* error codes */
 #define PVI_OK 0
 #define PVI_EINVAL -1   /* bad argument / unsupported shape (reference: ValueError / NotImplementedError) */
@@ -100,7 +104,7 @@ typedef struct pvi_desc {
     int32_t row_begin, row_end;      /* rows updated by a sweep */
     int32_t halo_lo, halo_hi;        /* extra rows of J kept below / above for the gathers */
     int32_t device;                  /* HIP device ordinal */
-    int32_t flags;                   /* reserved, 0 */
+    int32_t flags;                   /* PVI_FLAG_* */
     /* optional caller-owned device buffers (e.g. torch tensors used for the RCCL halo exchange):
        two J buffers of stored_rows*plane elements of `dtype`, one pi buffer of owned_rows*plane
        bytes (A<=256) or uint16 (A<=65536).  NULL -> allocated by the library. */

@@ -17,6 +17,7 @@ DYN_NODE_1x1, DYN_NODE_2x1, DYN_NODE_2x2 = 4, 5, 6        # any MechanicalSystem
 COST_TABLE, COST_QUADRATIC, COST_TIME = 0, 1, 2
 INTERP_LINEAR, INTERP_BICUBIC_SPLINE = 0, 1
 PVI_EHALO = -5
+FLAG_EXT_J_SLACK = 1
 ABI_VERSION = 1
 
 _dp = C.POINTER(C.c_double)
@@ -137,7 +138,7 @@ class Problem:
 
     def __init__(self, x_levels, u_levels, x_lb, x_ub, u_lb, u_ub, dt, dtype="float64", dynamics_id=DYN_TABLE,
                  dyn_params=(), trig=(), cost=None, rows=None, halo=(0, 0), device=0, ext_J=None, ext_pi=None,
-                 table_inf=0.0):
+                 table_inf=0.0, flags=0):
         L = lib()
         self._keep = []                      # host buffers the descriptor points to
         d = pvi_desc()
@@ -194,6 +195,7 @@ class Problem:
             d.ext_J[0], d.ext_J[1] = int(ext_J[0]), int(ext_J[1])
         if ext_pi is not None:
             d.ext_pi = int(ext_pi)
+        d.flags = int(flags)
         self.rows = (int(r0), int(r1))
         self.store_rows = (max(0, r0 - halo[0]), min(self.dims[0], r1 + halo[1]))
         self._h = _h()

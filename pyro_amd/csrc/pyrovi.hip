@@ -1827,6 +1827,14 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
         if (atoi(e) == 2) rs = 32 * ((summary[1] + 31) / 32) + 1;
     }
     if (const char* e = getenv("PVI_RS")) rs = std::max(rs, atoi(e));  // experiments: explicit row pitch
+    // 16-byte window DMA (4-D; J buffers with slack behind them): rows are packed with a pitch that is a multiple of
+    // 4 floats, one instruction then moves 256 consecutive window floats (about four rows).  PVI_DMA16=0: 4-byte DMA.
+    L.dma16 = (DOF == 2 && (h->own_J || (h->d.flags & PVI_FLAG_EXT_J_SLACK)) &&
+               !(getenv("PVI_DMA16") && !atoi(getenv("PVI_DMA16")))) ? 1 : 0;
+    if (L.dma16) {
+        rs = (summary[1] + 3) & ~3;
+        L.rs_magic = magic32((unsigned)rs);
+    }
     const long long need = (long long)summary[0] * rs + 128;
     if (need <= lds_budget_floats) {
         L.RS = rs;
@@ -2264,7 +2272,7 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
             h->J[b] = d->ext_J[b];
             h->own_J = false;
         } else {
-            HCHK(hipMalloc(&h->J[b], (size_t)h->stored * esz));
+            HCHK(hipMalloc(&h->J[b], (size_t)h->stored * esz + 64));  // + slack: 16-byte window loads may run past a row
             h->dev_allocs.push_back(h->J[b]);
             HCHK(hipMemsetAsync(h->J[b], 0, (size_t)h->stored * esz, h->stream));
         }

@@ -58,7 +58,8 @@ class HipSlab:
         tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
         nst = (self.store_rows[1] - self.store_rows[0]) * self.plane
         nown = (rows[1] - rows[0]) * self.plane
-        self.J = [torch.zeros(nst, dtype=tdt, device=self.dev) for _ in range(2)]
+        # (+16 elements of slack: the library's 16-byte window loads may run a few floats past the last stored row)
+        self.J = [torch.zeros(nst + 16, dtype=tdt, device=self.dev) for _ in range(2)]
         A = int(np.prod(grid_sys.u_grid_dim))
         self.pi = torch.zeros(nown, dtype=torch.uint8 if A <= 256 else torch.int16, device=self.dev)
         torch.cuda.synchronize(self.dev)        # the fills ran on torch's stream; the library works on its own streams
@@ -79,7 +80,8 @@ class HipSlab:
             a, b = piece
             return grid_sys._device_problem(
                 cost=cost, dtype=dtype, rows=(a, b), halo=(a - self.store_rows[0], self.store_rows[1] - b), device=device,
-                ext_J=[t.data_ptr() for t in self.J], ext_pi=self.pi.data_ptr() + (a - r0) * self.plane * self.pi.element_size())
+                ext_J=[t.data_ptr() for t in self.J], ext_pi=self.pi.data_ptr() + (a - r0) * self.plane * self.pi.element_size(),
+                flags=_native.FLAG_EXT_J_SLACK)
         self.handles = [make(pc) for pc in pieces]
         self.n_boundary = len(self.boundary)
         self.p = self.handles[-1]
