@@ -120,3 +120,27 @@ class DoublePendulum(_TwoLinkTerms, mechanical.MechanicalSystem):
         self.I1 = self.I2 = 0
         self.gravity = 9.81
         self.d1 = self.d2 = 0
+
+
+class Acrobot(DoublePendulum):
+    """Double pendulum with a single motor at the elbow (pendulum.py:699-735): B = [[0], [1]], |tau| <= 10.
+    Under-actuated, so it has no closed-form kernel; value iteration runs through the per-node tables of
+    MechanicalSystem.device_trig (PVI_DYN_NODE_2x1)."""
+
+    def __init__(self):
+        mechanical.MechanicalSystem.__init__(self, dof=2, actuators=1)
+        self.name = "Acrobot"
+        self.input_label[0], self.input_units[0] = "tau", "[Nm]"
+        self.u_lb[0], self.u_ub[0] = -10, +10
+        self.setparams()
+        self.l_domain = 3
+
+    def B(self, q):
+        return np.array([[0], [1]])
+
+    # the closed-form two-link kernel assumes both joints are driven: use the generic mechanical tier
+    def device_dynamics(self):
+        return mechanical.MechanicalSystem.device_dynamics(self)
+
+    def device_trig(self, x_level):
+        return mechanical.MechanicalSystem.device_trig(self, x_level)

@@ -542,7 +542,30 @@ def case_mintime():
     save("mintime_invpendulum_61x61x3", **out)
 
 
-CASES = dict(mintime=case_mintime, mountaincar=case_mountaincar, spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
+def case_acrobot():
+    """Acrobot (pendulum.py:699): under-actuated double pendulum, 9x9x9x9 grid, 5 torques, a few sweeps."""
+    with quiet():
+        s = pendulum.Acrobot()
+        s.x_ub = np.array([+2.0, +2.0, +4.0, +4.0]); s.x_lb = -s.x_ub
+        g = discretizer.GridDynamicSystem(s, [9, 9, 9, 9], [5], dt=0.05)
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+        q.INF = 200.0
+        out = _meta(s, g, q)
+        rng = np.random.default_rng(6)
+        X = rng.uniform(s.x_lb, s.x_ub, size=(64, 4)); U = rng.uniform(s.u_lb, s.u_ub, size=(64, 1))
+        out.update(f_X=X, f_U=U, f_dX=np.array([s.f(X[i], U[i]) for i in range(64)]))
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, q)
+        dp.save_time_history = False
+        for k in range(1, 7):
+            dp.initialize_backward_step(); dp.compute_backward_step(); dp.finalize_backward_step()
+            if k in (1, 6):
+                out["J_%d" % k] = dp.J.copy(); out["pi_%d" % k] = dp.pi.copy()
+                Q = np.sort(dp.Q, axis=1)
+                out["gap_%d" % k] = Q[:, 1] - Q[:, 0]
+    save("acrobot_9p4x5", **out)
+
+
+CASES = dict(acrobot=case_acrobot, mintime=case_mintime, mountaincar=case_mountaincar, spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
              policy_eval=case_policy_eval, cost_kat=case_cost_kat, grid_kat=case_grid_kat,
              pendulum_small=case_pendulum_small, config1=case_config1, lowdef=case_lowdef,
              pendulum_demo=case_pendulum_demo, cartpole_small=case_cartpole_small,

@@ -1016,3 +1016,32 @@ def test_closed_loop_rollout_of_a_node_tier_system_falls_back_to_the_host_loop()
     assert np.allclose(U[0, 0], ctl.c(np.array([-1.0, 0.0]), 0))
     assert np.allclose(X[0, 1], X[0, 0] + dp.sys.f(X[0, 0], U[0, 0], 0) * (20.0 / 2000))
     assert np.all(np.isfinite(X)) and np.all(X[:, :, 0] > -1.8) and np.all(X[:, :, 0] < 0.3)
+
+
+@pytest.mark.gpu
+def test_acrobot_runs_fused_through_node_tables_and_matches_reference():
+    """pendulum.py:699 Acrobot (two degrees of freedom, one actuator): generic mechanical tier PVI_DYN_NODE_2x1;
+    f bit for bit, J after 1 and 6 sweeps against the reference's run."""
+    from pyro_amd import _native
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import pendulum
+    from pyro_amd.planning import discretizer, dynamicprogramming
+    g = load("acrobot_9p4x5")
+    s = pendulum.Acrobot()
+    assert np.array_equal(np.array([s.f(x, u) for x, u in zip(g["f_X"], g["f_U"])]), g["f_dX"])
+    for dtype, tol in (("float64", 1e-12), ("float32", REL_F32)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            s = pendulum.Acrobot()
+            s.x_ub = np.array([+2.0, +2.0, +4.0, +4.0]); s.x_lb = -s.x_ub
+            grid = discretizer.GridDynamicSystem(s, [9, 9, 9, 9], [5], dt=0.05)
+            q = costfunction.QuadraticCostFunction.from_sys(s)
+            q.INF = 200.0
+            dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(grid, q, dtype=dtype)
+            dp.save_time_history = False
+            assert dp.tier == "fused" and dp._p.dynamics_id == _native.DYN_NODE_2x1
+            dp.compute_steps(1)
+            assert relerr(dp.J, g["J_1"]) < tol
+            dp.compute_steps(5)
+        assert relerr(dp.J, g["J_6"]) < tol
+        clear = g["gap_6"] > (1e-9 if dtype == "float64" else 1e-3)
+        assert np.array_equal(dp.pi[clear], g["pi_6"][clear])
