@@ -565,7 +565,33 @@ def case_acrobot():
     save("acrobot_9p4x5", **out)
 
 
-CASES = dict(acrobot=case_acrobot, mintime=case_mintime, mountaincar=case_mountaincar, spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
+def case_floatmass():
+    """float_mass_dp_optimal_controller.py reduced to 51x51x21: FloatingSingleMass (linear state space in mechanical
+    form), quadratic cost with R = 10, S = 10 I, INF 300."""
+    from pyro.dynamic import massspringdamper
+    with quiet():
+        s = massspringdamper.FloatingSingleMass()
+        s.x_ub[0] = 10.0; s.x_lb[0] = -10.0; s.x_lb[1] = -5.0; s.x_ub[1] = 5.0
+        s.u_ub[0] = 5.0; s.u_lb[0] = -5.0
+        g = discretizer.GridDynamicSystem(s, [51, 51], [21], 0.05)
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+        q.xbar = np.array([-0, 0]); q.INF = 300
+        q.R[0, 0] = 10.0; q.S[0, 0] = 10.0; q.S[1, 1] = 10.0
+        out = _meta(s, g, q)
+        rng = np.random.default_rng(8)
+        X = rng.uniform(s.x_lb, s.x_ub, size=(64, 2)); U = rng.uniform(s.u_lb, s.u_ub, size=(64, 1))
+        out.update(f_X=X, f_U=U, f_dX=np.array([s.f(X[i], U[i]) for i in range(64)]))
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, q)
+        dp.save_time_history = False
+        out.update(x_next_table=g.x_next_table, G=dp.G)
+        for k in range(1, 31):
+            dp.initialize_backward_step(); dp.compute_backward_step(); dp.finalize_backward_step()
+            if k in (1, 30):
+                out["J_%d" % k] = dp.J.copy(); out["pi_%d" % k] = dp.pi.copy()
+    save("floatmass_51x51x21", **out)
+
+
+CASES = dict(floatmass=case_floatmass, acrobot=case_acrobot, mintime=case_mintime, mountaincar=case_mountaincar, spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
              policy_eval=case_policy_eval, cost_kat=case_cost_kat, grid_kat=case_grid_kat,
              pendulum_small=case_pendulum_small, config1=case_config1, lowdef=case_lowdef,
              pendulum_demo=case_pendulum_demo, cartpole_small=case_cartpole_small,

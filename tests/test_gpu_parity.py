@@ -1045,3 +1045,40 @@ def test_acrobot_runs_fused_through_node_tables_and_matches_reference():
         assert relerr(dp.J, g["J_6"]) < tol
         clear = g["gap_6"] > (1e-9 if dtype == "float64" else 1e-3)
         assert np.array_equal(dp.pi[clear], g["pi_6"][clear])
+
+
+@pytest.mark.gpu
+def test_linear_state_space_mass_runs_fused_and_matches_reference():
+    """float_mass_dp_optimal_controller.py (reduced): FloatingSingleMass, a StateSpaceSystem in mechanical form, through
+    the per-node tables (a0 = velocity rows of A x, Bn = velocity rows of B): x_next bit for bit, J to 1e-13 (f64)."""
+    from pyro_amd import _native
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import massspringdamper
+    from pyro_amd.planning import discretizer, dynamicprogramming
+    g = load("floatmass_51x51x21")
+    s = massspringdamper.FloatingSingleMass()
+    assert np.array_equal(np.array([s.f(x, u) for x, u in zip(g["f_X"], g["f_U"])]), g["f_dX"])
+    for dtype, tol in (("float64", 1e-13), ("float32", REL_F32)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            s = massspringdamper.FloatingSingleMass()
+            s.x_ub[0], s.x_lb[0], s.x_lb[1], s.x_ub[1] = 10.0, -10.0, -5.0, 5.0
+            s.u_ub[0], s.u_lb[0] = 5.0, -5.0
+            grid = discretizer.GridDynamicSystem(s, [51, 51], [21], 0.05)
+            q = costfunction.QuadraticCostFunction.from_sys(s)
+            q.xbar, q.INF = np.array([-0, 0]), 300
+            q.R[0, 0] = 10.0; q.S[0, 0] = 10.0; q.S[1, 1] = 10.0
+            dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(grid, q, dtype=dtype)
+            dp.save_time_history = False
+            assert dp.tier == "fused" and dp._p.dynamics_id == _native.DYN_NODE_1x1
+            if dtype == "float64":
+                assert np.array_equal(grid.x_next_table, g["x_next_table"]) and relerr(dp.G, g["G"]) < 1e-14
+            dp.compute_steps(1)
+            assert relerr(dp.J, g["J_1"]) < tol
+            dp.compute_steps(29)
+        assert relerr(dp.J, g["J_30"]) < tol
+        if dtype == "float64":
+            assert (dp.pi != g["pi_30"]).mean() < 1e-3
+    # a state-space system that is not in mechanical form stays on the table tier
+    from pyro_amd.dynamic import statespace
+    A = np.array([[0.0, 1.0], [-1.0, -0.1]]); B = np.array([[0.5], [1.0]])
+    assert statespace.StateSpaceSystem(A, B, np.eye(2), np.zeros((2, 1))).device_dynamics() is None
