@@ -144,17 +144,23 @@ class GridDynamicSystem:
         self._lazy.update(x_next_table=xn, x_next_isok=ok)
         print("completed in %4.2f sec" % (time.time() - t0))
 
-    def _host_xnext_table(self):
-        """Generic systems: the reference's own loop over sys.f (arbitrary Python)."""
+    def _xnext_rows(self, lo, hi):
+        """The reference's own loop over sys.f (arbitrary Python) for nodes [lo, hi)."""
         s, X, U = self.sys, self.state_from_node_id, self.input_from_action_id
-        xn = np.zeros((self.nodes_n, self.actions_n, s.n))
-        ok = np.zeros((self.nodes_n, self.actions_n), dtype=bool)
-        for i in range(self.nodes_n):
+        xn = np.zeros((hi - lo, self.actions_n, s.n))
+        ok = np.zeros((hi - lo, self.actions_n), dtype=bool)
+        for i in range(lo, hi):
             for a in range(self.actions_n):
                 x_next = s.f(X[i], U[a]) * self.dt + X[i]
-                xn[i, a] = x_next
-                ok[i, a] = s.isavalidstate(x_next)
+                xn[i - lo, a] = x_next
+                ok[i - lo, a] = s.isavalidstate(x_next)
         return xn, ok
+
+    def _host_xnext_table(self):
+        """Generic systems: x_next / isok by calling sys.f and sys.isavalidstate cell by cell, as the reference does
+        (discretizer.py:342-376) -- the calls are independent, so large tables are split over the host cores."""
+        parts = host_parallel_rows(self, "_xnext_rows", self.nodes_n, self.nodes_n * self.actions_n)
+        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
 
     def compute_action_set_table(self):
         """action_isok[s,a] = sys.isavalidinput(x_s, u_a)."""
@@ -276,6 +282,36 @@ class GridDynamicSystem:
         """Colour map of input axis k selected by the policy (discretizer.py:826-834)."""
         return self.plot_grid_value(self.get_input_from_policy(pi, k), self.sys.input_label[k], i, j,
                                     self.sys.u_ub[k], self.sys.u_lb[k], cmap="bwr")
+
+
+# ---- host-side parallelism for the O(N*A) Python loops of the table tier -------------------------------------------
+_FORK_TARGET = {}
+
+
+def _fork_call(args):
+    name, lo, hi = args
+    return getattr(_FORK_TARGET["obj"], name)(lo, hi)
+
+
+def host_parallel_rows(obj, method, n_rows, n_calls, min_calls=200000):
+    """[obj.method(lo, hi) for consecutive row blocks], in forked worker processes when the job is large.
+    The workers inherit `obj` (system, cost function: arbitrary Python, not necessarily picklable) through fork and
+    never touch the GPU.  PYRO_AMD_HOST_WORKERS sets the worker count (0 or 1: serial)."""
+    import multiprocessing as mp
+    import os
+    workers = int(os.environ.get("PYRO_AMD_HOST_WORKERS", min(os.cpu_count() or 1, 64)))
+    if workers <= 1 or n_calls < min_calls or n_rows < 2 * workers:
+        return [getattr(obj, method)(0, n_rows)]
+    bounds = np.linspace(0, n_rows, 4 * workers + 1).astype(int)
+    jobs = [(method, int(a), int(b)) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+    _FORK_TARGET["obj"] = obj
+    try:
+        with mp.get_context("fork").Pool(workers) as pool:
+            return pool.map(_fork_call, jobs)
+    except Exception:                                   # no fork / no semaphores: the plain loop always works
+        return [getattr(obj, method)(0, n_rows)]
+    finally:
+        _FORK_TARGET.pop("obj", None)
 
 
 def device_dynamics_of(sys):

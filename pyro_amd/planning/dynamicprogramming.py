@@ -95,15 +95,22 @@ class DynamicProgramming:
         self._host = {}             # cached downloads: 'J', 'pi', 'J_next'
         self._dirty = False         # host J newer than the device copy
 
-    def _host_cost_table(self):
-        """compute_cost_lookuptable for arbitrary cf.g (dynamicprogramming.py:517-553)."""
+    def _cost_rows(self, lo, hi):
         g = self.grid_sys
         X, U = g.state_from_node_id, g.input_from_action_id
-        ok = g.action_isok & g.x_next_isok
-        G = np.full((g.nodes_n, g.actions_n), float(self.cf.INF))
+        ok = (g.action_isok & g.x_next_isok)[lo:hi]
+        G = np.full((hi - lo, g.actions_n), float(self.cf.INF))
         for s, a in zip(*np.nonzero(ok)):
-            G[s, a] = self.cf.g(X[s], U[a], self.t) * g.dt
+            G[s, a] = self.cf.g(X[lo + s], U[a], self.t) * g.dt
         return G
+
+    def _host_cost_table(self):
+        """compute_cost_lookuptable for arbitrary cf.g (dynamicprogramming.py:517-553); large tables are split over
+        the host cores like the x_next table."""
+        g = self.grid_sys
+        g.state_from_node_id, g.input_from_action_id, g.action_isok, g.x_next_isok     # materialise before forking
+        from pyro_amd.planning.discretizer import host_parallel_rows
+        return np.concatenate(host_parallel_rows(self, "_cost_rows", g.nodes_n, g.nodes_n * g.actions_n))
 
     # ------------------------------------------------------------------ J / pi live on the device
     def _flush(self):
