@@ -92,18 +92,33 @@ class MechanicalSystem(system.ContinuousDynamicSystem):
         return self._NODE_IDS[key], ()
 
     def device_trig(self, x_level):
-        """(a0 [N, dof], Bn [Nq, dof, m]) over the grid levels, C order (last axis fastest)."""
-        dof, m = self.dof, self.m
+        """(a0 [N, dof], Bn [Nq, dof, m]) over the grid levels, C order (last axis fastest).  O(N) calls of the model
+        terms; large grids are split over the host cores (pyro_amd.planning.discretizer.host_parallel_rows)."""
+        from pyro_amd.planning.discretizer import host_parallel_rows
+        dof = self.dof
+        nq = int(np.prod([len(l) for l in x_level[:dof]]))
+        nv = int(np.prod([len(l) for l in x_level[dof:]]))
+        self._trig_levels = x_level
+        try:
+            parts = host_parallel_rows(self, "_trig_rows", nq, nq * nv, min_calls=50000)
+        finally:
+            del self._trig_levels
+        a0 = np.concatenate([p[0] for p in parts])
+        return a0.reshape(nq * nv, dof), np.concatenate([p[1] for p in parts])
+
+    def _trig_rows(self, lo, hi):
+        x_level, dof, m = self._trig_levels, self.dof, self.m
         qdims = [len(l) for l in x_level[:dof]]
         vdims = [len(l) for l in x_level[dof:]]
-        nq, nv = int(np.prod(qdims)), int(np.prod(vdims))
-        a0 = np.empty((nq, nv, dof))
-        Bn = np.empty((nq, dof, m))
+        nv = int(np.prod(vdims))
+        a0 = np.empty((hi - lo, nv, dof))
+        Bn = np.empty((hi - lo, dof, m))
         zero = np.zeros(m)
-        for iq, qi in enumerate(np.ndindex(*qdims)):
+        for iq in range(lo, hi):
+            qi = np.unravel_index(iq, qdims)
             q = np.array([x_level[k][qi[k]] for k in range(dof)])
-            Bn[iq] = np.linalg.inv(self.H(q)) @ self.B(q)
+            Bn[iq - lo] = np.linalg.inv(self.H(q)) @ self.B(q)
             for iv, vi in enumerate(np.ndindex(*vdims)):
                 dq = np.array([x_level[dof + k][vi[k]] for k in range(dof)])
-                a0[iq, iv] = self.ddq(q, dq, zero)
-        return a0.reshape(nq * nv, dof), Bn
+                a0[iq - lo, iv] = self.ddq(q, dq, zero)
+        return a0, Bn
