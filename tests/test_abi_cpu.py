@@ -205,3 +205,26 @@ def test_node_tier_is_refused_when_ddq_is_not_affine_in_u():
     assert Plain(1).device_dynamics() is not None and Plain(2).device_dynamics() is not None
     assert Plain(2, actuators=1).device_dynamics() is not None
     assert mechanical.MechanicalSystem(3).device_dynamics() is None
+
+
+def test_host_parallel_rows_matches_the_serial_loop(monkeypatch):
+    """The forked-worker split of the table tier's host loops returns the same blocks, in order, as one serial call."""
+    from pyro_amd.planning import discretizer
+
+    class Work:
+        scale = 3.0                                     # (inherited by the workers through fork, not pickled)
+
+        def rows(self, lo, hi):
+            return np.arange(lo, hi, dtype=float) * self.scale, [(lambda v: v)(i) for i in range(lo, hi)]
+
+    w = Work()
+    monkeypatch.setenv("PYRO_AMD_HOST_WORKERS", "4")
+    par = discretizer.host_parallel_rows(w, "rows", 1000, 10 ** 9, min_calls=1)
+    monkeypatch.setenv("PYRO_AMD_HOST_WORKERS", "1")
+    ser = discretizer.host_parallel_rows(w, "rows", 1000, 10 ** 9, min_calls=1)
+    assert len(ser) == 1 and len(par) > 1
+    assert np.array_equal(np.concatenate([p[0] for p in par]), ser[0][0])
+    assert sum((p[1] for p in par), []) == ser[0][1]
+    # small jobs never fork
+    monkeypatch.setenv("PYRO_AMD_HOST_WORKERS", "4")
+    assert len(discretizer.host_parallel_rows(w, "rows", 1000, 10, min_calls=200000)) == 1

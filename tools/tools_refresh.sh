@@ -1,14 +1,17 @@
 #!/bin/bash
 # refresh the judged profiles: counters (4 pmc passes per workload) + kernel-trace stats of the bench command
 bash tools/tools_counters.sh c2 > gpurun_out/refresh_c2.log 2>&1
-# c3: pin the shape the set-up timing picks (15x34) so that the tuning sweeps of other shapes stay out of the averages
-export PVI_TV0=15 PVI_TV1=34 PVI_TV_EXACT=1
+# c3: pin the shape the set-up timing picks so that the tuning sweeps of other shapes stay out of the averages
+SHAPE=$(python tools/tools_describe.py c3 | grep -o 'tile=[0-9]*x[0-9]*' | head -1)
+TV0=$(echo $SHAPE | sed 's/tile=\([0-9]*\)x.*/\1/'); TV1=$(echo $SHAPE | sed 's/.*x//')
+echo "c3 shape $SHAPE" > gpurun_out/refresh_shape.log
+export PVI_TV0=$TV0 PVI_TV1=$TV1 PVI_TV_EXACT=1
 bash tools/tools_counters.sh c3 > gpurun_out/refresh_c3.log 2>&1
 unset PVI_TV0 PVI_TV1 PVI_TV_EXACT
 cd /tmp && export TMPDIR=/tmp
 for w in c2 c3; do
   S=$([ $w = c3 ] && echo "--steps 20 --warmup 2" || echo "")
-  if [ $w = c3 ]; then export PVI_TV0=15 PVI_TV1=34 PVI_TV_EXACT=1; fi
+  if [ $w = c3 ]; then export PVI_TV0=$TV0 PVI_TV1=$TV1 PVI_TV_EXACT=1; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/stats_$w -o s -- python /root/repo/bench.py --workload $w --no-cpu $S > /root/repo/gpurun_out/stats_$w.log 2>&1
   tail -1 /root/repo/gpurun_out/stats_$w.log | cut -c1-300
 done
