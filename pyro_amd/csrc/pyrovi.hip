@@ -1442,6 +1442,110 @@ __global__ __launch_bounds__(256) void k_sweep_table(DevP P, const double* __res
     sweep_finish(sc);
 }
 
+// =================================================================================================
+// tier B, float32 handles: the float64 tables are packed once (pvi_set_tables) into one record per cell,
+//   { int32 offset of corner 0 in the stored J buffer (-1: x_next outside the grid -> J_interp = 0),
+//     float32 fraction per axis, float32 G }            16 / 20 / 24 bytes for n = 2 / 3 / 4 (24 / 32 / 40 unpacked),
+// interval search, division and validity done in float64 exactly as k_sweep_table does them per sweep.  The sweep
+// is then a pure stream: load the record, gather 2^(n-1) corner pairs, lerp, Q = fma(alpha, J, G), first-minimum scan.
+// Fractions carry 6e-8 absolute error (they are rounded once from the float64 value), J is float32 storage anyway.
+// =================================================================================================
+template <int N>
+struct TabRec {
+    int base;
+    float y[N];
+    float G;
+};
+
+template <int N>
+__global__ __launch_bounds__(256) void k_table_pack(DevP P, const double* __restrict__ xnext, const double* __restrict__ Gt,
+                                                    const unsigned char* __restrict__ okt, TabRec<N>* __restrict__ out,
+                                                    long long cells, int* __restrict__ halo_err) {
+    const long long cell = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= cells) return;
+    bool inb = true;
+    long long b = 0;
+    TabRec<N> r;
+#pragma unroll
+    for (int d = 0; d < N; ++d) {
+        const double v = xnext[cell * N + d];
+        inb = inb && !(v < P.glo[d]) && !(v > P.ghi[d]);
+        double l0, l1;
+        const int ci = find_interval_lv(P.lev[d], P.dim[d], P.glo[d], P.inv_step[d], v, l0, l1);
+        r.y[d] = (float)((v - l0) / (l1 - l0));
+        int c = ci;
+        if (d == 0) {
+            if (inb && (c < P.store_begin || c + 1 >= P.store_end)) atomicOr(halo_err, 1);
+            c = min(max(c, P.store_begin), P.store_end - 2) - P.store_begin;
+        }
+        b += c * P.strd[d];
+    }
+    float G = (float)Gt[cell];
+    // base-class semantics (an invalid cell costs exactly INF, dynamicprogramming.py:225-233) = INF + alpha * 0
+    if (okt && !okt[cell]) {
+        inb = false;
+        G = (float)P.INF;
+    }
+    r.base = inb ? (int)b : -1;
+    r.G = G;
+    out[cell] = r;
+}
+
+template <int N, typename PI_T>
+__global__ __launch_bounds__(256) void k_sweep_tablep(DevP P, const TabRec<N>* __restrict__ rec, const float* __restrict__ Jin,
+                                                      float* __restrict__ Jout, PI_T* __restrict__ pi, float alpha,
+                                                      SweepCtl sc, int npb, int achunk) {
+    extern __shared__ __attribute__((aligned(16))) float qsf[];
+    if (sc.ctrl->done) return;
+    const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
+    const long long n0 = (long long)blockIdx.x * npb;
+    const int nn = (int)min((long long)npb, owned - n0);
+    float best = 0.f;
+    int arg = 0;
+    for (int a0 = 0; a0 < P.A; a0 += achunk) {
+        const int ac = min(achunk, P.A - a0);
+        const int ncell = nn * ac;
+        auto fetch = [&](int lc) {
+            const int ln = lc / ac, a = a0 + (lc - ln * ac);
+            return rec[(n0 + ln) * P.A + a];  // one chunk: consecutive lanes = consecutive records in memory
+        };
+        TabRec<N> cur, nxt;
+        if ((int)threadIdx.x < ncell) cur = fetch(threadIdx.x);
+        for (int lc = threadIdx.x; lc < ncell; lc += blockDim.x) {
+            if (lc + (int)blockDim.x < ncell) nxt = fetch(lc + blockDim.x);
+            float q = cur.G;
+            if (cur.base >= 0) q = fmaf(alpha, interp_f32<N>(Jin, P.strd, (long long)cur.base, cur.y), cur.G);
+            qsf[lc] = q;
+            cur = nxt;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nn) {
+            const float* row = qsf + threadIdx.x * ac;
+            for (int k = 0; k < ac; ++k) {
+                const float q = row[k];
+                if ((a0 == 0 && k == 0) || q < best) {
+                    best = q;
+                    arg = a0 + k;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
+    if ((int)threadIdx.x < nn) {
+        const long long o = n0 + threadIdx.x;
+        const long long self = o + (long long)(P.row_begin - P.store_begin) * P.plane;
+        Jout[self] = best;
+        pi[o] = (PI_T)arg;
+        const double jn = (double)best, d = jn - (double)Jin[self];
+        st_j = jn;
+        st_dmax = d;
+        st_ndmin = -d;
+    }
+    block_stats(st_j, st_dmax, st_ndmin, sc.slot);
+    sweep_finish(sc);
+}
+
 #include "sweep_spline.inc"
 
 // =================================================================================================
@@ -1673,6 +1777,8 @@ struct pvi_problem {
     double* d_xnext = nullptr;  // tier B tables
     double* d_G = nullptr;
     unsigned char* d_ok = nullptr;  // tier B base-class semantics (NULL: LUT semantics)
+    void* d_pack = nullptr;         // tier B, float32 handles: packed records (TabRec<n>), see k_table_pack
+    bool packed = false;
     double* stage = nullptr;  // f64 staging for up/download
     long long stage_n = 0;
     FastP F;                  // f32 fast path tables
@@ -2320,7 +2426,7 @@ extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
                        : h->lean_ok ? "lean"
                        : h->tile_ok ? "tile"
                        : (h->fast_ok && !is_node_dyn(h->d.dynamics_id)) ? "fast"
-                       : (h->d.dynamics_id == PVI_DYN_TABLE ? "table" : "exact-f32");
+                       : (h->d.dynamics_id == PVI_DYN_TABLE ? (h->packed ? "table-packed" : "table") : "exact-f32");
     snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d reach=%d opmag=%d note=%s",
              path, h->LP.TV0, h->LP.TV1, h->lean_grid.x, h->lean_grid.y, h->lean_grid.z, h->lean_block, h->lean_pw1,
              h->lean_lds, h->lean_ok ? h->LP.lsplit : h->F.lsplit, h->LP.tb_tile, h->lean_reach, h->lean_opmag, h->lean_why);
@@ -2626,6 +2732,29 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
                 const int A = h->A;
                 const int npb = A >= 2048 ? 1 : std::max(1, std::min(256, 2048 / A));
                 const int achunk = A >= 2048 ? 2048 : A;
+                if constexpr (sizeof(REAL) == 4) {
+                    if (h->packed) {
+                        const size_t ldsp = (size_t)npb * achunk * sizeof(float);
+                        const unsigned gp = (unsigned)((h->owned + npb - 1) / npb);
+                        sc.nblocks = gp;
+                        switch (h->P.n) {
+                            case 2:
+                                hipLaunchKernelGGL((k_sweep_tablep<2, PI_T>), gp, 256, ldsp, st, h->P, (const TabRec<2>*)h->d_pack,
+                                                   Jin, Jout, pi, (float)alpha, sc, npb, achunk);
+                                break;
+                            case 3:
+                                hipLaunchKernelGGL((k_sweep_tablep<3, PI_T>), gp, 256, ldsp, st, h->P, (const TabRec<3>*)h->d_pack,
+                                                   Jin, Jout, pi, (float)alpha, sc, npb, achunk);
+                                break;
+                            default:
+                                hipLaunchKernelGGL((k_sweep_tablep<4, PI_T>), gp, 256, ldsp, st, h->P, (const TabRec<4>*)h->d_pack,
+                                                   Jin, Jout, pi, (float)alpha, sc, npb, achunk);
+                                break;
+                        }
+                        HIPCHK(hipGetLastError());
+                        return PVI_OK;
+                    }
+                }
                 const int qs_doubles = (int)(((size_t)npb * achunk * sizeof(REAL) + 7) / 8);
                 int nlev = 0;
                 for (int d = 0; d < h->P.n; ++d) nlev += h->P.dim[d];
@@ -2985,6 +3114,34 @@ extern "C" int pvi_set_tables(pvi_handle h, const double* x_next, const double* 
         HIPCHK(hipMemcpyAsync(h->d_ok, ok, cells, hipMemcpyHostToDevice, h->stream));
     } else {
         h->d_ok = nullptr;  // (a previously uploaded mask stays allocated until destroy)
+    }
+    // float32 handles: pack the tables once (records of 16 / 20 / 24 bytes per cell instead of 24 / 32 / 40 in float64)
+    h->packed = false;
+    if (h->d.dtype == PVI_F32 && h->stored < 0x7fffffffLL && !getenv("PVI_NO_PACK")) {
+        const int N = h->P.n;
+        const size_t recsz = 4 + 4 * (size_t)N + 4;
+        if (!h->d_pack) {
+            void* p = nullptr;
+            HIPCHK(hipMalloc(&p, cells * recsz));
+            h->dev_allocs.push_back(p);
+            h->d_pack = p;
+        }
+        HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream));
+        const unsigned g = grid_for((long long)cells);
+        switch (N) {
+            case 2: hipLaunchKernelGGL((k_table_pack<2>), g, 256, 0, h->stream, h->P, h->d_xnext, h->d_G, h->d_ok, (TabRec<2>*)h->d_pack, (long long)cells, &h->ctrl->halo_err); break;
+            case 3: hipLaunchKernelGGL((k_table_pack<3>), g, 256, 0, h->stream, h->P, h->d_xnext, h->d_G, h->d_ok, (TabRec<3>*)h->d_pack, (long long)cells, &h->ctrl->halo_err); break;
+            default: hipLaunchKernelGGL((k_table_pack<4>), g, 256, 0, h->stream, h->P, h->d_xnext, h->d_G, h->d_ok, (TabRec<4>*)h->d_pack, (long long)cells, &h->ctrl->halo_err); break;
+        }
+        HIPCHK(hipGetLastError());
+        Ctrl c;
+        HIPCHK(hipMemcpyAsync(&c, h->ctrl, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (c.halo_err) {
+            HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream));
+            return fail(PVI_EHALO, "a table entry gathers outside the stored rows: halo too small");
+        }
+        h->packed = true;
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     return PVI_OK;
