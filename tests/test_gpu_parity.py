@@ -515,6 +515,17 @@ def test_table_tier_lut_and_base_semantics(name, sweeps):
                 assert relerr(h.get_J(), g[key % k]) < 1e-13
                 assert np.array_equal(h.get_pi(), g[pkey % k])
         h.close()
+        # float32 handle: the tables are packed into (offset, fractions, G) records; same semantics within 1e-5
+        h = _native.Problem(lv, ul, g["x_lb"], g["x_ub"], g["u_lb"], g["u_ub"], float(g["dt"]), dtype="float32",
+                            dynamics_id=_native.DYN_TABLE, table_inf=float(g["INF"]))
+        h.set_tables(g["x_next_table"], g["G"], mask)
+        assert "path=table-packed" in h.describe()
+        h.set_J(g["J0"])
+        h.sweep(sweeps, alpha, -1.0)
+        assert relerr(h.get_J(), g[key % sweeps]) < REL_F32
+        if "reachability" not in name:        # (0/1 costs: exact ties between actions, broken by float32 rounding)
+            assert (h.get_pi() != g[pkey % sweeps]).mean() < 0.02
+        h.close()
 
 
 def test_policy_evaluator_classes():
