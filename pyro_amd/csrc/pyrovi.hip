@@ -1494,46 +1494,70 @@ __global__ __launch_bounds__(256) void k_table_pack(DevP P, const double* __rest
 template <int N, typename PI_T>
 __global__ __launch_bounds__(256) void k_sweep_tablep(DevP P, const TabRec<N>* __restrict__ rec, const float* __restrict__ Jin,
                                                       float* __restrict__ Jout, PI_T* __restrict__ pi, float alpha,
-                                                      SweepCtl sc, int npb, int achunk) {
+                                                      SweepCtl sc, int npb, int achunk, int lpn_log2) {
     extern __shared__ __attribute__((aligned(16))) float qsf[];
     if (sc.ctrl->done) return;
     const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
     const long long n0 = (long long)blockIdx.x * npb;
     const int nn = (int)min((long long)npb, owned - n0);
+    const int T = blockDim.x;
+    // the first-minimum scan of a node's Q row is shared by 2^lpn_log2 neighbouring lanes (contiguous sub-ranges,
+    // merged with (value, index) comparisons over DPP-free xor shuffles)
+    const int lpn = 1 << lpn_log2, sn = threadIdx.x >> lpn_log2, sj = threadIdx.x & (lpn - 1);
     float best = 0.f;
     int arg = 0;
     for (int a0 = 0; a0 < P.A; a0 += achunk) {
         const int ac = min(achunk, P.A - a0);
         const int ncell = nn * ac;
-        auto fetch = [&](int lc) {
-            const int ln = lc / ac, a = a0 + (lc - ln * ac);
-            return rec[(n0 + ln) * P.A + a];  // one chunk: consecutive lanes = consecutive records in memory
-        };
+        const TabRec<N>* __restrict__ r0 = rec + n0 * P.A + a0;  // cell (ln, a) of this pass: r0[ln * A + a]
+        // (ln, a) of the thread's cell advance by T per trip: no division in the loop
+        const int dln = T / ac, da = T - dln * ac;
+        int ln = threadIdx.x / ac, a = threadIdx.x - ln * ac;
+        int ln1 = ln + dln, a1 = a + da;
+        if (a1 >= ac) { a1 -= ac; ++ln1; }
         TabRec<N> cur, nxt;
-        if ((int)threadIdx.x < ncell) cur = fetch(threadIdx.x);
-        for (int lc = threadIdx.x; lc < ncell; lc += blockDim.x) {
-            if (lc + (int)blockDim.x < ncell) nxt = fetch(lc + blockDim.x);
+        if ((int)threadIdx.x < ncell) cur = r0[(long long)ln * P.A + a];
+        for (int lc = threadIdx.x; lc < ncell; lc += T) {
+            if (lc + T < ncell) nxt = r0[(long long)ln1 * P.A + a1];
             float q = cur.G;
             if (cur.base >= 0) q = fmaf(alpha, interp_f32<N>(Jin, P.strd, (long long)cur.base, cur.y), cur.G);
             qsf[lc] = q;
             cur = nxt;
+            ln1 += dln;
+            a1 += da;
+            if (a1 >= ac) { a1 -= ac; ++ln1; }
         }
         __syncthreads();
-        if ((int)threadIdx.x < nn) {
-            const float* row = qsf + threadIdx.x * ac;
-            for (int k = 0; k < ac; ++k) {
+        if (sn < nn) {
+            const int per = (ac + lpn - 1) >> lpn_log2, k0 = sj * per, k1 = min(ac, k0 + per);
+            const float* row = qsf + sn * ac;
+            float m = INFINITY;
+            int mi = 0x7fffffff;
+            for (int k = k0; k < k1; ++k) {
                 const float q = row[k];
-                if ((a0 == 0 && k == 0) || q < best) {
-                    best = q;
-                    arg = a0 + k;
+                if (q < m || mi == 0x7fffffff) {
+                    m = q;
+                    mi = a0 + k;
                 }
+            }
+            for (int off = lpn >> 1; off > 0; off >>= 1) {  // all lanes of the group are active (sn < nn is group-uniform)
+                const float m2 = __shfl_xor(m, off, 64);
+                const int i2 = __shfl_xor(mi, off, 64);
+                if (i2 != 0x7fffffff && (mi == 0x7fffffff || m2 < m || (m2 == m && i2 < mi))) {
+                    m = m2;
+                    mi = i2;
+                }
+            }
+            if (mi != 0x7fffffff && (a0 == 0 || m < best)) {
+                best = m;
+                arg = mi;
             }
         }
         __syncthreads();
     }
     double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
-    if ((int)threadIdx.x < nn) {
-        const long long o = n0 + threadIdx.x;
+    if (sn < nn && sj == 0) {
+        const long long o = n0 + sn;
         const long long self = o + (long long)(P.row_begin - P.store_begin) * P.plane;
         Jout[self] = best;
         pi[o] = (PI_T)arg;
@@ -2737,18 +2761,20 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
                         const size_t ldsp = (size_t)npb * achunk * sizeof(float);
                         const unsigned gp = (unsigned)((h->owned + npb - 1) / npb);
                         sc.nblocks = gp;
+                        int lpn_log2 = 0;  // lanes that share the scan of one node: 256 threads over npb nodes
+                        while ((npb << (lpn_log2 + 1)) <= 256 && (2 << lpn_log2) <= 16 && (4 << lpn_log2) <= achunk) ++lpn_log2;
                         switch (h->P.n) {
                             case 2:
                                 hipLaunchKernelGGL((k_sweep_tablep<2, PI_T>), gp, 256, ldsp, st, h->P, (const TabRec<2>*)h->d_pack,
-                                                   Jin, Jout, pi, (float)alpha, sc, npb, achunk);
+                                                   Jin, Jout, pi, (float)alpha, sc, npb, achunk, lpn_log2);
                                 break;
                             case 3:
                                 hipLaunchKernelGGL((k_sweep_tablep<3, PI_T>), gp, 256, ldsp, st, h->P, (const TabRec<3>*)h->d_pack,
-                                                   Jin, Jout, pi, (float)alpha, sc, npb, achunk);
+                                                   Jin, Jout, pi, (float)alpha, sc, npb, achunk, lpn_log2);
                                 break;
                             default:
                                 hipLaunchKernelGGL((k_sweep_tablep<4, PI_T>), gp, 256, ldsp, st, h->P, (const TabRec<4>*)h->d_pack,
-                                                   Jin, Jout, pi, (float)alpha, sc, npb, achunk);
+                                                   Jin, Jout, pi, (float)alpha, sc, npb, achunk, lpn_log2);
                                 break;
                         }
                         HIPCHK(hipGetLastError());
