@@ -1324,7 +1324,7 @@ __global__ __launch_bounds__(256) void k_sweep_table(DevP P, const double* __res
                                                      const unsigned char* __restrict__ okt,
                                                      const REAL* __restrict__ Jin,
                                                      REAL* __restrict__ Jout, PI_T* __restrict__ pi, double alpha,
-                                                     SweepCtl sc, int npb, int achunk, int qs_doubles) {
+                                                     SweepCtl sc, int npb, int achunk, int qs_doubles, int lpn_log2) {
     extern __shared__ __attribute__((aligned(16))) double qs_raw[];
     REAL* qs = (REAL*)qs_raw;
     if (sc.ctrl->done) return;
@@ -1348,6 +1348,7 @@ __global__ __launch_bounds__(256) void k_sweep_table(DevP P, const double* __res
     const long long n0 = (long long)blockIdx.x * npb;
     const int nn = (int)min((long long)npb, owned - n0);
     const REAL alpha_r = (REAL)alpha;
+    const int lpn = 1 << lpn_log2, sn = threadIdx.x >> lpn_log2, sj = threadIdx.x & (lpn - 1);
     REAL best = (REAL)0;
     int arg = 0;
     for (int a0 = 0; a0 < P.A; a0 += achunk) {
@@ -1415,21 +1416,36 @@ __global__ __launch_bounds__(256) void k_sweep_table(DevP P, const double* __res
             cur = nxt;
         }
         __syncthreads();
-        if ((int)threadIdx.x < nn) {
-            const REAL* row = qs + threadIdx.x * ac;
-            for (int k = 0; k < ac; ++k) {
+        if (sn < nn) {  // first-minimum scan of the node's Q row, shared by 2^lpn_log2 neighbouring lanes
+            const int per = (ac + lpn - 1) >> lpn_log2, k0 = sj * per, k1 = min(ac, k0 + per);
+            const REAL* row = qs + sn * ac;
+            REAL m = (REAL)0;
+            int mi = 0x7fffffff;
+            for (int k = k0; k < k1; ++k) {
                 const REAL q = row[k];
-                if ((a0 == 0 && k == 0) || q < best) {
-                    best = q;
-                    arg = a0 + k;
+                if (mi == 0x7fffffff || q < m) {
+                    m = q;
+                    mi = a0 + k;
                 }
+            }
+            for (int off = lpn >> 1; off > 0; off >>= 1) {
+                const REAL m2 = __shfl_xor(m, off, 64);
+                const int i2 = __shfl_xor(mi, off, 64);
+                if (i2 != 0x7fffffff && (mi == 0x7fffffff || m2 < m || (m2 == m && i2 < mi))) {
+                    m = m2;
+                    mi = i2;
+                }
+            }
+            if (mi != 0x7fffffff && (a0 == 0 || m < best)) {
+                best = m;
+                arg = mi;
             }
         }
         __syncthreads();
     }
     double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
-    if ((int)threadIdx.x < nn) {
-        const long long o = n0 + threadIdx.x;
+    if (sn < nn && sj == 0) {
+        const long long o = n0 + sn;
         const long long self = o + (long long)(P.row_begin - P.store_begin) * P.plane;
         Jout[self] = best;
         pi[o] = (PI_T)arg;
@@ -2788,9 +2804,11 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
                 const size_t lds = (size_t)(qs_doubles + (lev_lds ? nlev : 0)) * 8;
                 const unsigned gt = (unsigned)((h->owned + npb - 1) / npb);
                 sc.nblocks = gt;
+                int lpn_t = 0;
+                while ((npb << (lpn_t + 1)) <= 256 && (2 << lpn_t) <= 16 && (4 << lpn_t) <= achunk) ++lpn_t;
 #define TABLE(NN, LL)                                                                                                   \
     hipLaunchKernelGGL((k_sweep_table<NN, REAL, PI_T, LL>), gt, 256, lds, st, h->P, h->d_xnext, h->d_G, h->d_ok, Jin, Jout, \
-                       pi, alpha, sc, npb, achunk, qs_doubles)
+                       pi, alpha, sc, npb, achunk, qs_doubles, lpn_t)
                 switch (h->P.n * 2 + lev_lds) {
                     case 4: TABLE(2, false); break;
                     case 5: TABLE(2, true); break;
