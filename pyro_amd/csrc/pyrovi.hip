@@ -1793,6 +1793,10 @@ static int fail(int code, const char* fmt, ...) {
                         hipGetErrorString(e_), __FILE__, __LINE__);                                     \
     } while (0)
 
+// dynamic-LDS ceiling set on the windowed kernels: a per-FUNCTION attribute, so it is always raised to the device
+// maximum (160 KiB per CU on gfx950) -- a per-handle value would be lowered by the next handle with a smaller window
+#define PVI_LDS_MAX (160 * 1024)
+
 static inline unsigned grid_for(long long n, int block = 256) { return (unsigned)((n + block - 1) / block); }
 
 static const int MAX_BATCH = 1024;  // sweeps per device-side batch (stats slots)
@@ -2656,7 +2660,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     {                                                                                                               \
         auto kfn = k_sweep_march<DYN, PI_T>;                                                                        \
         if (!h->march_lds_attr && h->march_lds > 48 * 1024) {                                                       \
-            HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->march_lds)); \
+            HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PVI_LDS_MAX)); \
             h->march_lds_attr = true;                                                                               \
         }                                                                                                           \
         hipLaunchKernelGGL(kfn, dim3(sc.nblocks), h->march_block, h->march_lds, st, h->P, h->LP, h->MP, h->F.act, h->LP.actc, Jin, \
@@ -2677,7 +2681,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     {                                                                                                               \
         auto kfn = k_sweep_lean<DYN, PI_T, U, NP>;                                                                  \
         if (!h->lean_lds_attr && h->lean_lds > 48 * 1024) {                                                         \
-            HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lean_lds)); \
+            HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PVI_LDS_MAX)); \
             h->lean_lds_attr = true;                                                                                \
         }                                                                                                           \
         hipLaunchKernelGGL(kfn, h->lean_grid, h->lean_block, h->lean_lds, st, h->P, h->LP, h->F.act, h->LP.actc, Jin, Jout, pi, al, \
