@@ -2774,8 +2774,11 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             {
                 // nodes per workgroup / actions per LDS chunk: ~2048 cells of Q (<= 16 KB) per pass
                 const int A = h->A;
-                const int npb = A >= 2048 ? 1 : std::max(1, std::min(256, 2048 / A));
-                const int achunk = A >= 2048 ? 2048 : A;
+                // cells of Q per pass: 16 KB of LDS either way (float32 packed: 4096 cells, float64: 2048)
+                int tab_cells = (sizeof(REAL) == 4 && h->packed) ? 4096 : 2048;
+                if (const char* e = getenv("PVI_TAB_CELLS")) tab_cells = std::max(256, atoi(e));  // experiments
+                const int npb = A >= tab_cells ? 1 : std::max(1, std::min(256, tab_cells / A));
+                const int achunk = A >= tab_cells ? tab_cells : A;
                 if constexpr (sizeof(REAL) == 4) {
                     if (h->packed) {
                         const size_t ldsp = (size_t)npb * achunk * sizeof(float);
