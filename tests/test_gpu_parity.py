@@ -1093,3 +1093,15 @@ def test_linear_state_space_mass_runs_fused_and_matches_reference():
     from pyro_amd.dynamic import statespace
     A = np.array([[0.0, 1.0], [-1.0, -0.1]]); B = np.array([[0.5], [1.0]])
     assert statespace.StateSpaceSystem(A, B, np.eye(2), np.zeros((2, 1))).device_dynamics() is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("script,args", [("tools_fuzz.py", ["30", "101"]), ("tools_fuzz_tiers.py", ["30", "102"])])
+def test_randomised_consistency_runs(script, args):
+    """A short run of the randomised checks under tools/: float32 kernels against the float64 kernel on random problems
+    (1e-5), and the table tier fed with the fused tier's tables against the fused sweeps (bit for bit)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)] + args, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
