@@ -1472,6 +1472,7 @@ struct TabRec {
     float y[N];
     float G;
 };
+#define TAB_NB 1024  // nodes per block of the packed layout (four workgroups of 256 lanes read one block)
 
 template <int N>
 __global__ __launch_bounds__(256) void k_table_pack(DevP P, const double* __restrict__ xnext, const double* __restrict__ Gt,
@@ -1504,76 +1505,54 @@ __global__ __launch_bounds__(256) void k_table_pack(DevP P, const double* __rest
     }
     r.base = inb ? (int)b : -1;
     r.G = G;
-    out[cell] = r;
+    // records are stored action-major inside blocks of TAB_NB nodes: [block][action][node in block], so that the sweep's
+    // lanes (= consecutive nodes) read consecutive records for one action and keep their running minimum in registers
+    const long long o = cell / P.A;
+    const int a = (int)(cell - o * P.A);
+    out[((o / TAB_NB) * P.A + a) * TAB_NB + (o % TAB_NB)] = r;
 }
 
 template <int N, typename PI_T>
 __global__ __launch_bounds__(256) void k_sweep_tablep(DevP P, const TabRec<N>* __restrict__ rec, const float* __restrict__ Jin,
-                                                      float* __restrict__ Jout, PI_T* __restrict__ pi, float alpha,
-                                                      SweepCtl sc, int npb, int achunk, int lpn_log2) {
-    extern __shared__ __attribute__((aligned(16))) float qsf[];
+                                                         float* __restrict__ Jout, PI_T* __restrict__ pi, float alpha,
+                                                         SweepCtl sc) {
     if (sc.ctrl->done) return;
     const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
-    const long long n0 = (long long)blockIdx.x * npb;
-    const int nn = (int)min((long long)npb, owned - n0);
-    const int T = blockDim.x;
-    // the first-minimum scan of a node's Q row is shared by 2^lpn_log2 neighbouring lanes (contiguous sub-ranges,
-    // merged with (value, index) comparisons over DPP-free xor shuffles)
-    const int lpn = 1 << lpn_log2, sn = threadIdx.x >> lpn_log2, sj = threadIdx.x & (lpn - 1);
-    float best = 0.f;
-    int arg = 0;
-    for (int a0 = 0; a0 < P.A; a0 += achunk) {
-        const int ac = min(achunk, P.A - a0);
-        const int ncell = nn * ac;
-        const TabRec<N>* __restrict__ r0 = rec + n0 * P.A + a0;  // cell (ln, a) of this pass: r0[ln * A + a]
-        // (ln, a) of the thread's cell advance by T per trip: no division in the loop
-        const int dln = T / ac, da = T - dln * ac;
-        int ln = threadIdx.x / ac, a = threadIdx.x - ln * ac;
-        int ln1 = ln + dln, a1 = a + da;
-        if (a1 >= ac) { a1 -= ac; ++ln1; }
-        TabRec<N> cur, nxt;
-        if ((int)threadIdx.x < ncell) cur = r0[(long long)ln * P.A + a];
-        for (int lc = threadIdx.x; lc < ncell; lc += T) {
-            if (lc + T < ncell) nxt = r0[(long long)ln1 * P.A + a1];
-            float q = cur.G;
-            if (cur.base >= 0) q = fmaf(alpha, interp_f32<N>(Jin, P.strd, (long long)cur.base, cur.y), cur.G);
-            qsf[lc] = q;
-            cur = nxt;
-            ln1 += dln;
-            a1 += da;
-            if (a1 >= ac) { a1 -= ac; ++ln1; }
-        }
-        __syncthreads();
-        if (sn < nn) {
-            const int per = (ac + lpn - 1) >> lpn_log2, k0 = sj * per, k1 = min(ac, k0 + per);
-            const float* row = qsf + sn * ac;
-            float m = INFINITY;
-            int mi = 0x7fffffff;
-            for (int k = k0; k < k1; ++k) {
-                const float q = row[k];
-                if (q < m || mi == 0x7fffffff) {
-                    m = q;
-                    mi = a0 + k;
-                }
-            }
-            for (int off = lpn >> 1; off > 0; off >>= 1) {  // all lanes of the group are active (sn < nn is group-uniform)
-                const float m2 = __shfl_xor(m, off, 64);
-                const int i2 = __shfl_xor(mi, off, 64);
-                if (i2 != 0x7fffffff && (mi == 0x7fffffff || m2 < m || (m2 == m && i2 < mi))) {
-                    m = m2;
-                    mi = i2;
-                }
-            }
-            if (mi != 0x7fffffff && (a0 == 0 || m < best)) {
-                best = m;
-                arg = mi;
-            }
-        }
-        __syncthreads();
-    }
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    // lane = node, actions in order: consecutive lanes read consecutive records; no LDS, no scan, first minimum by '<'
+    const TabRec<N>* __restrict__ r = rec + (o / TAB_NB) * P.A * TAB_NB + (o % TAB_NB);
     double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
-    if (sn < nn && sj == 0) {
-        const long long o = n0 + sn;
+    if (o < owned) {
+        // The stream is bound by (bytes in flight per wave) / latency: actions are taken four at a time, the next
+        // four records requested before the current four are gathered and evaluated.
+        constexpr int U = 4;
+        float best = INFINITY;
+        int arg = -1;
+        TabRec<N> cur[U], nxt[U];
+        const int A = P.A;
+#pragma unroll
+        for (int k = 0; k < U; ++k)
+            if (k < A) cur[k] = r[(long long)k * TAB_NB];
+        for (int a0 = 0; a0 < A; a0 += U) {
+#pragma unroll
+            for (int k = 0; k < U; ++k)
+                if (a0 + U + k < A) nxt[k] = r[(long long)(a0 + U + k) * TAB_NB];
+            float q[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                q[k] = cur[k].G;
+                if (a0 + k < A && cur[k].base >= 0)
+                    q[k] = fmaf(alpha, interp_f32<N>(Jin, P.strd, (long long)cur[k].base, cur[k].y), cur[k].G);
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k)
+                if (a0 + k < A && (arg < 0 || q[k] < best)) {
+                    best = q[k];
+                    arg = a0 + k;
+                }
+#pragma unroll
+            for (int k = 0; k < U; ++k) cur[k] = nxt[k];
+        }
         const long long self = o + (long long)(P.row_begin - P.store_begin) * P.plane;
         Jout[self] = best;
         pi[o] = (PI_T)arg;
@@ -2774,30 +2753,27 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             {
                 // nodes per workgroup / actions per LDS chunk: ~2048 cells of Q (<= 16 KB) per pass
                 const int A = h->A;
-                // cells of Q per pass: 16 KB of LDS either way (float32 packed: 4096 cells, float64: 2048)
-                int tab_cells = (sizeof(REAL) == 4 && h->packed) ? 4096 : 2048;
+                // cells of Q per pass (16 KB of LDS in float64)
+                int tab_cells = 2048;
                 if (const char* e = getenv("PVI_TAB_CELLS")) tab_cells = std::max(256, atoi(e));  // experiments
                 const int npb = A >= tab_cells ? 1 : std::max(1, std::min(256, tab_cells / A));
                 const int achunk = A >= tab_cells ? tab_cells : A;
                 if constexpr (sizeof(REAL) == 4) {
                     if (h->packed) {
-                        const size_t ldsp = (size_t)npb * achunk * sizeof(float);
-                        const unsigned gp = (unsigned)((h->owned + npb - 1) / npb);
+                        const unsigned gp = (unsigned)((h->owned + 255) / 256);
                         sc.nblocks = gp;
-                        int lpn_log2 = 0;  // lanes that share the scan of one node: 256 threads over npb nodes
-                        while ((npb << (lpn_log2 + 1)) <= 256 && (2 << lpn_log2) <= 16 && (4 << lpn_log2) <= achunk) ++lpn_log2;
                         switch (h->P.n) {
                             case 2:
-                                hipLaunchKernelGGL((k_sweep_tablep<2, PI_T>), gp, 256, ldsp, st, h->P, (const TabRec<2>*)h->d_pack,
-                                                   Jin, Jout, pi, (float)alpha, sc, npb, achunk, lpn_log2);
+                                hipLaunchKernelGGL((k_sweep_tablep<2, PI_T>), gp, 256, 0, st, h->P, (const TabRec<2>*)h->d_pack, Jin,
+                                                   Jout, pi, (float)alpha, sc);
                                 break;
                             case 3:
-                                hipLaunchKernelGGL((k_sweep_tablep<3, PI_T>), gp, 256, ldsp, st, h->P, (const TabRec<3>*)h->d_pack,
-                                                   Jin, Jout, pi, (float)alpha, sc, npb, achunk, lpn_log2);
+                                hipLaunchKernelGGL((k_sweep_tablep<3, PI_T>), gp, 256, 0, st, h->P, (const TabRec<3>*)h->d_pack, Jin,
+                                                   Jout, pi, (float)alpha, sc);
                                 break;
                             default:
-                                hipLaunchKernelGGL((k_sweep_tablep<4, PI_T>), gp, 256, ldsp, st, h->P, (const TabRec<4>*)h->d_pack,
-                                                   Jin, Jout, pi, (float)alpha, sc, npb, achunk, lpn_log2);
+                                hipLaunchKernelGGL((k_sweep_tablep<4, PI_T>), gp, 256, 0, st, h->P, (const TabRec<4>*)h->d_pack, Jin,
+                                                   Jout, pi, (float)alpha, sc);
                                 break;
                         }
                         HIPCHK(hipGetLastError());
@@ -3173,7 +3149,8 @@ extern "C" int pvi_set_tables(pvi_handle h, const double* x_next, const double* 
         const size_t recsz = 4 + 4 * (size_t)N + 4;
         if (!h->d_pack) {
             void* p = nullptr;
-            HIPCHK(hipMalloc(&p, cells * recsz));
+            const size_t nblk = ((size_t)h->owned + TAB_NB - 1) / TAB_NB;
+            HIPCHK(hipMalloc(&p, nblk * TAB_NB * (size_t)h->A * recsz));  // whole blocks of TAB_NB nodes
             h->dev_allocs.push_back(p);
             h->d_pack = p;
         }
