@@ -201,7 +201,9 @@ def table_tier_reference(cfg, sweeps=10):
     h.close()
     # bytes the sweep streams per cell: float32 handles read the packed records (int32 offset, n float32 fractions,
     # float32 G), float64 handles the reference's float64 tables
-    byt = G.size * ((4 + 4 * xn.shape[2] + 4) if packed else (xn.shape[2] * 8 + 8))
+    n_ = xn.shape[2]
+    rec = (4 + 4 * n_ + 4) if cfg["dtype"] == "float32" else (8 + 8 * n_ + 8)
+    byt = G.size * (rec if packed else (n_ * 8 + 8))
     return {"kernel": "k_sweep_tablep (packed records)" if packed else "k_sweep_table", "ms_per_step": ms, "table_bytes_per_step": byt, "cells_per_sec": G.size / (ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": byt / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}

@@ -1459,37 +1459,39 @@ __global__ __launch_bounds__(256) void k_sweep_table(DevP P, const double* __res
 }
 
 // =================================================================================================
-// tier B, float32 handles: the float64 tables are packed once (pvi_set_tables) into one record per cell,
+// tier B, packed: the reference-layout tables are packed once (pvi_set_tables) into one record per cell,
 //   { int32 offset of corner 0 in the stored J buffer (-1: x_next outside the grid -> J_interp = 0),
-//     float32 fraction per axis, float32 G }            16 / 20 / 24 bytes for n = 2 / 3 / 4 (24 / 32 / 40 unpacked),
-// interval search, division and validity done in float64 exactly as k_sweep_table does them per sweep.  The sweep
-// is then a pure stream: load the record, gather 2^(n-1) corner pairs, lerp, Q = fma(alpha, J, G), first-minimum scan.
-// Fractions carry 6e-8 absolute error (they are rounded once from the float64 value), J is float32 storage anyway.
+//     one fraction per axis, G }        float32 handles: 16 / 20 / 24 bytes for n = 2 / 3 / 4 (tables: 24 / 32 / 40),
+//                                       float64 handles: 32 / 40 / 48 bytes, fractions and G kept in float64,
+// with interval search, division and validity done in float64 exactly as k_sweep_table does them per sweep -- so the
+// float64 records reproduce that kernel bit for bit while the sweep becomes a pure stream: record, 2^(n-1) corner-pair
+// gathers, the interpolation sum, Q, running first minimum.  Records are stored action-major inside blocks of TAB_NB
+// nodes ([block][action][node]): lane = node, consecutive lanes read consecutive records, no LDS, no scan.
 // =================================================================================================
-template <int N>
+template <int N, typename REAL>
 struct TabRec {
     int base;
-    float y[N];
-    float G;
+    REAL y[N];
+    REAL G;
 };
 #define TAB_NB 1024  // nodes per block of the packed layout (four workgroups of 256 lanes read one block)
 
-template <int N>
+template <int N, typename REAL>
 __global__ __launch_bounds__(256) void k_table_pack(DevP P, const double* __restrict__ xnext, const double* __restrict__ Gt,
-                                                    const unsigned char* __restrict__ okt, TabRec<N>* __restrict__ out,
+                                                    const unsigned char* __restrict__ okt, TabRec<N, REAL>* __restrict__ out,
                                                     long long cells, int* __restrict__ halo_err) {
     const long long cell = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= cells) return;
     bool inb = true;
     long long b = 0;
-    TabRec<N> r;
+    TabRec<N, REAL> r;
 #pragma unroll
     for (int d = 0; d < N; ++d) {
         const double v = xnext[cell * N + d];
         inb = inb && !(v < P.glo[d]) && !(v > P.ghi[d]);
         double l0, l1;
         const int ci = find_interval_lv(P.lev[d], P.dim[d], P.glo[d], P.inv_step[d], v, l0, l1);
-        r.y[d] = (float)((v - l0) / (l1 - l0));
+        r.y[d] = (REAL)((v - l0) / (l1 - l0));
         int c = ci;
         if (d == 0) {
             if (inb && (c < P.store_begin || c + 1 >= P.store_end)) atomicOr(halo_err, 1);
@@ -1497,38 +1499,36 @@ __global__ __launch_bounds__(256) void k_table_pack(DevP P, const double* __rest
         }
         b += c * P.strd[d];
     }
-    float G = (float)Gt[cell];
+    REAL G = (REAL)Gt[cell];
     // base-class semantics (an invalid cell costs exactly INF, dynamicprogramming.py:225-233) = INF + alpha * 0
     if (okt && !okt[cell]) {
         inb = false;
-        G = (float)P.INF;
+        G = (REAL)P.INF;
     }
     r.base = inb ? (int)b : -1;
     r.G = G;
-    // records are stored action-major inside blocks of TAB_NB nodes: [block][action][node in block], so that the sweep's
-    // lanes (= consecutive nodes) read consecutive records for one action and keep their running minimum in registers
     const long long o = cell / P.A;
     const int a = (int)(cell - o * P.A);
     out[((o / TAB_NB) * P.A + a) * TAB_NB + (o % TAB_NB)] = r;
 }
 
-template <int N, typename PI_T>
-__global__ __launch_bounds__(256) void k_sweep_tablep(DevP P, const TabRec<N>* __restrict__ rec, const float* __restrict__ Jin,
-                                                         float* __restrict__ Jout, PI_T* __restrict__ pi, float alpha,
-                                                         SweepCtl sc) {
+template <int N, typename REAL, typename PI_T>
+__global__ __launch_bounds__(256) void k_sweep_tablep(DevP P, const TabRec<N, REAL>* __restrict__ rec,
+                                                      const REAL* __restrict__ Jin, REAL* __restrict__ Jout,
+                                                      PI_T* __restrict__ pi, double alpha, SweepCtl sc) {
     if (sc.ctrl->done) return;
     const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
     const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
-    // lane = node, actions in order: consecutive lanes read consecutive records; no LDS, no scan, first minimum by '<'
-    const TabRec<N>* __restrict__ r = rec + (o / TAB_NB) * P.A * TAB_NB + (o % TAB_NB);
+    const TabRec<N, REAL>* __restrict__ r = rec + (o / TAB_NB) * P.A * TAB_NB + (o % TAB_NB);
+    const REAL alpha_r = (REAL)alpha;
     double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
     if (o < owned) {
-        // The stream is bound by (bytes in flight per wave) / latency: actions are taken four at a time, the next
-        // four records requested before the current four are gathered and evaluated.
-        constexpr int U = 4;
-        float best = INFINITY;
+        // The stream is bound by (bytes in flight per wave) / latency: actions are taken U at a time, the next U records
+        // requested before the current ones are gathered and evaluated.
+        constexpr int U = sizeof(REAL) == 4 ? 4 : 2;
+        REAL best = (REAL)0;
         int arg = -1;
-        TabRec<N> cur[U], nxt[U];
+        TabRec<N, REAL> cur[U], nxt[U];
         const int A = P.A;
 #pragma unroll
         for (int k = 0; k < U; ++k)
@@ -1537,12 +1537,23 @@ __global__ __launch_bounds__(256) void k_sweep_tablep(DevP P, const TabRec<N>* _
 #pragma unroll
             for (int k = 0; k < U; ++k)
                 if (a0 + U + k < A) nxt[k] = r[(long long)(a0 + U + k) * TAB_NB];
-            float q[U];
+            REAL q[U];
 #pragma unroll
             for (int k = 0; k < U; ++k) {
                 q[k] = cur[k].G;
-                if (a0 + k < A && cur[k].base >= 0)
-                    q[k] = fmaf(alpha, interp_f32<N>(Jin, P.strd, (long long)cur[k].base, cur[k].y), cur[k].G);
+                if (a0 + k < A && cur[k].base >= 0) {
+                    if constexpr (sizeof(REAL) == 8) {
+                        double yd[N];
+#pragma unroll
+                        for (int d = 0; d < N; ++d) yd[d] = cur[k].y[d];
+                        q[k] = cur[k].G + alpha_r * interp_f64<N>((const double*)Jin, P.strd, (long long)cur[k].base, yd);
+                    } else {
+                        float yf[N];
+#pragma unroll
+                        for (int d = 0; d < N; ++d) yf[d] = cur[k].y[d];
+                        q[k] = fmaf(alpha_r, interp_f32<N>((const float*)Jin, P.strd, (long long)cur[k].base, yf), cur[k].G);
+                    }
+                }
             }
 #pragma unroll
             for (int k = 0; k < U; ++k)
@@ -2758,27 +2769,25 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
                 if (const char* e = getenv("PVI_TAB_CELLS")) tab_cells = std::max(256, atoi(e));  // experiments
                 const int npb = A >= tab_cells ? 1 : std::max(1, std::min(256, tab_cells / A));
                 const int achunk = A >= tab_cells ? tab_cells : A;
-                if constexpr (sizeof(REAL) == 4) {
-                    if (h->packed) {
-                        const unsigned gp = (unsigned)((h->owned + 255) / 256);
-                        sc.nblocks = gp;
-                        switch (h->P.n) {
-                            case 2:
-                                hipLaunchKernelGGL((k_sweep_tablep<2, PI_T>), gp, 256, 0, st, h->P, (const TabRec<2>*)h->d_pack, Jin,
-                                                   Jout, pi, (float)alpha, sc);
-                                break;
-                            case 3:
-                                hipLaunchKernelGGL((k_sweep_tablep<3, PI_T>), gp, 256, 0, st, h->P, (const TabRec<3>*)h->d_pack, Jin,
-                                                   Jout, pi, (float)alpha, sc);
-                                break;
-                            default:
-                                hipLaunchKernelGGL((k_sweep_tablep<4, PI_T>), gp, 256, 0, st, h->P, (const TabRec<4>*)h->d_pack, Jin,
-                                                   Jout, pi, (float)alpha, sc);
-                                break;
-                        }
-                        HIPCHK(hipGetLastError());
-                        return PVI_OK;
+                if (h->packed) {
+                    const unsigned gp = (unsigned)((h->owned + 255) / 256);
+                    sc.nblocks = gp;
+                    switch (h->P.n) {
+                        case 2:
+                            hipLaunchKernelGGL((k_sweep_tablep<2, REAL, PI_T>), gp, 256, 0, st, h->P,
+                                               (const TabRec<2, REAL>*)h->d_pack, Jin, Jout, pi, alpha, sc);
+                            break;
+                        case 3:
+                            hipLaunchKernelGGL((k_sweep_tablep<3, REAL, PI_T>), gp, 256, 0, st, h->P,
+                                               (const TabRec<3, REAL>*)h->d_pack, Jin, Jout, pi, alpha, sc);
+                            break;
+                        default:
+                            hipLaunchKernelGGL((k_sweep_tablep<4, REAL, PI_T>), gp, 256, 0, st, h->P,
+                                               (const TabRec<4, REAL>*)h->d_pack, Jin, Jout, pi, alpha, sc);
+                            break;
                     }
+                    HIPCHK(hipGetLastError());
+                    return PVI_OK;
                 }
                 const int qs_doubles = (int)(((size_t)npb * achunk * sizeof(REAL) + 7) / 8);
                 int nlev = 0;
@@ -3142,11 +3151,12 @@ extern "C" int pvi_set_tables(pvi_handle h, const double* x_next, const double* 
     } else {
         h->d_ok = nullptr;  // (a previously uploaded mask stays allocated until destroy)
     }
-    // float32 handles: pack the tables once (records of 16 / 20 / 24 bytes per cell instead of 24 / 32 / 40 in float64)
+    // pack the tables once into per-cell records (k_table_pack); PVI_NO_PACK=1 keeps the per-sweep table kernel
     h->packed = false;
-    if (h->d.dtype == PVI_F32 && h->stored < 0x7fffffffLL && !getenv("PVI_NO_PACK")) {
+    if (h->stored < 0x7fffffffLL && !getenv("PVI_NO_PACK")) {
         const int N = h->P.n;
-        const size_t recsz = 4 + 4 * (size_t)N + 4;
+        const bool f64 = h->d.dtype == PVI_F64;
+        const size_t recsz = f64 ? (8 + 8 * (size_t)N + 8) : (4 + 4 * (size_t)N + 4);
         if (!h->d_pack) {
             void* p = nullptr;
             const size_t nblk = ((size_t)h->owned + TAB_NB - 1) / TAB_NB;
@@ -3156,11 +3166,19 @@ extern "C" int pvi_set_tables(pvi_handle h, const double* x_next, const double* 
         }
         HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream));
         const unsigned g = grid_for((long long)cells);
+#define PACK(NN)                                                                                                        \
+    if (f64)                                                                                                            \
+        hipLaunchKernelGGL((k_table_pack<NN, double>), g, 256, 0, h->stream, h->P, h->d_xnext, h->d_G, h->d_ok,         \
+                           (TabRec<NN, double>*)h->d_pack, (long long)cells, &h->ctrl->halo_err);                       \
+    else                                                                                                                \
+        hipLaunchKernelGGL((k_table_pack<NN, float>), g, 256, 0, h->stream, h->P, h->d_xnext, h->d_G, h->d_ok,          \
+                           (TabRec<NN, float>*)h->d_pack, (long long)cells, &h->ctrl->halo_err);
         switch (N) {
-            case 2: hipLaunchKernelGGL((k_table_pack<2>), g, 256, 0, h->stream, h->P, h->d_xnext, h->d_G, h->d_ok, (TabRec<2>*)h->d_pack, (long long)cells, &h->ctrl->halo_err); break;
-            case 3: hipLaunchKernelGGL((k_table_pack<3>), g, 256, 0, h->stream, h->P, h->d_xnext, h->d_G, h->d_ok, (TabRec<3>*)h->d_pack, (long long)cells, &h->ctrl->halo_err); break;
-            default: hipLaunchKernelGGL((k_table_pack<4>), g, 256, 0, h->stream, h->P, h->d_xnext, h->d_G, h->d_ok, (TabRec<4>*)h->d_pack, (long long)cells, &h->ctrl->halo_err); break;
+            case 2: PACK(2) break;
+            case 3: PACK(3) break;
+            default: PACK(4) break;
         }
+#undef PACK
         HIPCHK(hipGetLastError());
         Ctrl c;
         HIPCHK(hipMemcpyAsync(&c, h->ctrl, sizeof(c), hipMemcpyDeviceToHost, h->stream));

@@ -24,8 +24,10 @@ for ok in (None, (xo & ao)):
     h.sweep(20, 1.0, -1.0)
     ms = h.last_sweep_ms() / 20
     cells = G.size
-    packed = "packed" in h.describe() if False else (dtype == "float32")
-    byt = cells * ((4 + 4 * xn.shape[2] + 4) if packed else (xn.shape[2] * 8 + 8 + (1 if ok is not None else 0)))
+    packed = "table-packed" in h.describe()
+    n_ = xn.shape[2]
+    rec = (4 + 4 * n_ + 4) if dtype == "float32" else (8 + 8 * n_ + 8)           # packed record (f64: padded offset)
+    byt = cells * (rec if packed else (n_ * 8 + 8 + (1 if ok is not None else 0)))
     print("%s %s  %.3f ms/sweep  %.1f G cells/s  table stream %.0f GB/s  rel err vs fused %.1e" %
           (spec, "base" if ok is not None else "LUT ", ms, cells / ms / 1e6, byt / ms / 1e6, err), flush=True)
     h.close()
