@@ -228,3 +228,36 @@ def test_host_parallel_rows_matches_the_serial_loop(monkeypatch):
     # small jobs never fork
     monkeypatch.setenv("PYRO_AMD_HOST_WORKERS", "4")
     assert len(discretizer.host_parallel_rows(w, "rows", 1000, 10, min_calls=200000)) == 1
+
+
+def test_acrobot_and_mass_mirrors_match_reference_f():
+    """pendulum.py:699 Acrobot and massspringdamper.py FloatingSingleMass: f bit for bit on the reference's samples, and
+    the tier each one selects."""
+    from pyro_amd import _native
+    from pyro_amd.dynamic import massspringdamper, pendulum
+    g = np.load(os.path.join(GOLDEN, "acrobot_9p4x5.npz"))
+    s = pendulum.Acrobot()
+    assert np.array_equal(np.array([s.f(x, u) for x, u in zip(g["f_X"], g["f_U"])]), g["f_dX"])
+    assert s.device_dynamics() == (_native.DYN_NODE_2x1, ()) and s.m == 1 and s.dof == 2
+    g = np.load(os.path.join(GOLDEN, "floatmass_51x51x21.npz"))
+    s = massspringdamper.FloatingSingleMass()
+    assert np.array_equal(np.array([s.f(x, u) for x, u in zip(g["f_X"], g["f_U"])]), g["f_dX"])
+    assert s.device_dynamics() == (_native.DYN_NODE_1x1, ())
+    a0, Bn = s.device_trig([np.linspace(-1, 1, 5), np.linspace(-2, 2, 4)])
+    assert a0.shape == (20, 1) and Bn.shape == (5, 1, 1) and np.all(a0 == 0.0) and np.all(Bn == 1.0)
+    assert massspringdamper.SingleMass(2.0, 3.0, 0.5).device_dynamics() == (_native.DYN_NODE_1x1, ())
+
+
+def test_time_cost_device_parameters():
+    from pyro_amd.analysis import costfunction
+    tcf = costfunction.TimeCostFunction(np.array([0.5, 0.0]))
+    tcf.INF, tcf.EPS = 10.0, 0.1
+    d = tcf.device_cost()
+    assert d["kind"] == "time" and d["INF"] == 10.0 and d["EPS"] == 0.1 and np.array_equal(d["xbar"], [0.5, 0.0])
+    assert tcf.g(np.array([0.5, 0.05]), np.zeros(1)) == 0 and tcf.g(np.array([0.5, 0.2]), np.zeros(1)) == 1
+
+    class Mine(costfunction.TimeCostFunction):
+        def g(self, x, u, t=0):
+            return 2
+
+    assert Mine(np.zeros(2)).device_cost() is None       # subclasses change g: table tier
