@@ -2455,7 +2455,8 @@ extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
                  h->d.dynamics_id == PVI_DYN_TABLE ? "table" : "fused", h->SP.chunk0, h->SP.warm0, h->SP.chunk1, h->SP.warm1);
         return PVI_OK;
     }
-    const char* path = h->d.dtype == PVI_F64 ? "exact-f64"
+    const char* path = h->d.dynamics_id == PVI_DYN_TABLE ? (h->packed ? "table-packed" : "table")
+                       : h->d.dtype == PVI_F64 ? "exact-f64"
                        : h->march_ok ? "march"
                        : h->lean_ok ? "lean"
                        : h->tile_ok ? "tile"
