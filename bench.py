@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+HBM_STREAM_GBS = 6300.0      # measured on the GPU box: pure 16-byte read stream, tools/hbmbench.hip (6.0-6.7 TB/s)
 VALU_PEAK_F32_TFLOPS = 157.3
 
 
@@ -162,6 +163,7 @@ def run_single(args):
         "jstar_rel_err_vs_cpu": rel_err, "jstar_rel_err_after_sweeps": n_cmp,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": ctr.get("hbm_bytes_per_launch"),
+                     "measured_read_stream_GBps": HBM_STREAM_GBS,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                      "note": "nominal: the sweep is instruction-issue bound (A actions per node on 9 B of traffic), see roofline_issue"},
         "roofline_issue": None if not ctr.get("valu_insts_per_launch") else issue_roofline(ctr, kern_ms, N * A),
@@ -206,7 +208,8 @@ def table_tier_reference(cfg, sweeps=10):
     byt = G.size * (rec if packed else (n_ * 8 + 8))
     return {"kernel": "k_sweep_tablep (packed records)" if packed else "k_sweep_table", "ms_per_step": ms, "table_bytes_per_step": byt, "cells_per_sec": G.size / (ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": byt / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                         "frac": byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "measured_read_stream_GBps": HBM_STREAM_GBS,
+                         "frac_of_measured_stream": byt / (ms * 1e-3) / 1e9 / HBM_STREAM_GBS}}
 
 
 def sharded_reference(name="c4", sweeps=5):
