@@ -28,6 +28,12 @@ def lib():
         L.vio_sweep.restype = None
         L.vio_sweep.argtypes = [C.POINTER(vio_problem), _dp, _dp, C.POINTER(C.c_int64), C.c_double, C.c_int64,
                                 C.c_int64, C.c_int32, C.c_int32]
+        L.vio_sweeps.restype = None
+        L.vio_sweeps.argtypes = [C.POINTER(vio_problem), _dp, _dp, C.POINTER(C.c_int64), C.c_double, C.c_int32,
+                                 C.c_int32, C.c_int32]
+        L.vio_q_at.restype = None
+        L.vio_q_at.argtypes = [C.POINTER(vio_problem), _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int64,
+                               C.c_double, _dp, _dp]
         L.vio_terminal_cost.restype = None
         L.vio_terminal_cost.argtypes = [C.POINTER(vio_problem), _dp]
         L.vio_max_threads.restype = C.c_int
@@ -85,5 +91,45 @@ class CProblem:
         return out[node0:node1], pi[node0:node1]
 
 
+    def sweeps(self, J0, nsweeps, alpha=1.0, f32=False, threads=0, work=None):
+        """`nsweeps` whole-grid backups in one persistent parallel region (bench.py's cpu_baseline).  `work` =
+        (J0, J1, pi) buffers from a previous call are reused, so repeated timings allocate nothing."""
+        if work is None:
+            work = (np.array(J0, dtype=np.float64), np.zeros(self.p.nodes_n), np.zeros(self.p.nodes_n, dtype=np.int64))
+        a, b, pi = work
+        lib().vio_sweeps(C.byref(self.d), _ptr(a), _ptr(b), pi.ctypes.data_as(C.POINTER(C.c_int64)), float(alpha),
+                         int(nsweeps), int(f32), int(threads))
+        return (b if nsweeps & 1 else a), pi, work
+
+    def q_at(self, J, nodes, actions, alpha=1.0):
+        """(Q[s, a_s], min_a Q[s, a]) for the given node ids and one action each."""
+        Jin = np.ascontiguousarray(J, dtype=np.float64)
+        nodes = np.ascontiguousarray(nodes, dtype=np.int64)
+        actions = np.ascontiguousarray(actions, dtype=np.int64)
+        q, qmin = np.empty(len(nodes)), np.empty(len(nodes))
+        i64 = C.POINTER(C.c_int64)
+        lib().vio_q_at(C.byref(self.d), _ptr(Jin), nodes.ctypes.data_as(i64), actions.ctypes.data_as(i64), len(nodes),
+                       float(alpha), _ptr(q), _ptr(qmin))
+        return q, qmin
+
+
 def max_threads():
     return lib().vio_max_threads()
+
+
+def physical_cores():
+    """Distinct (package, core) pairs this process may run on: SMT siblings share one set of execution units, so the
+    all-cores baseline uses one thread per physical core."""
+    import os
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        return os.cpu_count() or 1
+    seen = set()
+    for cpu in allowed:
+        try:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % cpu
+            seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        except OSError:
+            seen.add(("?", cpu))
+    return max(1, len(seen))

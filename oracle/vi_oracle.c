@@ -154,52 +154,119 @@ static double interp(const vio_problem* P, const double* J, const int64_t* strd,
     return val;
 }
 
+/* per-node prologue shared by the sweep and the Q probes */
+typedef struct {
+    double x[4], tr[4], gx;
+    int on_target;
+} node_ctx;
+
+static void node_prologue(const vio_problem* P, int64_t node, node_ctx* c) {
+    const int n = P->n;
+    int idx[4];
+    int64_t rem = node;
+    for (int d = n - 1; d >= 0; --d) { idx[d] = (int)(rem % P->dim[d]); rem /= P->dim[d]; }
+    double dx[4];
+    for (int d = 0; d < n; ++d) { c->x[d] = P->lev[d][idx[d]]; dx[d] = c->x[d] - P->xbar[d]; }
+    state_trig(P, idx, c->tr);
+    c->gx = quad_form(P->Q, dx, n);
+    c->on_target = P->ontarget && (l2norm(dx, n) < P->EPS);
+}
+
+/* Q[s,a] = G + alpha * J_interp(x_next)   (dynamicprogramming.py:534-549, :567) */
+static double cell_q(const vio_problem* P, const int64_t* strd, const double* Jin, const node_ctx* c, int a,
+                     double alpha) {
+    const int n = P->n, m = P->m, dof = n / 2;
+    const double* x = c->x;
+    double u[2], du[2], acc[2], xn[4];
+    int aok = 1;
+    for (int k = 0; k < m; ++k) {
+        u[k] = P->utab[a * m + k];
+        du[k] = u[k] - P->ubar[k];
+        aok &= !(u[k] < P->u_lb[k]) & !(u[k] > P->u_ub[k]);
+    }
+    accel(P, x, c->tr, u, acc);
+    int ok = aok;
+    for (int i = 0; i < dof; ++i) {
+        xn[i] = x[dof + i] * P->dt + x[i];
+        xn[dof + i] = acc[i] * P->dt + x[dof + i];
+    }
+    for (int d = 0; d < n; ++d) ok &= !(xn[d] < P->lb[d]) & !(xn[d] > P->ub[d]);
+    double g = c->on_target ? 0.0 : (c->gx + quad_form(P->R, du, m));
+    double G = ok ? g * P->dt : P->INF;
+    return G + alpha * interp(P, Jin, strd, xn);
+}
+
+static void grid_strides(const vio_problem* P, int64_t* strd) {
+    int64_t s = 1;
+    for (int d = P->n - 1; d >= 0; --d) { strd[d] = s; s *= P->dim[d]; }
+}
+
+static void backup_node(const vio_problem* P, const int64_t* strd, const double* Jin, double* Jout, int64_t* pi,
+                        double alpha, int64_t node, int32_t f32_storage) {
+    node_ctx c;
+    node_prologue(P, node, &c);
+    double best = 0.0;
+    int64_t arg = 0;
+    for (int a = 0; a < P->A; ++a) {
+        double q = cell_q(P, strd, Jin, &c, a, alpha);
+        if (a == 0 || q < best) { best = q; arg = a; }  /* first minimum, np.argmin (:569-570) */
+    }
+    Jout[node] = f32_storage ? (double)(float)best : best;
+    if (pi) pi[node] = arg;
+}
+
 /* one Bellman backup of nodes [node0, node1); J is the full grid; f32_storage rounds J_out to float */
 void vio_sweep(const vio_problem* P, const double* Jin, double* Jout, int64_t* pi, double alpha, int64_t node0,
                int64_t node1, int32_t f32_storage, int32_t nthreads) {
-    const int n = P->n, m = P->m, dof = n / 2;
     int64_t strd[4];
-    int64_t s = 1;
-    for (int d = n - 1; d >= 0; --d) { strd[d] = s; s *= P->dim[d]; }
-    double gu[65536 / 64]; /* not used for big A: computed per action below */
-    (void)gu;
+    grid_strides(P, strd);
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
 #pragma omp parallel for schedule(static)
-    for (int64_t node = node0; node < node1; ++node) {
-        int idx[4];
-        int64_t rem = node;
-        for (int d = n - 1; d >= 0; --d) { idx[d] = (int)(rem % P->dim[d]); rem /= P->dim[d]; }
-        double x[4], dx[4], tr[4];
-        for (int d = 0; d < n; ++d) { x[d] = P->lev[d][idx[d]]; dx[d] = x[d] - P->xbar[d]; }
-        state_trig(P, idx, tr);
-        double gx = quad_form(P->Q, dx, n);
-        int on_target = P->ontarget && (l2norm(dx, n) < P->EPS);
-        double best = 0.0;
-        int64_t arg = 0;
-        for (int a = 0; a < P->A; ++a) {
-            double u[2], du[2], acc[2], xn[4];
-            int aok = 1;
-            for (int k = 0; k < m; ++k) {
-                u[k] = P->utab[a * m + k];
-                du[k] = u[k] - P->ubar[k];
-                aok &= !(u[k] < P->u_lb[k]) & !(u[k] > P->u_ub[k]);
-            }
-            accel(P, x, tr, u, acc);
-            int ok = aok;
-            for (int i = 0; i < dof; ++i) {
-                xn[i] = x[dof + i] * P->dt + x[i];
-                xn[dof + i] = acc[i] * P->dt + x[dof + i];
-            }
-            for (int d = 0; d < n; ++d) ok &= !(xn[d] < P->lb[d]) & !(xn[d] > P->ub[d]);
-            double g = on_target ? 0.0 : (gx + quad_form(P->R, du, m));
-            double G = ok ? g * P->dt : P->INF;
-            double q = G + alpha * interp(P, Jin, strd, xn);
-            if (a == 0 || q < best) { best = q; arg = a; }
+    for (int64_t node = node0; node < node1; ++node) backup_node(P, strd, Jin, Jout, pi, alpha, node, f32_storage);
+}
+
+/* `nsweeps` whole-grid backups inside ONE parallel region (bench.py's cpu_baseline): the two caller-owned buffers
+   ping-pong, no allocation and no thread start-up between sweeps, nodes dealt in contiguous static blocks so that
+   every thread keeps writing the pages it touched first.  The result is in J[nsweeps & 1]. */
+void vio_sweeps(const vio_problem* P, double* J0, double* J1, int64_t* pi, double alpha, int32_t nsweeps,
+                int32_t f32_storage, int32_t nthreads) {
+    int64_t strd[4], N = 1;
+    grid_strides(P, strd);
+    for (int d = 0; d < P->n; ++d) N *= P->dim[d];
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+    {
+        for (int k = 0; k < nsweeps; ++k) {
+            const double* Jin = (k & 1) ? J1 : J0;
+            double* Jout = (k & 1) ? J0 : J1;
+#pragma omp for schedule(static)
+            for (int64_t node = 0; node < N; ++node) backup_node(P, strd, Jin, Jout, pi, alpha, node, f32_storage);
+            /* (implicit barrier: the next sweep reads what every thread wrote) */
         }
-        Jout[node] = f32_storage ? (double)(float)best : best;
-        pi[node] = arg;
+    }
+}
+
+/* Q of chosen (node, action) pairs and the minimum over the actions of the same nodes: the tests' policy check
+   (regret of a policy = Q[s, pi_test[s]] - min_a Q[s, a]) at sizes the NumPy oracle is slow at */
+void vio_q_at(const vio_problem* P, const double* Jin, const int64_t* nodes, const int64_t* actions, int64_t count,
+              double alpha, double* q_out, double* qmin_out) {
+    int64_t strd[4];
+    grid_strides(P, strd);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < count; ++i) {
+        node_ctx c;
+        node_prologue(P, nodes[i], &c);
+        q_out[i] = cell_q(P, strd, Jin, &c, (int)actions[i], alpha);
+        double best = 0.0;
+        for (int a = 0; a < P->A; ++a) {
+            double q = cell_q(P, strd, Jin, &c, a, alpha);
+            if (a == 0 || q < best) best = q;
+        }
+        qmin_out[i] = best;
     }
 }
 

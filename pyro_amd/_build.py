@@ -8,6 +8,12 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 SRC = [os.path.join(PKG, "csrc", "pyrovi.hip")]
 HDR = [os.path.join(ROOT, "include", "pyrovi.h")]
+
+
+def sources():
+    """Every file the library is compiled from: the translation unit, the kernel files it includes, the C ABI header."""
+    csrc = os.path.join(PKG, "csrc")
+    return sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".inc", ".h"))) + HDR
 OUT = os.path.join(PKG, "libpyrovi.so")
 # -ffp-contract=off: the f64 kernels mirror the reference's NumPy arithmetic (no implicit FMA)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
@@ -24,7 +30,7 @@ def up_to_date():
     if not os.path.exists(OUT):
         return False
     t = os.path.getmtime(OUT)
-    return all(os.path.getmtime(p) <= t for p in SRC + HDR)
+    return all(os.path.getmtime(p) <= t for p in sources())
 
 
 def build(force=False, verbose=True):

@@ -14,6 +14,7 @@ PVI_MAX_N, PVI_MAX_M, PVI_MAX_TRIG = 4, 2, 4
 PVI_F32, PVI_F64 = 0, 1
 DYN_TABLE, DYN_PENDULUM, DYN_CARTPOLE, DYN_TWOLINK = 0, 1, 2, 3
 DYN_NODE_1x1, DYN_NODE_2x1, DYN_NODE_2x2 = 4, 5, 6        # any MechanicalSystem through per-node tables
+CLOSED_FORM_IDS = (DYN_PENDULUM, DYN_CARTPOLE, DYN_TWOLINK)    # dynamics pvi_eval_f / pvi_rollout can evaluate anywhere
 COST_TABLE, COST_QUADRATIC, COST_TIME = 0, 1, 2
 INTERP_LINEAR, INTERP_BICUBIC_SPLINE = 0, 1
 PVI_EHALO = -5

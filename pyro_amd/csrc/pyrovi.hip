@@ -2462,9 +2462,10 @@ extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
                        : h->tile_ok ? "tile"
                        : (h->fast_ok && !is_node_dyn(h->d.dynamics_id)) ? "fast"
                        : (h->d.dynamics_id == PVI_DYN_TABLE ? (h->packed ? "table-packed" : "table") : "exact-f32");
-    snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d reach=%d opmag=%d note=%s",
+    snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d reach=%d opmag=%d note=%s",
              path, h->LP.TV0, h->LP.TV1, h->lean_grid.x, h->lean_grid.y, h->lean_grid.z, h->lean_block, h->lean_pw1,
-             h->lean_lds, h->lean_ok ? h->LP.lsplit : h->F.lsplit, h->LP.tb_tile, h->lean_reach, h->lean_opmag, h->lean_why);
+             h->lean_lds, h->lean_ok ? h->LP.lsplit : h->F.lsplit, h->LP.tb_tile, h->lean_ok ? h->LP.dma16 : 0, h->lean_reach,
+             h->lean_opmag, h->lean_why);
     return PVI_OK;
 }
 

@@ -37,10 +37,17 @@ class CartPole(mechanical.MechanicalSystem):
         return np.zeros(2)
 
     # device: c = [m1+m2, m2*lcg, m2*lcg^2, -m2*lcg, m2*g*lcg]   (kernel: Dyn<PVI_DYN_CARTPOLE>)
+    def _closed_form(self):
+        return self.stock_model(CartPole, self._MODEL_TERMS)
+
     def device_dynamics(self):
+        if not self._closed_form():          # overridden model terms: per-node tables of the generic tier
+            return mechanical.MechanicalSystem.device_dynamics(self)
         return _native.DYN_CARTPOLE, [float(self.m1 + self.m2), float(self.m2 * self.lcg),
                                       float(self.m2 * self.lcg ** 2), float(-self.m2 * self.lcg),
                                       float(self.m2 * self.gravity * self.lcg)]
 
     def device_trig(self, x_level):
+        if not self._closed_form():
+            return mechanical.MechanicalSystem.device_trig(self, x_level)
         return np.cos(x_level[1]), np.sin(x_level[1])

@@ -54,3 +54,6 @@ class TwoLinkManipulator(_TwoLinkTerms, Manipulator):
         c12, s12 = np.cos(q[0] + q[1]), np.sin(q[0] + q[1])
         return np.array([[self.l1 * c1 + self.l2 * c12, self.l2 * c12],
                          [-self.l1 * s1 - self.l2 * s12, -self.l2 * s12]])
+
+
+TwoLinkManipulator._STOCK_OWNER = TwoLinkManipulator

@@ -75,10 +75,12 @@ class MechanicalSystem(system.ContinuousDynamicSystem):
     # O(N) evaluations of the model terms (the reference's look-up tables cost O(N*A) calls of f); the sweeps then
     # run in the fused kernels like the closed-form systems.  Subclasses with closed-form kernels override both.
     _NODE_IDS = {(1, 1): 4, (2, 1): 5, (2, 2): 6}          # _native.DYN_NODE_1x1 / 2x1 / 2x2
+    _MODEL_TERMS = ("H", "C", "B", "g", "d", "ddq", "f", "x2q", "q2x")   # what a closed-form kernel hard-codes
 
     def device_dynamics(self):
         key = (self.dof, self.m)
-        if type(self).f is not MechanicalSystem.f or key not in self._NODE_IDS or self.n != 2 * self.dof:
+        if (not self.stock_model(MechanicalSystem, ("f", "x2q", "q2x")) or key not in self._NODE_IDS
+                or self.n != 2 * self.dof):
             return None
         # the u-dependence must be exactly B(q) u (a subclass may have redefined ddq): spot check
         rng = np.random.default_rng(0)

@@ -38,13 +38,21 @@ class SinglePendulum(mechanical.MechanicalSystem):
     def d(self, q, dq):
         return np.array([self.d1 * dq[0]])
 
-    # device: c = [1/H, signed m1*g*lc1, d1]   (kernel: Dyn<PVI_DYN_PENDULUM>)
+    # device: c = [1/H, signed m1*g*lc1, d1]   (kernel: Dyn<PVI_DYN_PENDULUM>).  The kernel hard-codes THIS class's
+    # H, C, B, g, d: a subclass or instance that overrides any of them runs through the per-node tables instead.
+    def _closed_form(self):
+        return self.stock_model(SinglePendulum, self._MODEL_TERMS)
+
     def device_dynamics(self):
+        if not self._closed_form():
+            return mechanical.MechanicalSystem.device_dynamics(self)
         H = self.m1 * self.lc1 ** 2 + self.I1
         gc = self.m1 * self.gravity * self.lc1
         return _native.DYN_PENDULUM, [1.0 / float(H), self._gravity_sign * gc, float(self.d1)]
 
     def device_trig(self, x_level):
+        if not self._closed_form():
+            return mechanical.MechanicalSystem.device_trig(self, x_level)
         return (np.sin(x_level[0]),)
 
 
@@ -88,8 +96,19 @@ class _TwoLinkTerms:
     def d(self, q, dq):
         return np.array([self.d1 * dq[0], self.d2 * dq[1]])
 
-    # device: c = [k0, m2, k1, k2, I2, k3, k4, g1c, g2c, d1, d2]   (kernel: Dyn<PVI_DYN_TWOLINK>)
+    # device: c = [k0, m2, k1, k2, I2, k3, k4, g1c, g2c, d1, d2]   (kernel: Dyn<PVI_DYN_TWOLINK>).  The kernel
+    # hard-codes the terms above with B = I and no end-effector force: any override (H, C, B, g, d, ddq, f, and for
+    # manipulators J / f_ext) sends the system to the per-node tables of the generic mechanical tier.
+    _STOCK_OWNER = None         # set below: the concrete class whose model the kernel implements
+
+    def _closed_form(self):
+        names = self._MODEL_TERMS + (("J", "f_ext") if hasattr(self, "f_ext") else ())
+        owner = next(c for c in type(self).__mro__ if c.__dict__.get("_STOCK_OWNER") is c)
+        return self.stock_model(owner, names)
+
     def device_dynamics(self):
+        if not self._closed_form():
+            return mechanical.MechanicalSystem.device_dynamics(self)
         k0 = self.m1 * self.lc1 ** 2 + self.I1
         k1 = self.l1 ** 2 + self.lc2 ** 2
         k2 = 2 * self.l1 * self.lc2
@@ -101,6 +120,8 @@ class _TwoLinkTerms:
                                      (k0, self.m2, k1, k2, self.I2, k3, k4, g1c, g2c, self.d1, self.d2)]
 
     def device_trig(self, x_level):
+        if not self._closed_form():
+            return mechanical.MechanicalSystem.device_trig(self, x_level)
         q0, q1 = x_level[0], x_level[1]
         return np.sin(q0), np.cos(q1), np.sin(q1), np.sin(q0[:, None] + q1[None, :])
 
@@ -120,6 +141,9 @@ class DoublePendulum(_TwoLinkTerms, mechanical.MechanicalSystem):
         self.I1 = self.I2 = 0
         self.gravity = 9.81
         self.d1 = self.d2 = 0
+
+
+DoublePendulum._STOCK_OWNER = DoublePendulum
 
 
 class Acrobot(DoublePendulum):

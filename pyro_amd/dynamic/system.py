@@ -88,11 +88,21 @@ class ContinuousDynamicSystem:
         """Host-side sin/cos tables over the grid levels consumed by the kernels."""
         return ()
 
+    def stock_model(self, owner, names):
+        """True when every method in `names` is the one class `owner` resolves: no subclass and no instance
+        override.  The closed-form kernels hard-code `owner`'s model, so anything else must not use them."""
+        for nm in names:
+            if nm in self.__dict__ or getattr(type(self), nm, None) is not getattr(owner, nm, None):
+                return False
+        return True
+
     def f_batch(self, X, U):
-        """dX[b] = f(X[b], U[b]); on the GPU for systems with device_dynamics()."""
-        dd = self.device_dynamics()
+        """dX[b] = f(X[b], U[b]); on the GPU for systems with a closed-form kernel (per-node tables only cover
+        the grid nodes), otherwise the plain loop over self.f."""
+        from pyro_amd.planning.discretizer import device_dynamics_of
+        from pyro_amd import _native
+        dd = device_dynamics_of(self)
         X, U = np.atleast_2d(X), np.atleast_2d(U)
-        if dd is not None:
-            from pyro_amd import _native
+        if dd is not None and dd[0] in _native.CLOSED_FORM_IDS:
             return _native.eval_f(dd[0], dd[1], X, U)
         return np.array([self.f(X[i], U[i]) for i in range(X.shape[0])])

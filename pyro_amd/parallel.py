@@ -129,7 +129,10 @@ class HipSlab:
         return self.rows_view(self.rows[0], self.rows[1] - self.rows[0]).double().cpu().numpy()
 
     def owned_pi(self):
-        return self.pi.cpu().numpy().astype(np.int64)
+        pi = self.pi.cpu().numpy()
+        if pi.dtype == np.int16:                # the library writes uint16 action ids into the int16 tensor
+            pi = pi.view(np.uint16)
+        return pi.astype(np.int64)
 
     def describe(self):
         return "%s pieces=%s" % (self.p.describe(), self.boundary + ([self.interior] if self.interior else []))

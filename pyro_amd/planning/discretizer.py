@@ -41,6 +41,8 @@ class GridDynamicSystem:
         if len(self.x_grid_dim) != self.sys.n or len(self.u_grid_dim) != self.sys.m:
             raise ValueError("grid dimensions do not match the system dimensions")
         self._lazy.clear()
+        self.__dict__.pop("_trig", None)
+        self.__dict__.pop("_trig_key", None)
         self.discretize_state_space()
         self.discretize_input_space()
         print("\nGenerating a mesh for:", self.sys.name)
@@ -117,14 +119,19 @@ class GridDynamicSystem:
             dyn_id, params, trig = _native.DYN_TABLE, (), ()
         else:
             dyn_id, params = dd
-            if "_trig" not in self.__dict__:        # (per-node tables of generic mechanical systems are O(N) Python)
-                if dyn_id >= _native.DYN_NODE_1x1:
+            if dyn_id < _native.DYN_NODE_1x1:
+                trig = s.device_trig(self.x_level)           # closed forms: a few np.sin / np.cos over the levels
+            else:
+                # per-node tables of generic mechanical systems are O(N) Python calls: cached, keyed on the grid
+                # and on the system's parameters
+                key = (dyn_id, _fingerprint(s, self.x_level, self.dt))
+                if self.__dict__.get("_trig_key") != key:
                     t0 = time.time()
                     print("Computing per-node dynamics tables..  ", end="")
-                self.__dict__["_trig"] = s.device_trig(self.x_level)
-                if dyn_id >= _native.DYN_NODE_1x1:
+                    self.__dict__["_trig"] = s.device_trig(self.x_level)
+                    self.__dict__["_trig_key"] = key
                     print("completed in %4.2f sec" % (time.time() - t0))
-            trig = self.__dict__["_trig"]
+                trig = self.__dict__["_trig"]
         if dyn_id != _native.DYN_TABLE and cost is None:
             cost = _null_cost(s.n, s.m)
         return _native.Problem(self.x_level, self.u_level, s.x_lb, s.x_ub, s.u_lb, s.u_ub, self.dt, dtype=dtype,
@@ -321,9 +328,29 @@ def device_dynamics_of(sys):
     fn = getattr(sys, "device_dynamics", None)
     if fn is None or not isinstance(sys, Base):
         return None
-    if type(sys).isavalidstate is not Base.isavalidstate or type(sys).isavalidinput is not Base.isavalidinput:
+    # the kernels implement the plain inclusive box: a subclass override AND an instance attribute (the reference
+    # itself assigns sys.isavalidstate on instances, manipulator.py:441) both send the system to the table tier
+    if (getattr(sys.isavalidstate, "__func__", None) is not Base.isavalidstate
+            or getattr(sys.isavalidinput, "__func__", None) is not Base.isavalidinput):
         return None
     return fn()
+
+
+def _fingerprint(sys, x_level, dt):
+    """Key of the cached per-node dynamics tables: grid levels + every numeric attribute of the system (mass, bounds,
+    ...), so that editing the system or the grid between two DynamicProgramming objects rebuilds them."""
+    import hashlib
+    h = hashlib.sha1()
+    for l in x_level:
+        h.update(np.ascontiguousarray(l, dtype=np.float64).tobytes())
+    h.update(repr((type(sys).__qualname__, float(dt))).encode())
+    for k in sorted(vars(sys)):
+        v = vars(sys)[k]
+        if isinstance(v, (bool, int, float, np.integer, np.floating)):
+            h.update(("%s=%r;" % (k, float(v))).encode())
+        elif isinstance(v, np.ndarray) and v.dtype.kind in "fiub" and v.size <= 4096:
+            h.update(k.encode() + np.ascontiguousarray(v, dtype=np.float64).tobytes())
+    return h.hexdigest()
 
 
 def _box_isavalidinput():

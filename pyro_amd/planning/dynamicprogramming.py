@@ -81,6 +81,8 @@ class DynamicProgramming:
         dd = device_dynamics_of(self.sys)
         cost = self.cf.device_cost() if hasattr(self.cf, "device_cost") else None
         self.tier = "fused" if (dd is not None and cost is not None) else "table"
+        if self.INTERPOLATION != "linear" and dd is not None and dd[0] != _native.DYN_PENDULUM:
+            self.tier = "table"         # the spline sweep has in-kernel dynamics for the pendulum family only
         if self.tier == "fused":
             self._p = self.grid_sys._device_problem(cost=cost, dtype=self.dtype, device=self.device)
         else:
@@ -88,9 +90,11 @@ class DynamicProgramming:
             self._p = _native.Problem(g.x_level, g.u_level, s.x_lb, s.x_ub, s.u_lb, s.u_ub, g.dt, dtype=self.dtype,
                                       dynamics_id=_native.DYN_TABLE, cost=None, device=self.device,
                                       table_inf=float(self.cf.INF))
+            if self.INTERPOLATION != "linear":
+                self._p.set_interpolation(self.INTERPOLATION)       # before the tables: the spline sweep reads them raw
             ok = (g.action_isok & g.x_next_isok) if self.HARD_INF else None
             self._p.set_tables(g.x_next_table, self._host_cost_table(), ok)
-        if self.INTERPOLATION != "linear":
+        if self.tier == "fused" and self.INTERPOLATION != "linear":
             self._p.set_interpolation(self.INTERPOLATION)
         self._host = {}             # cached downloads: 'J', 'pi', 'J_next'
         self._dirty = False         # host J newer than the device copy
@@ -281,8 +285,7 @@ class DynamicProgramming:
         (controller.py:328-355, simulation.py:298-324).  Returns t [n], X [B,n,sys.n], U [B,n,sys.m]."""
         dt = (tf + 0.0) / (n - 1)
         t = np.linspace(0, tf, n)
-        closed_form = self.tier == "fused" and self._p.dynamics_id in (_native.DYN_PENDULUM, _native.DYN_CARTPOLE,
-                                                                        _native.DYN_TWOLINK)
+        closed_form = self.tier == "fused" and self._p.dynamics_id in _native.CLOSED_FORM_IDS
         if closed_form:
             self._p.set_pi(self.pi)             # the host policy may have been edited (clean_infeasible_set)
             X, U = self._p.rollout(X0, n, dt)

@@ -261,3 +261,142 @@ def test_time_cost_device_parameters():
             return 2
 
     assert Mine(np.zeros(2)).device_cost() is None       # subclasses change g: table tier
+
+
+def test_build_staleness_covers_every_source_file(tmp_path, monkeypatch):
+    """A non-forced build must notice edits to the included kernel files, not only to pyrovi.hip."""
+    from pyro_amd import _build
+    names = {os.path.basename(p) for p in _build.sources()}
+    assert {"pyrovi.hip", "sweep_lean.inc", "sweep_spline.inc", "pyrovi.h"} <= names
+    assert _build.up_to_date()
+    inc = [p for p in _build.sources() if p.endswith("sweep_lean.inc")][0]
+    st = os.stat(inc)
+    try:
+        os.utime(inc, (st.st_atime, os.path.getmtime(_build.OUT) + 10))
+        assert not _build.up_to_date()
+    finally:
+        os.utime(inc, (st.st_atime, st.st_mtime))
+
+
+def test_reference_side_stub_mirrors_the_abi_struct():
+    """examples/reference_side_stub (INTEGRATION.md route B) declares its own pvi_desc: same layout as the binding."""
+    import ctypes as C
+    import importlib.util
+    from pyro_amd import _native
+    spec = importlib.util.spec_from_file_location(
+        "dynamicprogramming_hip", os.path.join(ROOT, "examples", "reference_side_stub", "dynamicprogramming_hip.py"))
+    stub = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(stub)
+    assert C.sizeof(stub.pvi_desc) == C.sizeof(_native.pvi_desc)
+    for (n1, _), (n2, _) in zip(stub.pvi_desc._fields_, _native.pvi_desc._fields_):
+        assert n1 == n2 and getattr(stub.pvi_desc, n1).offset == getattr(_native.pvi_desc, n2).offset
+    lib = stub.load_library(_native.LIB_PATH)       # loads without a GPU; every bound symbol resolves
+    assert lib.pvi_abi_version() == _native.ABI_VERSION
+
+
+def test_lookup_tables_save_load_round_trip(tmp_path):
+    """save_lookup_tables / load_lookup_tables (discretizer.py:410-442): same .npz keys, same arrays back."""
+    import contextlib, io
+    from pyro_amd.dynamic import system
+    from pyro_amd.planning import discretizer
+
+    class Integrator(system.ContinuousDynamicSystem):
+        def __init__(self):
+            super().__init__(2, 1, 2)
+            self.x_ub, self.x_lb = np.array([2.0, 1.0]), np.array([-2.0, -1.0])
+
+        def f(self, x, u, t=0):
+            return np.array([x[1], u[0]])
+
+        def isavalidinput(self, x, u):
+            return bool(abs(u[0]) <= 0.5 + abs(x[0]))
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        g = discretizer.GridDynamicSystem(Integrator(), [7, 5], [3], 0.1)
+        xn, ok, aok = g.x_next_table.copy(), g.x_next_isok.copy(), g.action_isok.copy()
+        name = str(tmp_path / "grid")
+        g.save_lookup_tables(name)
+        data = np.load(name + ".npz")
+        assert sorted(data.files) == ["action_isok", "x_next_isok", "x_next_table"]
+        g2 = discretizer.GridDynamicSystem(Integrator(), [7, 5], [3], 0.1)
+        g2.load_lookup_tables(name)
+        g2.load_lookup_tables(str(tmp_path / "missing"))           # prints "File not found", keeps the tables
+    assert "x_next_table" in g2._lazy                               # loaded, not recomputed
+    assert np.array_equal(g2.x_next_table, xn) and np.array_equal(g2.x_next_isok, ok)
+    assert np.array_equal(g2.action_isok, aok) and g2.x_next_table.shape == (35, 3, 2)
+    assert not aok.all() and aok.any()
+
+
+def test_closed_form_kernels_are_only_used_for_stock_models():
+    """The closed-form kernels hard-code SinglePendulum / CartPole / two-link model terms.  In the reference every
+    override takes effect through sys.f, so a subclass or instance that changes H, C, B, g, d, ddq, f_ext or the
+    validity tests must leave the closed form: per-node tables (which call the system's own methods) or the table tier."""
+    from pyro_amd import _native
+    from pyro_amd.dynamic import cartpole, manipulator, pendulum
+    from pyro_amd.planning.discretizer import device_dynamics_of
+
+    assert device_dynamics_of(pendulum.SinglePendulum())[0] == _native.DYN_PENDULUM
+    assert device_dynamics_of(pendulum.InvertedPendulum())[0] == _native.DYN_PENDULUM
+    assert device_dynamics_of(cartpole.CartPole())[0] == _native.DYN_CARTPOLE
+    assert device_dynamics_of(manipulator.TwoLinkManipulator())[0] == _native.DYN_TWOLINK
+    assert device_dynamics_of(pendulum.DoublePendulum())[0] == _native.DYN_TWOLINK
+    assert device_dynamics_of(pendulum.Acrobot())[0] == _native.DYN_NODE_2x1
+
+    class DampedP(pendulum.SinglePendulum):
+        def d(self, q, dq):
+            return np.array([0.3 * dq[0] * abs(dq[0])])
+
+    class PushedArm(manipulator.TwoLinkManipulator):
+        def f_ext(self, q, dq, t=0):
+            return np.array([1.0, -2.0])
+
+        def g(self, q):
+            return 0.5 * manipulator.TwoLinkManipulator.g(self, q)
+
+    class StiffCart(cartpole.CartPole):
+        def g(self, q):
+            return cartpole.CartPole.g(self, q) + np.array([3.0 * q[0], 0.0])
+
+    for s, node_id in ((DampedP(), _native.DYN_NODE_1x1), (PushedArm(), _native.DYN_NODE_2x2),
+                       (StiffCart(), _native.DYN_NODE_2x1)):
+        dd = device_dynamics_of(s)
+        assert dd is not None and dd[0] == node_id, (type(s).__name__, dd)
+        # the per-node tables are built from the system's OWN terms: a0 = ddq(q, dq, 0) at a grid node
+        lv = [np.linspace(s.x_lb[i], s.x_ub[i], 3) for i in range(s.n)]
+        a0, Bn = s.device_trig(lv)
+        x = np.array([l[1] for l in lv[:s.dof]] + [l[2] for l in lv[s.dof:]])
+        node = int(np.ravel_multi_index([1] * s.dof + [2] * s.dof, [3] * s.n))
+        assert np.allclose(a0[node], s.f(x, np.zeros(s.m))[s.dof:], rtol=1e-13, atol=1e-13)
+
+    # an instance-level override of a model term or of the validity test (manipulator.py:441 does the latter)
+    p = pendulum.SinglePendulum()
+    p.g = lambda q: np.array([0.0])
+    assert device_dynamics_of(p)[0] == _native.DYN_NODE_1x1
+    p = pendulum.SinglePendulum()
+    p.isavalidstate = lambda x: bool(x[0] < 1.0)
+    assert device_dynamics_of(p) is None
+    p = cartpole.CartPole()
+    p.f = lambda x, u, t=0: np.zeros(4)
+    assert device_dynamics_of(p) is None
+    # f_batch of a node-tier system uses the host loop (pvi_eval_f has no closed form for it)
+    s = DampedP()
+    X, U = np.array([[0.3, 1.2], [1.0, -2.0]]), np.array([[0.7], [0.1]])
+    assert np.allclose(s.f_batch(X, U), [s.f(X[i], U[i]) for i in range(2)])
+
+
+def test_per_node_table_cache_follows_the_system_parameters():
+    from pyro_amd.planning import discretizer as D
+
+    class S:
+        pass
+    s = S()
+    s.mass, s.x_ub = 1.0, np.array([1.0, 2.0])
+    lv = [np.linspace(0, 1, 5), np.linspace(-1, 1, 3)]
+    k0 = D._fingerprint(s, lv, 0.05)
+    assert k0 == D._fingerprint(s, lv, 0.05)
+    s.mass = 2.0
+    k1 = D._fingerprint(s, lv, 0.05)
+    s.x_ub = np.array([1.0, 3.0])
+    k2 = D._fingerprint(s, lv, 0.05)
+    k3 = D._fingerprint(s, [np.linspace(0, 1, 6), lv[1]], 0.05)
+    assert len({k0, k1, k2, k3}) == 4
