@@ -183,7 +183,9 @@ int pvi_set_tables(pvi_handle h, const double* x_next, const double* G, const ui
                                         x_next clamped to the grid box, no zero fill */
 /* PVI_INTERP_BICUBIC_SPLINE turns the handle into DynamicProgramming2DRectBivariateSpline
    (dynamicprogramming.py:578-614): n == 2, whole-grid handles only, >= 4 levels per axis; works with the
-   pendulum-family in-kernel dynamics (look-up-table semantics) and with tier-B tables. */
+   pendulum-family in-kernel dynamics (look-up-table semantics) and with tier-B tables.  On a tier-B handle call it
+   BEFORE pvi_set_tables: the linear sweep keeps only packed records of the tables, the spline sweep the raw tables
+   (PVI_ESTATE otherwise). */
 int pvi_set_interpolation(pvi_handle h, int32_t kind);
 /* fit the spline through the CURRENT cost-to-go and return its B-spline coefficients [x_dim0][x_dim1]
    (RectBivariateSpline.get_coeffs() of dp.J_interpol, dynamicprogramming.py:594) */

@@ -1,5 +1,6 @@
 """ctypes front end of oracle/vi_oracle.c (test infrastructure; see that file's header)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -19,6 +20,12 @@ class vio_problem(C.Structure):
 
 
 _lib = None
+# CPUs this process may run on, taken BEFORE libgomp is loaded: with OMP_PROC_BIND set the runtime pins the calling
+# thread to one place, after which sched_getaffinity(0) reports a single CPU
+try:
+    ALLOWED_CPUS = frozenset(os.sched_getaffinity(0))
+except AttributeError:
+    ALLOWED_CPUS = frozenset(range(os.cpu_count() or 1))
 
 
 def lib():
@@ -120,13 +127,8 @@ def max_threads():
 def physical_cores():
     """Distinct (package, core) pairs this process may run on: SMT siblings share one set of execution units, so the
     all-cores baseline uses one thread per physical core."""
-    import os
-    try:
-        allowed = os.sched_getaffinity(0)
-    except AttributeError:
-        return os.cpu_count() or 1
     seen = set()
-    for cpu in allowed:
+    for cpu in ALLOWED_CPUS:
         try:
             base = "/sys/devices/system/cpu/cpu%d/topology/" % cpu
             seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))

@@ -223,13 +223,14 @@ void vio_sweep(const vio_problem* P, const double* Jin, double* Jout, int64_t* p
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
-#pragma omp parallel for schedule(static)
+    /* (blocks of 512 nodes dealt on demand: in-box cells cost several times an out-of-box cell, and those come in
+       long contiguous runs of the C-order node numbering) */
+#pragma omp parallel for schedule(dynamic, 512)
     for (int64_t node = node0; node < node1; ++node) backup_node(P, strd, Jin, Jout, pi, alpha, node, f32_storage);
 }
 
 /* `nsweeps` whole-grid backups inside ONE parallel region (bench.py's cpu_baseline): the two caller-owned buffers
-   ping-pong, no allocation and no thread start-up between sweeps, nodes dealt in contiguous static blocks so that
-   every thread keeps writing the pages it touched first.  The result is in J[nsweeps & 1]. */
+   ping-pong, no allocation and no thread start-up between sweeps.  The result is in J[nsweeps & 1]. */
 void vio_sweeps(const vio_problem* P, double* J0, double* J1, int64_t* pi, double alpha, int32_t nsweeps,
                 int32_t f32_storage, int32_t nthreads) {
     int64_t strd[4], N = 1;
@@ -243,7 +244,7 @@ void vio_sweeps(const vio_problem* P, double* J0, double* J1, int64_t* pi, doubl
         for (int k = 0; k < nsweeps; ++k) {
             const double* Jin = (k & 1) ? J1 : J0;
             double* Jout = (k & 1) ? J0 : J1;
-#pragma omp for schedule(static)
+#pragma omp for schedule(dynamic, 512)
             for (int64_t node = 0; node < N; ++node) backup_node(P, strd, Jin, Jout, pi, alpha, node, f32_storage);
             /* (implicit barrier: the next sweep reads what every thread wrote) */
         }

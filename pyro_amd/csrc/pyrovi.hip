@@ -1479,15 +1479,17 @@ struct TabRec {
 template <int N, typename REAL>
 __global__ __launch_bounds__(256) void k_table_pack(DevP P, const double* __restrict__ xnext, const double* __restrict__ Gt,
                                                     const unsigned char* __restrict__ okt, TabRec<N, REAL>* __restrict__ out,
-                                                    long long cells, int* __restrict__ halo_err) {
-    const long long cell = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (cell >= cells) return;
+                                                    long long cell0, long long cells, int* __restrict__ halo_err) {
+    // the tables arrive in chunks: `xnext`, `Gt`, `okt` hold cells [cell0, cell0 + cells) of the reference layout
+    const long long lc = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lc >= cells) return;
+    const long long cell = cell0 + lc;
     bool inb = true;
     long long b = 0;
     TabRec<N, REAL> r;
 #pragma unroll
     for (int d = 0; d < N; ++d) {
-        const double v = xnext[cell * N + d];
+        const double v = xnext[lc * N + d];
         inb = inb && !(v < P.glo[d]) && !(v > P.ghi[d]);
         double l0, l1;
         const int ci = find_interval_lv(P.lev[d], P.dim[d], P.glo[d], P.inv_step[d], v, l0, l1);
@@ -1499,9 +1501,9 @@ __global__ __launch_bounds__(256) void k_table_pack(DevP P, const double* __rest
         }
         b += c * P.strd[d];
     }
-    REAL G = (REAL)Gt[cell];
+    REAL G = (REAL)Gt[lc];
     // base-class semantics (an invalid cell costs exactly INF, dynamicprogramming.py:225-233) = INF + alpha * 0
-    if (okt && !okt[cell]) {
+    if (okt && !okt[lc]) {
         inb = false;
         G = (REAL)P.INF;
     }
@@ -2633,7 +2635,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         const SplineP& S = h->SP;
         spline_fit_launch<REAL>(h, Jin, st);
         if (h->d.dynamics_id == PVI_DYN_TABLE) {
-            if (!h->d_xnext || !h->d_G) return fail(PVI_ESTATE, "tier B sweep before pvi_set_tables");
+            if (!h->d_xnext || !h->d_G) return fail(PVI_ESTATE, "spline sweep without the raw tables: pvi_set_tables after pvi_set_interpolation");
             hipLaunchKernelGGL((k_sweep_spline<PVI_DYN_TABLE, REAL, PI_T>), g, 256, 0, st, h->P, S, h->d_xnext, h->d_G,
                                h->d_ok, Jin, Jout, pi, alpha, sc, h->P.utab, h->P.gu, h->aok32);
         } else {
@@ -2762,7 +2764,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         case PVI_DYN_NODE_2x1: EXACT(PVI_DYN_NODE_2x1) break;
         case PVI_DYN_NODE_2x2: EXACT(PVI_DYN_NODE_2x2) break;
         case PVI_DYN_TABLE:
-            if (!h->d_xnext || !h->d_G) return fail(PVI_ESTATE, "tier B sweep before pvi_set_tables");
+            if (!h->packed && (!h->d_xnext || !h->d_G)) return fail(PVI_ESTATE, "tier B sweep before pvi_set_tables");
             {
                 // nodes per workgroup / actions per LDS chunk: ~2048 cells of Q (<= 16 KB) per pass
                 const int A = h->A;
@@ -3005,6 +3007,9 @@ extern "C" int pvi_set_interpolation(pvi_handle h, int32_t kind) {
         return fail(PVI_EINVAL, "spline interpolation needs a whole-grid handle (the fit couples every row)");
     if (h->d.dynamics_id != PVI_DYN_TABLE && h->d.dynamics_id != PVI_DYN_PENDULUM)
         return fail(PVI_EINVAL, "no 2-D in-kernel dynamics with id %d", h->d.dynamics_id);
+    if (h->d.dynamics_id == PVI_DYN_TABLE && h->packed && !h->d_xnext)
+        return fail(PVI_ESTATE, "the tables were packed for the linear sweep and the raw copies dropped: call "
+                                "pvi_set_interpolation before pvi_set_tables");
     HIPCHK(hipSetDevice(h->device));
     if (!h->SP.coef) {
         std::vector<double> t, lu, rt, lev0(h->P.dim[0]), lev1(h->P.dim[1]);
@@ -3131,67 +3136,100 @@ extern "C" int pvi_set_tables(pvi_handle h, const double* x_next, const double* 
     if (h->d.dynamics_id != PVI_DYN_TABLE) return fail(PVI_ESTATE, "handle was created with in-kernel dynamics");
     HIPCHK(hipSetDevice(h->device));
     const size_t cells = (size_t)h->owned * h->A;
-    if (!h->d_xnext) {
-        void* p = nullptr;
-        HIPCHK(hipMalloc(&p, cells * h->P.n * 8));
-        h->dev_allocs.push_back(p);
-        h->d_xnext = (double*)p;
-        HIPCHK(hipMalloc(&p, cells * 8));
-        h->dev_allocs.push_back(p);
-        h->d_G = (double*)p;
-    }
-    HIPCHK(hipMemcpyAsync(h->d_xnext, x_next, cells * h->P.n * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_G, G, cells * 8, hipMemcpyHostToDevice, h->stream));
-    if (ok) {
-        if (!h->d_ok) {
-            void* p = nullptr;
-            HIPCHK(hipMalloc(&p, cells));
-            h->dev_allocs.push_back(p);
-            h->d_ok = (unsigned char*)p;
-        }
-        HIPCHK(hipMemcpyAsync(h->d_ok, ok, cells, hipMemcpyHostToDevice, h->stream));
-    } else {
-        h->d_ok = nullptr;  // (a previously uploaded mask stays allocated until destroy)
-    }
-    // pack the tables once into per-cell records (k_table_pack); PVI_NO_PACK=1 keeps the per-sweep table kernel
+    const int N = h->P.n;
+    // The linear sweep streams PACKED records (k_table_pack), built chunk by chunk from the host tables, so the raw
+    // float64 tables ((n+1)*8 bytes per cell) are never resident next to the records.  The raw tables are kept only
+    // where a kernel reads them: spline mode, grids beyond int32 offsets, PVI_NO_PACK=1 (the per-sweep table kernel).
+    const bool pack = h->stored < 0x7fffffffLL && !getenv("PVI_NO_PACK") && !h->spline;
     h->packed = false;
-    if (h->stored < 0x7fffffffLL && !getenv("PVI_NO_PACK")) {
-        const int N = h->P.n;
-        const bool f64 = h->d.dtype == PVI_F64;
-        const size_t recsz = f64 ? (8 + 8 * (size_t)N + 8) : (4 + 4 * (size_t)N + 4);
-        if (!h->d_pack) {
+    if (!pack) {
+        if (!h->d_xnext) {
             void* p = nullptr;
-            const size_t nblk = ((size_t)h->owned + TAB_NB - 1) / TAB_NB;
-            HIPCHK(hipMalloc(&p, nblk * TAB_NB * (size_t)h->A * recsz));  // whole blocks of TAB_NB nodes
+            HIPCHK(hipMalloc(&p, cells * N * 8));
             h->dev_allocs.push_back(p);
-            h->d_pack = p;
+            h->d_xnext = (double*)p;
+            HIPCHK(hipMalloc(&p, cells * 8));
+            h->dev_allocs.push_back(p);
+            h->d_G = (double*)p;
         }
-        HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream));
-        const unsigned g = grid_for((long long)cells);
-#define PACK(NN)                                                                                                        \
-    if (f64)                                                                                                            \
-        hipLaunchKernelGGL((k_table_pack<NN, double>), g, 256, 0, h->stream, h->P, h->d_xnext, h->d_G, h->d_ok,         \
-                           (TabRec<NN, double>*)h->d_pack, (long long)cells, &h->ctrl->halo_err);                       \
-    else                                                                                                                \
-        hipLaunchKernelGGL((k_table_pack<NN, float>), g, 256, 0, h->stream, h->P, h->d_xnext, h->d_G, h->d_ok,          \
-                           (TabRec<NN, float>*)h->d_pack, (long long)cells, &h->ctrl->halo_err);
+        HIPCHK(hipMemcpyAsync(h->d_xnext, x_next, cells * N * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_G, G, cells * 8, hipMemcpyHostToDevice, h->stream));
+        if (ok) {
+            if (!h->d_ok) {
+                void* p = nullptr;
+                HIPCHK(hipMalloc(&p, cells));
+                h->dev_allocs.push_back(p);
+                h->d_ok = (unsigned char*)p;
+            }
+            HIPCHK(hipMemcpyAsync(h->d_ok, ok, cells, hipMemcpyHostToDevice, h->stream));
+        } else {
+            h->d_ok = nullptr;  // (a previously uploaded mask stays allocated until destroy)
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return PVI_OK;
+    }
+    // raw tables of an earlier call (e.g. before spline mode was switched off) are not needed any more
+    dev_release(h, h->d_xnext);
+    dev_release(h, h->d_G);
+    h->d_xnext = h->d_G = nullptr;
+    h->d_ok = nullptr;
+    const bool f64 = h->d.dtype == PVI_F64;
+    const size_t recsz = f64 ? (8 + 8 * (size_t)N + 8) : (4 + 4 * (size_t)N + 4);
+    if (!h->d_pack) {
+        void* p = nullptr;
+        const size_t nblk = ((size_t)h->owned + TAB_NB - 1) / TAB_NB;
+        HIPCHK(hipMalloc(&p, nblk * TAB_NB * (size_t)h->A * recsz));  // whole blocks of TAB_NB nodes
+        h->dev_allocs.push_back(p);
+        h->d_pack = p;
+    }
+    const size_t chunk = std::min<size_t>(cells, (size_t)1 << 22);  // cells per staged pass (<= 168 MB of staging)
+    double *sx = nullptr, *sg = nullptr;
+    unsigned char* so = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(sx);
+        (void)hipFree(sg);
+        (void)hipFree(so);
+    };
+    hipError_t e = hipMalloc((void**)&sx, chunk * N * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&sg, chunk * 8);
+    if (e == hipSuccess && ok) e = hipMalloc((void**)&so, chunk);
+    if (e == hipSuccess) e = hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream);
+    for (size_t c0 = 0; c0 < cells && e == hipSuccess; c0 += chunk) {
+        const size_t cc = std::min(chunk, cells - c0);
+        e = hipMemcpyAsync(sx, x_next + c0 * N, cc * N * 8, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(sg, G + c0, cc * 8, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess && ok) e = hipMemcpyAsync(so, ok + c0, cc, hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) break;
+        const unsigned g = grid_for((long long)cc);
+#define PACK(NN)                                                                                                       \
+    if (f64)                                                                                                           \
+        hipLaunchKernelGGL((k_table_pack<NN, double>), g, 256, 0, h->stream, h->P, sx, sg, so,                         \
+                           (TabRec<NN, double>*)h->d_pack, (long long)c0, (long long)cc, &h->ctrl->halo_err);          \
+    else                                                                                                               \
+        hipLaunchKernelGGL((k_table_pack<NN, float>), g, 256, 0, h->stream, h->P, sx, sg, so,                          \
+                           (TabRec<NN, float>*)h->d_pack, (long long)c0, (long long)cc, &h->ctrl->halo_err);
         switch (N) {
             case 2: PACK(2) break;
             case 3: PACK(3) break;
             default: PACK(4) break;
         }
 #undef PACK
-        HIPCHK(hipGetLastError());
-        Ctrl c;
-        HIPCHK(hipMemcpyAsync(&c, h->ctrl, sizeof(c), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        if (c.halo_err) {
-            HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream));
-            return fail(PVI_EHALO, "a table entry gathers outside the stored rows: halo too small");
-        }
-        h->packed = true;
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // the staging buffers are reused by the next chunk
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
+    Ctrl c;
+    memset(&c, 0, sizeof(c));
+    if (e == hipSuccess) e = hipMemcpyAsync(&c, h->ctrl, sizeof(c), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    cleanup();
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? PVI_ENOMEM : PVI_EHIP, "pvi_set_tables failed: %s", hipGetErrorString(e));
+    if (c.halo_err) {
+        HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return fail(PVI_EHALO, "a table entry gathers outside the stored rows: halo too small");
+    }
+    h->packed = true;
     return PVI_OK;
 }
 

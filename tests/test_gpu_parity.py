@@ -913,9 +913,16 @@ def test_spline_value_iteration_matches_reference_golden(tier):
         else:
             xn, _, _, G = O.cells(p, np.arange(p.nodes_n))
             h = _native.Problem(p.levels, p.u_levels, p.x_lb, p.x_ub, p.u_lb, p.u_ub, p.dt, dynamics_id=_native.DYN_TABLE)
+            h.set_tables(xn, G)                     # packed for the linear sweep, raw tables dropped ...
+            with pytest.raises(RuntimeError, match="before pvi_set_tables"):
+                h.set_interpolation("bicubic")      # ... so the spline mode must be chosen first
+            h.close()
+            h = _native.Problem(p.levels, p.u_levels, p.x_lb, p.x_ub, p.u_lb, p.u_ub, p.dt, dynamics_id=_native.DYN_TABLE)
+            h.set_interpolation("bicubic")
             h.set_tables(xn, G)
             h.set_J(O.terminal_cost(p))
-        h.set_interpolation("bicubic")
+        if tier == "fused":
+            h.set_interpolation("bicubic")
         for k in range(1, 9):
             if k in (1, 2, 8):
                 C = h.spline_coefficients()

@@ -1,11 +1,13 @@
 """Merge gpurun_out/counters_<w>.json (tools_counters.sh) into profiles/counters.json (read by bench.py)."""
-import json, os, sys
+import json, os, subprocess, sys
+ROUND = os.environ.get("PVI_ROUND", "r02")
+HEAD = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("PVI_HEAD", "?")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(ROOT, "profiles", "counters.json")
 out = json.load(open(dst)) if os.path.exists(dst) else {}
 for w in sys.argv[1:]:
     src = json.load(open(os.path.join(ROOT, "gpurun_out", "counters_%s.json" % w)))["kernels"]
-    sweep = next(v for k, v in src.items() if "k_sweep" in k)
+    kname, sweep = max(((k, v) for k, v in src.items() if "k_sweep" in k), key=lambda kv: kv[1].get("SQ_INSTS_VALU", 0.0))
     cal = next((v for k, v in src.items() if "to_f64" in k), {})
     out[w] = {
         "hbm_bytes_per_launch": (2.0 * sweep["FETCH_SIZE"] + sweep["WRITE_SIZE"]) * 1024.0,
@@ -15,7 +17,12 @@ for w in sys.argv[1:]:
         "valu_busy_quadcycles": sweep["SQ_ACTIVE_INST_VALU"], "lds_idx_active_cycles": sweep["SQ_LDS_IDX_ACTIVE"],
         "lds_bank_conflict_cycles": sweep["SQ_LDS_BANK_CONFLICT"], "gui_active_cycles_8xcd": sweep["GRBM_GUI_ACTIVE"],
         "calibration_k_to_f64": {k: cal[k] for k in ("FETCH_SIZE", "WRITE_SIZE") if k in cal},
+        "wave_cycles_quad": sweep.get("SQ_WAVE_CYCLES"), "wait_any_quad": sweep.get("SQ_WAIT_ANY"),
+        "wait_inst_any_quad": sweep.get("SQ_WAIT_INST_ANY"), "active_inst_any_quad": sweep.get("SQ_ACTIVE_INST_ANY"),
+        "kernel": kname,
+        "source": "profiles/%s_counters_%s.json (rocprofv3 --pmc passes of tools/tools_counters.sh), kernel %s as of commit %s"
+                  % (ROUND, w, kname.split("<")[0], HEAD),
     }
-    json.dump({"workload": w, "kernels": src}, open(os.path.join(ROOT, "profiles", "r01_counters_%s.json" % w), "w"), indent=1)
+    json.dump({"workload": w, "kernels": src}, open(os.path.join(ROOT, "profiles", "%s_counters_%s.json" % (ROUND, w)), "w"), indent=1)
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps({k: v.get("hbm_bytes_per_launch") for k, v in out.items() if isinstance(v, dict)}))

@@ -44,9 +44,9 @@ for case in range(n_cases):
                             table_inf=float(cf.INF))
         base_sem = rng.random() < 0.5 and not spline          # base-class semantics: exact INF on invalid cells
         okm = (xo & ao) if base_sem else None
-        h.set_tables(xn, G, okm)
         if spline:
             h.set_interpolation("bicubic")
+        h.set_tables(xn, G, okm)
         h.set_J(J0)
         h.sweep(nsw, alpha, -1.0)
         Jt, pit = h.get_J(), h.get_pi()
