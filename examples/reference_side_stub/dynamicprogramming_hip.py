@@ -30,7 +30,9 @@ class pvi_desc(C.Structure):            # mirrors struct pvi_desc in include/pyr
                 ("Q", C.c_double * 16), ("R", C.c_double * 4), ("S", C.c_double * 16),
                 ("xbar", C.c_double * 4), ("ubar", C.c_double * 2), ("EPS", C.c_double), ("INF", C.c_double),
                 ("row_begin", C.c_int32), ("row_end", C.c_int32), ("halo_lo", C.c_int32), ("halo_hi", C.c_int32),
-                ("device", C.c_int32), ("flags", C.c_int32), ("ext_J", C.c_void_p * 2), ("ext_pi", C.c_void_p)]
+                ("device", C.c_int32), ("flags", C.c_int32), ("ext_J", C.c_void_p * 2), ("ext_pi", C.c_void_p),
+                ("n_obs", C.c_int32), ("obs_axis", C.c_int32 * 2), ("obs_half", C.c_double * 2),
+                ("obs_box", (C.c_double * 4) * 8), ("act_aux", _dp)]
 
 
 def load_library(path=None):

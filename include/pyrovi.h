@@ -23,14 +23,20 @@
 extern "C" {
 #endif
 
-#define PVI_ABI_VERSION 1
+#define PVI_ABI_VERSION 2
 #define PVI_MAX_N 4 /* state dimensions supported by the reference grid: 2, 3, 4 (discretizer.py:183-245) */
 #define PVI_MAX_M 2 /* input dimensions: 1, 2 (discretizer.py:271-306) */
 #define PVI_MAX_TRIG 4
+#define PVI_MAX_OBS 8 /* axis-aligned obstacle boxes of a system's isavalidstate */
 
 /* pvi_desc.flags */
 #define PVI_FLAG_EXT_J_SLACK 1 /* the ext_J buffers have >= 64 readable bytes behind the stored rows (lets the 4-D
                                   window fill use 16-byte loads that may run past the end of a row) */
+
+#define PVI_FLAG_HARD_INF 2    /* base-class semantics of DynamicProgramming.compute_backward_step (dynamicprogramming.py:
+                                  195-236): an invalid action / next state costs exactly INF instead of the look-up-table
+                                  class's INF + alpha*J_interp (:567).  The two differ only where isavalidstate rejects
+                                  states INSIDE the grid box (obstacles): honoured by the n = 3 obstacle dynamics */
 
 /* error codes */
 #define PVI_OK 0
@@ -59,11 +65,27 @@ extern "C" {
 #define PVI_DYN_NODE_2x1 5  /* e.g. pendulum.py Acrobot (dof 2, one actuator) */
 #define PVI_DYN_NODE_2x2 6
 
+/* Three-dimensional systems of the reference's value-iteration demos (x_grid n = 3, discretizer.py:201-215), closed
+   forms in the reference's operation order; trig[] = host tables over the levels of the axis named below.
+   Their isavalidstate adds axis-aligned obstacle boxes to the state box (pvi_desc.obs_*). */
+#define PVI_DYN_HELICOPTER 7 /* pyro/dynamic/drone.py:547 ConstantSpeedHelicopterTunnel, x = [dy, y, x], m = 1:
+                                f = [(1/mass) u, x0, vx]; dyn_params = [1/mass, vx] */
+#define PVI_DYN_KINCAR 8     /* pyro/dynamic/vehicle_steering.py:20 KinematicBicyleModel and subclasses (:717 car,
+                                :973 car with obstacles), x = [x, y, theta], u = [v, beta]:
+                                f = [u0 cos x2, u0 sin x2, u0 tan(u1) (1/length)]; trig[0] = cos, trig[1] = sin over the
+                                levels of axis 2; act_aux[a] = u0 tan(u1) (1/length) per action (host NumPy) */
+#define PVI_DYN_QUARTERCAR 9 /* pyro/dynamic/suspension.py:20 QuarterCarOnRoughTerrain, x = [dy, y, x], m = 1:
+                                f = [(1/mass)(u - k (x1 - z) - b (x0 - dz)), x0, vx]; trig[0] = z(x2), trig[1] = dz(x2)
+                                over the levels of axis 2 (the system's own ground profile);
+                                dyn_params = [1/mass, k, b, vx] */
+
 /* cost evaluated in-kernel */
 #define PVI_COST_TABLE 0      /* G supplied by the host */
 #define PVI_COST_QUADRATIC 1  /* pyro/analysis/costfunction.py:101 QuadraticCostFunction */
 #define PVI_COST_TIME 2       /* costfunction.py:287 TimeCostFunction: g = 1 (0 inside the target ball), h = 0;
                                  uses xbar, EPS, INF, ontarget_check; Q, R, S, ubar are ignored */
+#define PVI_COST_QUADRATIC_DOMAIN 3 /* costfunction.py:339 QuadraticCostFunctionWithDomainCheck: the quadratic g / h, INF on
+                                 states the system's isavalidstate rejects (box + obstacles), 0 on target (applied last) */
 
 typedef struct pvi_problem* pvi_handle;
 
@@ -110,6 +132,16 @@ typedef struct pvi_desc {
        bytes (A<=256) or uint16 (A<=65536).  NULL -> allocated by the library. */
     void* ext_J[2];
     void* ext_pi;
+    /* ---- ABI 2 ---- */
+    /* isavalidstate beyond the box (drone.py:590-611, vehicle_steering.py:1004-1021): x is invalid when, for some box b,
+         x[obs_axis[0]] + obs_half[0] > obs_box[b][0]  and  x[obs_axis[1]] + obs_half[1] > obs_box[b][1]  and
+         x[obs_axis[0]] - obs_half[0] < obs_box[b][2]  and  x[obs_axis[1]] - obs_half[1] < obs_box[b][3].
+       Only read for the PVI_DYN_HELICOPTER / KINCAR / QUARTERCAR dynamics. */
+    int32_t n_obs;
+    int32_t obs_axis[2];
+    double obs_half[2];
+    double obs_box[PVI_MAX_OBS][4];
+    const double* act_aux;           /* per-action constants of the dynamics ([A] doubles, see PVI_DYN_KINCAR) or NULL */
 } pvi_desc;
 
 /* ---- library ------------------------------------------------------------------------------ */

@@ -14,12 +14,15 @@ PVI_MAX_N, PVI_MAX_M, PVI_MAX_TRIG = 4, 2, 4
 PVI_F32, PVI_F64 = 0, 1
 DYN_TABLE, DYN_PENDULUM, DYN_CARTPOLE, DYN_TWOLINK = 0, 1, 2, 3
 DYN_NODE_1x1, DYN_NODE_2x1, DYN_NODE_2x2 = 4, 5, 6        # any MechanicalSystem through per-node tables
+DYN_HELICOPTER, DYN_KINCAR, DYN_QUARTERCAR = 7, 8, 9      # the reference's three-dimensional demo systems (n = 3)
 CLOSED_FORM_IDS = (DYN_PENDULUM, DYN_CARTPOLE, DYN_TWOLINK)    # dynamics pvi_eval_f / pvi_rollout can evaluate anywhere
-COST_TABLE, COST_QUADRATIC, COST_TIME = 0, 1, 2
+COST_TABLE, COST_QUADRATIC, COST_TIME, COST_QUADRATIC_DOMAIN = 0, 1, 2, 3
 INTERP_LINEAR, INTERP_BICUBIC_SPLINE = 0, 1
 PVI_EHALO = -5
 FLAG_EXT_J_SLACK = 1
-ABI_VERSION = 1
+FLAG_HARD_INF = 2
+ABI_VERSION = 2
+PVI_MAX_OBS = 8
 
 _dp = C.POINTER(C.c_double)
 
@@ -40,6 +43,9 @@ class pvi_desc(C.Structure):
         ("row_begin", C.c_int32), ("row_end", C.c_int32), ("halo_lo", C.c_int32), ("halo_hi", C.c_int32),
         ("device", C.c_int32), ("flags", C.c_int32),
         ("ext_J", C.c_void_p * 2), ("ext_pi", C.c_void_p),
+        # ABI 2: obstacle boxes of isavalidstate, per-action constants of the dynamics
+        ("n_obs", C.c_int32), ("obs_axis", C.c_int32 * 2), ("obs_half", C.c_double * 2),
+        ("obs_box", (C.c_double * 4) * PVI_MAX_OBS), ("act_aux", _dp),
     ]
 
 
@@ -139,7 +145,7 @@ class Problem:
 
     def __init__(self, x_levels, u_levels, x_lb, x_ub, u_lb, u_ub, dt, dtype="float64", dynamics_id=DYN_TABLE,
                  dyn_params=(), trig=(), cost=None, rows=None, halo=(0, 0), device=0, ext_J=None, ext_pi=None,
-                 table_inf=0.0, flags=0):
+                 table_inf=0.0, flags=0, obstacles=None, act_aux=None):
         L = lib()
         self._keep = []                      # host buffers the descriptor points to
         d = pvi_desc()
@@ -175,7 +181,7 @@ class Problem:
             d.EPS, d.INF = float(cost["EPS"]), float(cost["INF"])
             d.ontarget_check = int(bool(cost.get("ontarget_check", True)))
         elif cost is not None:
-            d.cost_id = COST_QUADRATIC
+            d.cost_id = COST_QUADRATIC_DOMAIN if cost.get("kind") == "quadratic_domain" else COST_QUADRATIC
             n, m = d.n, d.m
             for name, k in (("Q", n), ("S", n), ("R", m)):
                 M = _f64(cost[name])
@@ -197,6 +203,20 @@ class Problem:
         if ext_pi is not None:
             d.ext_pi = int(ext_pi)
         d.flags = int(flags)
+        if obstacles is not None:
+            # dict(axes=(ax, ay), half=(hx, hy), boxes=[[lo_x, lo_y, hi_x, hi_y], ...]) -- include/pyrovi.h obs_*
+            boxes = np.asarray(obstacles["boxes"], dtype=np.float64).reshape(-1, 4)
+            if len(boxes) > PVI_MAX_OBS:
+                raise ValueError("at most %d obstacle boxes" % PVI_MAX_OBS)
+            d.n_obs = len(boxes)
+            d.obs_axis[0], d.obs_axis[1] = int(obstacles["axes"][0]), int(obstacles["axes"][1])
+            d.obs_half[0], d.obs_half[1] = float(obstacles["half"][0]), float(obstacles["half"][1])
+            for b, box in enumerate(boxes):
+                for k in range(4):
+                    d.obs_box[b][k] = float(box[k])
+        if act_aux is not None:
+            a = _f64(act_aux); self._keep.append(a)
+            d.act_aux = _ptr(a)
         self.rows = (int(r0), int(r1))
         self.store_rows = (max(0, r0 - halo[0]), min(self.dims[0], r1 + halo[1]))
         self._h = _h()

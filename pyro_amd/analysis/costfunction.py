@@ -109,6 +109,19 @@ class QuadraticCostFunctionWithDomainCheck(QuadraticCostFunction):
         cf.xbar, cf.ubar = sys.xbar, sys.ubar
         return cf
 
+    def device_cost(self):
+        """In-kernel (PVI_COST_QUADRATIC_DOMAIN) when the validity test is a system's own bound isavalidstate: the
+        caller (DynamicProgramming._make_engine) checks that it is the system of the grid."""
+        if type(self) is not QuadraticCostFunctionWithDomainCheck or getattr(self.isavalidstate, "__self__", None) is None:
+            return None
+        d = dict(
+            Q=np.array(self.Q, dtype=float), R=np.array(self.R, dtype=float), S=np.array(self.S, dtype=float),
+            xbar=np.array(self.xbar, dtype=float), ubar=np.array(self.ubar, dtype=float), EPS=float(self.EPS),
+            INF=float(self.INF), ontarget_check=bool(self.ontarget_check))
+        d["kind"] = "quadratic_domain"
+        d["validity_of"] = self.isavalidstate.__self__
+        return d
+
     def h(self, x, t=0):
         dx = np.asarray(x, dtype=float) - self.xbar
         if self._on_target(dx):

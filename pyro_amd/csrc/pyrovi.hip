@@ -53,6 +53,12 @@ struct DevP {
     double Q[16], S[16], xbar[PVI_MAX_N];
     double EPS, INF;
     int ontarget;
+    // isavalidstate beyond the box: axis-aligned obstacles (include/pyrovi.h pvi_desc.obs_*), and the cost functions
+    // that test the NODE state against it (QuadraticCostFunctionWithDomainCheck)
+    int nobs, obs_ax[2], domain_check, hard_inf;
+    double obs_half[2];
+    double obs[PVI_MAX_OBS][4];
+    const double* aux;          // [A] per-action constants of the dynamics (PVI_DYN_KINCAR)
 };
 
 struct Ctrl {
@@ -586,6 +592,21 @@ __device__ inline void decode_node(const DevP& P, long long o, int* idx) {
 // =================================================================================================
 // terminal cost  J0[s] = h(x_s)   (dynamicprogramming.py:159-171; costfunction.py:151-165)
 // =================================================================================================
+// sys.isavalidstate (system.py:198-205 inclusive box; drone.py:590-611, vehicle_steering.py:1004-1021 obstacles)
+template <int N>
+__device__ inline bool state_valid(const DevP& P, const double* x) {
+    bool bad = false;
+#pragma unroll
+    for (int d = 0; d < N; ++d) bad = bad || (x[d] < P.lb[d]) || (x[d] > P.ub[d]);
+    const double px = x[P.obs_ax[0]], py = x[P.obs_ax[1]];
+    for (int b = 0; b < P.nobs; ++b) {
+        const bool on_obs = ((px + P.obs_half[0]) > P.obs[b][0]) && ((py + P.obs_half[1]) > P.obs[b][1]) &&
+                            ((px - P.obs_half[0]) < P.obs[b][2]) && ((py - P.obs_half[1]) < P.obs[b][3]);
+        bad = bad || on_obs;
+    }
+    return !bad;
+}
+
 template <typename REAL, int N>
 __global__ void k_terminal_cost(DevP P, REAL* __restrict__ J) {
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -595,10 +616,14 @@ __global__ void k_terminal_cost(DevP P, REAL* __restrict__ J) {
     Q.row_begin = P.store_begin;
     int idx[N];
     decode_node<N>(Q, s, idx);
-    double dx[N];
+    double x[N], dx[N];
 #pragma unroll
-    for (int d = 0; d < N; ++d) dx[d] = P.lev[d][idx[d]] - P.xbar[d];
+    for (int d = 0; d < N; ++d) {
+        x[d] = P.lev[d][idx[d]];
+        dx[d] = x[d] - P.xbar[d];
+    }
     double h = quad_form<N>(P.S, dx);
+    if (P.domain_check && !state_valid<N>(P, x)) h = P.INF;  // costfunction.py:385-387
     if (P.ontarget && l2norm<N>(dx) < P.EPS) h = 0.0;
     J[s] = (REAL)h;
 }
@@ -734,6 +759,215 @@ __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ 
     sweep_finish(sc);
 }
 
+
+// =================================================================================================
+// Three-dimensional systems (n = 3; the reference's helicopter / car-parking / active-suspension demos).  They are not
+// mechanical (no [q; dq] split), so they get their own closed forms and one thread-per-node sweep: x_next in float64 in
+// the reference's operation order, validity = box + obstacle list, look-up-table semantics Q = G + alpha*J_interp with
+// G = INF on invalid cells (dynamicprogramming.py:534-549, :567), scipy-order trilinear interpolation.
+// Axes whose x_next does not depend on the action (UDEP bit clear) get their interval and fraction once per node.
+// =================================================================================================
+template <int DYN>
+struct Dyn3;
+
+// ConstantSpeedHelicopterTunnel (drone.py:613-636): dx = [1/mass * u, x0, vx].  c = [1/mass, vx]
+template <>
+struct Dyn3<PVI_DYN_HELICOPTER> {
+    static constexpr int M = 1, UDEP = 1;
+    __device__ void init(const DevP&, const int*, const double*) {}
+    __device__ void f(const DevP& P, const double* x, const double* u, int, double* dx) const {
+        dx[0] = P.c[0] * u[0];
+        dx[1] = x[0];
+        dx[2] = P.c[1];
+    }
+};
+
+// KinematicBicyleModel (vehicle_steering.py:64-86): dx = [u0 cos x2, u0 sin x2, u0 tan(u1) (1/length)]
+template <>
+struct Dyn3<PVI_DYN_KINCAR> {
+    static constexpr int M = 2, UDEP = 7;
+    double c2, s2;
+    __device__ void init(const DevP& P, const int* idx, const double*) {
+        c2 = P.trig[0][idx[2]];
+        s2 = P.trig[1][idx[2]];
+    }
+    __device__ void f(const DevP& P, const double*, const double* u, int a, double* dx) const {
+        dx[0] = u[0] * c2;
+        dx[1] = u[0] * s2;
+        dx[2] = P.aux[a];
+    }
+};
+
+// QuarterCarOnRoughTerrain (suspension.py:100-124): dx = [1/mass (u - k (x1 - z) - b (x0 - dz)), x0, vx]
+// c = [1/mass, k, b, vx]; z, dz = ground height / slope at the node's x2 (host tables)
+template <>
+struct Dyn3<PVI_DYN_QUARTERCAR> {
+    static constexpr int M = 1, UDEP = 1;
+    double ks, bs;  // k (x1 - z), b (x0 - dz)
+    __device__ void init(const DevP& P, const int* idx, const double* x) {
+        ks = P.c[1] * (x[1] - P.trig[0][idx[2]]);
+        bs = P.c[2] * (x[0] - P.trig[1][idx[2]]);
+    }
+    __device__ void f(const DevP& P, const double* x, const double* u, int, double* dx) const {
+        dx[0] = P.c[0] * ((u[0] - ks) - bs);
+        dx[1] = x[0];
+        dx[2] = P.c[3];
+    }
+};
+
+template <int DYN, typename REAL, typename PI_T>
+__global__ __launch_bounds__(256) void k_sweep3(DevP P, const REAL* __restrict__ Jin, REAL* __restrict__ Jout,
+                                                PI_T* __restrict__ pi, double alpha, SweepCtl sc,
+                                                const double* __restrict__ utab, const double* __restrict__ gutab,
+                                                const int* __restrict__ aoktab) {
+    using D = Dyn3<DYN>;
+    constexpr int N = 3, M = D::M;
+    if (sc.ctrl->done) return;
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
+    double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
+    if (o < owned) {
+        int idx[N];
+        decode_node<N>(P, o, idx);
+        double x[N], dx[N];
+        long long self = (long long)(idx[0] - P.store_begin) * P.strd[0];
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+            x[d] = P.lev[d][idx[d]];
+            dx[d] = x[d] - P.xbar[d];
+            if (d > 0) self += idx[d] * P.strd[d];
+        }
+        // node part of g (costfunction.py:195-202; :403-414 with the domain check): INF on a rejected node, 0 on target
+        const double gx = quad_form<N>(P.Q, dx);
+        const bool on_target = P.ontarget && (l2norm<N>(dx) < P.EPS);
+        const bool node_bad = P.domain_check && !state_valid<N>(P, x);
+        D dyn;
+        dyn.init(P, idx, x);
+        // axes whose x_next is the same for every action: evaluated with a placeholder action
+        double xn[N], y[N], u0[M];
+        int ci[N];
+        bool inb_fix = true;
+#pragma unroll
+        for (int k = 0; k < M; ++k) u0[k] = 0.0;
+        {
+            double f0[N];
+            dyn.f(P, x, u0, 0, f0);
+#pragma unroll
+            for (int d = 0; d < N; ++d) {
+                if (!((D::UDEP >> d) & 1)) {
+                    xn[d] = f0[d] * P.dt + x[d];
+                    inb_fix = inb_fix && !(xn[d] < P.glo[d]) && !(xn[d] > P.ghi[d]);
+                    double l0, l1;
+                    ci[d] = find_interval_lv(P.lev[d], P.dim[d], P.glo[d], P.inv_step[d], xn[d], l0, l1);
+                    y[d] = (xn[d] - l0) / (l1 - l0);
+                }
+            }
+        }
+        REAL best = (REAL)0;
+        int arg = 0;
+        const REAL alpha_r = (REAL)alpha;
+        for (int a = 0; a < P.A; ++a) {
+            double u[M], fa[N];
+#pragma unroll
+            for (int k = 0; k < M; ++k) u[k] = utab[a * M + k];
+            dyn.f(P, x, u, a, fa);
+            bool inb = inb_fix;
+#pragma unroll
+            for (int d = 0; d < N; ++d) {
+                if ((D::UDEP >> d) & 1) {
+                    xn[d] = fa[d] * P.dt + x[d];  // discretizer.py:363
+                    inb = inb && !(xn[d] < P.glo[d]) && !(xn[d] > P.ghi[d]);
+                }
+            }
+            const bool ok = aoktab[a] != 0 && state_valid<N>(P, xn);
+            REAL Jn = (REAL)0;
+            if (inb) {
+                long long b = 0;
+#pragma unroll
+                for (int d = 0; d < N; ++d) {
+                    if ((D::UDEP >> d) & 1) {
+                        double l0, l1;
+                        ci[d] = find_interval_lv(P.lev[d], P.dim[d], P.glo[d], P.inv_step[d], xn[d], l0, l1);
+                        y[d] = (xn[d] - l0) / (l1 - l0);
+                    }
+                    int c = ci[d];
+                    if (d == 0) {
+                        if (c < P.store_begin || c + 1 >= P.store_end) {
+                            atomicOr(&sc.ctrl->halo_err, 1);
+                            c = min(max(c, P.store_begin), P.store_end - 2);
+                        }
+                        c -= P.store_begin;
+                    }
+                    b += c * P.strd[d];
+                }
+                Jn = Interp<REAL, N>::eval(Jin, P.strd, b, y);
+            }
+            const double g = on_target ? 0.0 : (node_bad ? P.INF : (gx + gutab[a]));
+            const REAL G = ok ? (REAL)(g * P.dt) : (REAL)P.INF;
+            REAL q;
+            if (sizeof(REAL) == 8)
+                q = G + alpha_r * Jn;
+            else
+                q = fmaf(alpha_r, Jn, G);
+            if (P.hard_inf && !ok) q = (REAL)P.INF;  // base class: exactly INF (dynamicprogramming.py:225-233)
+            if (a == 0 || q < best) {
+                best = q;
+                arg = a;
+            }
+        }
+        Jout[self] = best;
+        pi[o] = (PI_T)arg;
+        const double jn = (double)best, d = jn - (double)Jin[self];
+        st_j = jn;
+        st_dmax = d;
+        st_ndmin = -d;
+    }
+    block_stats(st_j, st_dmax, st_ndmin, sc.slot);
+    sweep_finish(sc);
+}
+
+// reference tables of the n = 3 systems: x_next_table, x_next_isok, action_isok, G (one thread per cell)
+template <int DYN>
+__global__ void k_build_tables3(DevP P, long long node0, long long nnodes, double* __restrict__ xnext,
+                                unsigned char* __restrict__ xok, unsigned char* __restrict__ aok,
+                                double* __restrict__ G) {
+    using D = Dyn3<DYN>;
+    constexpr int N = 3, M = D::M;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nnodes * P.A) return;
+    const long long ln = t / P.A;
+    const int a = (int)(t - ln * P.A);
+    DevP Q = P;
+    Q.row_begin = 0;
+    int idx[N];
+    decode_node<N>(Q, node0 + ln, idx);
+    double x[N], dx[N], u[M], fa[N], xn[N];
+#pragma unroll
+    for (int d = 0; d < N; ++d) {
+        x[d] = P.lev[d][idx[d]];
+        dx[d] = x[d] - P.xbar[d];
+    }
+    D dyn;
+    dyn.init(P, idx, x);
+#pragma unroll
+    for (int k = 0; k < M; ++k) u[k] = P.utab[a * M + k];
+    dyn.f(P, x, u, a, fa);
+#pragma unroll
+    for (int d = 0; d < N; ++d) xn[d] = fa[d] * P.dt + x[d];
+    const bool ok = state_valid<N>(P, xn);
+    if (xnext) {
+#pragma unroll
+        for (int d = 0; d < N; ++d) xnext[t * N + d] = xn[d];
+    }
+    if (xok) xok[t] = ok;
+    if (aok) aok[t] = P.aok[a];
+    if (G) {
+        const bool on_target = P.ontarget && (l2norm<N>(dx) < P.EPS);
+        const bool node_bad = P.domain_check && !state_valid<N>(P, x);
+        const double g = on_target ? 0.0 : (node_bad ? P.INF : (quad_form<N>(P.Q, dx) + P.gu[a]));
+        G[t] = (ok && P.aok[a]) ? g * P.dt : P.INF;
+    }
+}
 
 // =================================================================================================
 // f32 fast path ("v1").  Same recursion; the inner loop is float32 and system independent:
@@ -2172,6 +2406,10 @@ extern "C" int pvi_device_count(int* count) {
 }
 
 static inline bool is_node_dyn(int dyn) { return dyn >= PVI_DYN_NODE_1x1 && dyn <= PVI_DYN_NODE_2x2; }
+static inline bool is_dyn3(int dyn) { return dyn >= PVI_DYN_HELICOPTER && dyn <= PVI_DYN_QUARTERCAR; }
+static inline bool is_cost_in_kernel(int c) {
+    return c == PVI_COST_QUADRATIC || c == PVI_COST_TIME || c == PVI_COST_QUADRATIC_DOMAIN;
+}
 
 static int dyn_shape(int dyn, int* n, int* m) {
     switch (dyn) {
@@ -2181,6 +2419,9 @@ static int dyn_shape(int dyn, int* n, int* m) {
         case PVI_DYN_NODE_1x1: *n = 2; *m = 1; return 0;
         case PVI_DYN_NODE_2x1: *n = 4; *m = 1; return 0;
         case PVI_DYN_NODE_2x2: *n = 4; *m = 2; return 0;
+        case PVI_DYN_HELICOPTER: *n = 3; *m = 1; return 0;
+        case PVI_DYN_KINCAR: *n = 3; *m = 2; return 0;
+        case PVI_DYN_QUARTERCAR: *n = 3; *m = 1; return 0;
     }
     return -1;
 }
@@ -2209,8 +2450,16 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
         if (dyn_shape(d->dynamics_id, &n, &m)) return fail(PVI_EINVAL, "unknown dynamics_id %d", d->dynamics_id);
         if (n != d->n || m != d->m)
             return fail(PVI_EINVAL, "dynamics %d needs n=%d m=%d, got n=%d m=%d", d->dynamics_id, n, m, d->n, d->m);
-        if (d->cost_id != PVI_COST_QUADRATIC && d->cost_id != PVI_COST_TIME)
-            return fail(PVI_EINVAL, "in-kernel dynamics need cost_id QUADRATIC or TIME");
+        if (!is_cost_in_kernel(d->cost_id))
+            return fail(PVI_EINVAL, "in-kernel dynamics need cost_id QUADRATIC, TIME or QUADRATIC_DOMAIN");
+        if (is_dyn3(d->dynamics_id)) {
+            if (d->n_obs < 0 || d->n_obs > PVI_MAX_OBS) return fail(PVI_EINVAL, "n_obs=%d not in [0,%d]", d->n_obs, PVI_MAX_OBS);
+            for (int k = 0; k < 2; ++k)
+                if (d->n_obs && (d->obs_axis[k] < 0 || d->obs_axis[k] >= d->n))
+                    return fail(PVI_EINVAL, "obs_axis[%d]=%d is not a state axis", k, d->obs_axis[k]);
+            if (d->dynamics_id == PVI_DYN_QUARTERCAR && (!d->trig[0] || !d->trig[1]))
+                return fail(PVI_EINVAL, "PVI_DYN_QUARTERCAR needs the ground tables z, dz in trig[0], trig[1]");
+        }
     }
     long long plane = 1, A = 1;
     for (int i = 0; i < d->n; ++i) {
@@ -2299,6 +2548,16 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
     P.EPS = d->EPS;
     P.INF = d->INF;
     P.ontarget = d->ontarget_check;
+    P.domain_check = d->cost_id == PVI_COST_QUADRATIC_DOMAIN;
+    P.hard_inf = (d->flags & PVI_FLAG_HARD_INF) != 0;
+    if (is_dyn3(d->dynamics_id)) {
+        P.nobs = d->n_obs;
+        P.obs_ax[0] = d->n_obs ? d->obs_axis[0] : 0;
+        P.obs_ax[1] = d->n_obs ? d->obs_axis[1] : 0;
+        P.obs_half[0] = d->obs_half[0];
+        P.obs_half[1] = d->obs_half[1];
+        memcpy(P.obs, d->obs_box, sizeof(double) * 4 * (size_t)d->n_obs);
+    }
 
     // action tables, C order over u_dim (discretizer.py:253-302)
     std::vector<double> utab((size_t)A * d->m), gu((size_t)A);
@@ -2356,7 +2615,7 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
         bool box_is_grid = true;
         for (int i = 0; i < d->n; ++i)
             box_is_grid = box_is_grid && d->x_lb[i] == P.glo[i] && d->x_ub[i] == P.ghi[i];
-        h->fast_ok = d->dtype == PVI_F32 && d->dynamics_id != PVI_DYN_TABLE && box_is_grid &&
+        h->fast_ok = d->dtype == PVI_F32 && d->dynamics_id != PVI_DYN_TABLE && !is_dyn3(d->dynamics_id) && box_is_grid &&
                      h->stored < 0x7fffffffLL && !getenv("PVI_NO_FAST");
         // the per-sweep bounding-box tile kernel predates the lean kernel; where the lean window does not fit LDS its
         // window does not pay either (two-link 101^4 x 121 f32: tile 167 ms, fast 35 ms): opt-in, PVI_TILE=1
@@ -2398,6 +2657,14 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
                 for (int j = 0; j < d->x_dim[1]; ++j)
                     t[(size_t)i * d->x_dim[1] + j] = std::sin(d->x_level[0][i] + d->x_level[1][j]);
         if ((rc = dev_upload(h, t.data(), t.size(), &P.trig[3]))) return bail(rc);
+    } else if (d->dynamics_id == PVI_DYN_KINCAR) {
+        if ((rc = table(0, 2, fcos)) || (rc = table(1, 2, fsin))) return bail(rc);
+        std::vector<double> aux((size_t)A);
+        for (long long a = 0; a < A; ++a)  // u0 * tan(u1) * (1/length), vehicle_steering.py:84
+            aux[a] = d->act_aux ? d->act_aux[a] : utab[a * 2] * std::tan(utab[a * 2 + 1]) * d->dyn_params[0];
+        if ((rc = dev_upload(h, aux.data(), aux.size(), &P.aux))) return bail(rc);
+    } else if (d->dynamics_id == PVI_DYN_QUARTERCAR) {
+        if ((rc = table(0, 2, fsin)) || (rc = table(1, 2, fcos))) return bail(rc);  // (both supplied: checked above)
     } else if (is_node_dyn(d->dynamics_id)) {
         if (!d->trig[0] || !d->trig[1]) return bail(fail(PVI_EINVAL, "PVI_DYN_NODE_* needs the a0 / Bn tables in trig[0], trig[1]"));
         const int dof = d->n / 2;
@@ -2496,8 +2763,8 @@ static int terminal_cost_t(pvi_problem* h) {
 
 extern "C" int pvi_terminal_cost(pvi_handle h) {
     if (!h) return fail(PVI_EINVAL, "NULL handle");
-    if (h->d.cost_id != PVI_COST_QUADRATIC && h->d.cost_id != PVI_COST_TIME)
-        return fail(PVI_ESTATE, "terminal cost needs an in-kernel cost (QUADRATIC or TIME)");
+    if (!is_cost_in_kernel(h->d.cost_id))
+        return fail(PVI_ESTATE, "terminal cost needs an in-kernel cost (QUADRATIC, TIME or QUADRATIC_DOMAIN)");
     HIPCHK(hipSetDevice(h->device));
     return h->d.dtype == PVI_F64 ? terminal_cost_t<double>(h) : terminal_cost_t<float>(h);
 }
@@ -2756,7 +3023,13 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     else                                                                                                               \
         hipLaunchKernelGGL((k_sweep<DYN, REAL, PI_T, false>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha, sc, h->P.utab,   \
                            h->P.gu, h->aok32);
+#define SWEEP3(DYN)                                                                                                  \
+    hipLaunchKernelGGL((k_sweep3<DYN, REAL, PI_T>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha, sc, h->P.utab, h->P.gu, \
+                       h->aok32)
     switch (h->d.dynamics_id) {
+        case PVI_DYN_HELICOPTER: SWEEP3(PVI_DYN_HELICOPTER); break;
+        case PVI_DYN_KINCAR: SWEEP3(PVI_DYN_KINCAR); break;
+        case PVI_DYN_QUARTERCAR: SWEEP3(PVI_DYN_QUARTERCAR); break;
         case PVI_DYN_PENDULUM: EXACT(PVI_DYN_PENDULUM) break;
         case PVI_DYN_CARTPOLE: EXACT(PVI_DYN_CARTPOLE) break;
         case PVI_DYN_TWOLINK: EXACT(PVI_DYN_TWOLINK) break;
@@ -2820,6 +3093,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             return fail(PVI_EINVAL, "unknown dynamics_id");
     }
 #undef EXACT
+#undef SWEEP3
     HIPCHK(hipGetLastError());
     return PVI_OK;
 }
@@ -3090,6 +3364,18 @@ extern "C" int pvi_build_tables(pvi_handle h, int32_t row0, int32_t nrows, doubl
         const long long c = nodes - s < chunk_nodes ? nodes - s : chunk_nodes;
         const unsigned g = grid_for(c * A);
         switch (h->d.dynamics_id) {
+            case PVI_DYN_HELICOPTER:
+                hipLaunchKernelGGL((k_build_tables3<PVI_DYN_HELICOPTER>), g, 256, 0, h->stream, h->P, node0 + s, c, dx, dxo,
+                                   dao, dG);
+                break;
+            case PVI_DYN_KINCAR:
+                hipLaunchKernelGGL((k_build_tables3<PVI_DYN_KINCAR>), g, 256, 0, h->stream, h->P, node0 + s, c, dx, dxo,
+                                   dao, dG);
+                break;
+            case PVI_DYN_QUARTERCAR:
+                hipLaunchKernelGGL((k_build_tables3<PVI_DYN_QUARTERCAR>), g, 256, 0, h->stream, h->P, node0 + s, c, dx, dxo,
+                                   dao, dG);
+                break;
             case PVI_DYN_PENDULUM:
                 hipLaunchKernelGGL((k_build_tables<PVI_DYN_PENDULUM>), g, 256, 0, h->stream, h->P, node0 + s, c, dx, dxo,
                                    dao, dG);
@@ -3259,8 +3545,8 @@ extern "C" int pvi_set_pi(pvi_handle h, const int64_t* pr, int32_t row0, int32_t
 extern "C" int pvi_rollout(pvi_handle h, int64_t B, const double* X0, int32_t npts, double dt, double* X_traj,
                            double* U_traj, double* X_end) {
     if (!h || !X0) return fail(PVI_EINVAL, "NULL argument");
-    if (h->d.dynamics_id == PVI_DYN_TABLE || is_node_dyn(h->d.dynamics_id))
-        return fail(PVI_ESTATE, "rollouts need closed-form in-kernel dynamics (the node tables only cover the grid nodes)");
+    if (h->d.dynamics_id == PVI_DYN_TABLE || is_node_dyn(h->d.dynamics_id) || is_dyn3(h->d.dynamics_id))
+        return fail(PVI_ESTATE, "rollouts need the closed-form mechanical dynamics (node / level tables only cover the grid nodes)");
     if (h->P.store_begin != 0 || h->P.store_end != h->P.dim[0] || h->P.row_begin != 0 || h->P.row_end != h->P.dim[0])
         return fail(PVI_ESTATE, "rollouts need a whole-grid handle");
     if (B <= 0 || npts < 1) return PVI_OK;
@@ -3306,7 +3592,7 @@ extern "C" int pvi_eval_f(int32_t dyn, const double* params, int32_t n, int32_t 
                           const double* U, double* dX) {
     if (!params || !X || !U || !dX) return fail(PVI_EINVAL, "NULL argument");
     int en, em;
-    if (dyn_shape(dyn, &en, &em) || is_node_dyn(dyn)) return fail(PVI_EINVAL, "no closed-form dynamics with id %d", dyn);
+    if (dyn_shape(dyn, &en, &em) || is_node_dyn(dyn) || is_dyn3(dyn)) return fail(PVI_EINVAL, "no closed-form dynamics with id %d", dyn);
     if (en != n || em != m) return fail(PVI_EINVAL, "dynamics %d needs n=%d m=%d", dyn, en, em);
     if (B <= 0) return PVI_OK;
     double *dc = nullptr, *dXd = nullptr, *dU = nullptr, *dO = nullptr;

@@ -134,6 +134,10 @@ class GridDynamicSystem:
                 trig = self.__dict__["_trig"]
         if dyn_id != _native.DYN_TABLE and cost is None:
             cost = _null_cost(s.n, s.m)
+        if dd is not None and getattr(s.isavalidstate, "__func__", None) is not _base_isavalidstate():
+            kw.setdefault("obstacles", s.device_obstacles())
+        if dd is not None and hasattr(s, "device_act_aux"):
+            kw.setdefault("act_aux", s.device_act_aux(self.input_from_action_id))
         return _native.Problem(self.x_level, self.u_level, s.x_lb, s.x_ub, s.u_lb, s.u_ub, self.dt, dtype=dtype,
                                dynamics_id=dyn_id, dyn_params=params, trig=trig, cost=cost, **kw)
 
@@ -330,9 +334,17 @@ def device_dynamics_of(sys):
         return None
     # the kernels implement the plain inclusive box: a subclass override AND an instance attribute (the reference
     # itself assigns sys.isavalidstate on instances, manipulator.py:441) both send the system to the table tier
-    if (getattr(sys.isavalidstate, "__func__", None) is not Base.isavalidstate
-            or getattr(sys.isavalidinput, "__func__", None) is not Base.isavalidinput):
+    if getattr(sys.isavalidinput, "__func__", None) is not Base.isavalidinput:
         return None
+    vs = getattr(sys.isavalidstate, "__func__", None)
+    if vs is not Base.isavalidstate:
+        # box + obstacle boxes: in-kernel when it is exactly the test of the class that describes its obstacles to the
+        # library (device_obstacles of the helicopter tunnel / the car with obstacles)
+        owner = getattr(type(sys), "_OBSTACLE_OWNER", None)
+        if owner is None or vs is not owner.__dict__.get("isavalidstate") or "device_obstacles" in vars(sys):
+            return None
+        if type(sys).device_obstacles is not owner.device_obstacles:
+            return None
     return fn()
 
 
@@ -351,6 +363,11 @@ def _fingerprint(sys, x_level, dt):
         elif isinstance(v, np.ndarray) and v.dtype.kind in "fiub" and v.size <= 4096:
             h.update(k.encode() + np.ascontiguousarray(v, dtype=np.float64).tobytes())
     return h.hexdigest()
+
+
+def _base_isavalidstate():
+    from pyro_amd.dynamic.system import ContinuousDynamicSystem
+    return ContinuousDynamicSystem.isavalidstate
 
 
 def _box_isavalidinput():

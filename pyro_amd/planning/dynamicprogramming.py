@@ -80,11 +80,18 @@ class DynamicProgramming:
     def _make_engine(self):
         dd = device_dynamics_of(self.sys)
         cost = self.cf.device_cost() if hasattr(self.cf, "device_cost") else None
+        if cost is not None and cost.get("kind") == "quadratic_domain":
+            # the in-kernel domain check tests the node against the SYSTEM's validity: it must be this system's own
+            if cost.pop("validity_of", None) is not self.sys or getattr(self.cf.isavalidstate, "__func__", None) is not getattr(self.sys.isavalidstate, "__func__", 0):
+                cost = None
         self.tier = "fused" if (dd is not None and cost is not None) else "table"
         if self.INTERPOLATION != "linear" and dd is not None and dd[0] != _native.DYN_PENDULUM:
             self.tier = "table"         # the spline sweep has in-kernel dynamics for the pendulum family only
         if self.tier == "fused":
-            self._p = self.grid_sys._device_problem(cost=cost, dtype=self.dtype, device=self.device)
+            # (base class: an invalid cell costs exactly INF; the same as INF + alpha*0 unless the system rejects
+            #  states inside the grid box, i.e. obstacles)
+            self._p = self.grid_sys._device_problem(cost=cost, dtype=self.dtype, device=self.device,
+                                                    flags=_native.FLAG_HARD_INF if self.HARD_INF else 0)
         else:
             g, s = self.grid_sys, self.sys
             self._p = _native.Problem(g.x_level, g.u_level, s.x_lb, s.x_ub, s.u_lb, s.u_ub, g.dt, dtype=self.dtype,

@@ -382,6 +382,54 @@ def case_helicopter():
     save("helicopter_11x11x11x5", **out)
 
 
+def case_car():
+    """KinematicCarModelwithObstacles 3-D 21x21x11 x 3x3 with the car_parking.py bounds / weights (plain quadratic
+    cost, alpha 0.99): tables, LUT and base class; f / isavalidstate known answers."""
+    from pyro.dynamic import vehicle_steering
+    with quiet():
+        s = vehicle_steering.KinematicCarModelwithObstacles()
+        s.x_ub = np.array([+35, +3, +3]); s.x_lb = np.array([-5, -2, -3])
+        s.u_ub = np.array([+3, +1]); s.u_lb = np.array([-3, -1])
+        g = discretizer.GridDynamicSystem(s, (21, 21, 11), (3, 3), 0.1)
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+        q.xbar = np.array([0, 0, 0]); q.INF = 1E8; q.EPS = 0.00
+        q.R = np.array([[0.1, 0], [0, 0]])
+    out = _meta(s, g, q)
+    out.update(_lut_and_base(g, q, 5, (1, 5), alpha=0.99))
+    out.update(_kat3(s))
+    out.update(lenght=s.lenght, width=s.width, obstacles=np.array(s.obstacles, dtype=float).reshape(-1, 4))
+    save("car_21x21x11x3x3", **out)
+
+
+def case_suspension():
+    """QuarterCarOnRoughTerrain 3-D 13x11x21 x 5 with the active_suspension.py parameters (alpha 0.99)."""
+    from pyro.dynamic import suspension
+    with quiet():
+        s = suspension.QuarterCarOnRoughTerrain()
+        s.mass = 0.5; s.b = 0.5; s.k = 8.0; s.vx = 10.0
+        s.x_ub = np.array([+12, +1, +40]); s.x_lb = np.array([-12, -1, +0])
+        s.u_ub = np.array([+40]); s.u_lb = np.array([-40])
+        g = discretizer.GridDynamicSystem(s, (13, 11, 21), [5], 0.05)
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+        q.xbar = np.array([0.0, 0.0, 20]); q.INF = 100000; q.EPS = 0.5
+        q.Q[0, 0] = 2.0; q.Q[1, 1] = 5.0; q.Q[2, 2] = 0.0; q.R[0, 0] = 0.1
+        q.S[0, 0] = 0.0; q.S[1, 1] = 0.0; q.S[2, 2] = 0.0
+    out = _meta(s, g, q)
+    out.update(_lut_and_base(g, q, 5, (1, 5), alpha=0.99))
+    out.update(_kat3(s))
+    out.update(params=np.array([s.mass, s.k, s.b, s.vx], dtype=float), a=s.a, w=s.w, phi=s.phi)
+    save("suspension_13x11x21x5", **out)
+
+
+def _kat3(s):
+    """64 random (x, u) around the state box -> f, isavalidstate of a three-dimensional system."""
+    rng = np.random.default_rng(3)
+    X = rng.uniform(s.x_lb - 1.0, s.x_ub + 1.0, size=(64, s.n))
+    U = rng.uniform(s.u_lb, s.u_ub, size=(64, s.m))
+    return dict(kat_X=X, kat_U=U, kat_dX=np.array([s.f(X[i], U[i]) for i in range(64)]),
+                kat_valid=np.array([bool(s.isavalidstate(X[i])) for i in range(64)]))
+
+
 def case_reachability():
     """Reachability cost on the pendulum 41x41 x 3 (pendulum_reachability.py), 20 sweeps."""
     with quiet():
@@ -591,7 +639,7 @@ def case_floatmass():
     save("floatmass_51x51x21", **out)
 
 
-CASES = dict(floatmass=case_floatmass, acrobot=case_acrobot, mintime=case_mintime, mountaincar=case_mountaincar, spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
+CASES = dict(car=case_car, suspension=case_suspension, floatmass=case_floatmass, acrobot=case_acrobot, mintime=case_mintime, mountaincar=case_mountaincar, spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
              policy_eval=case_policy_eval, cost_kat=case_cost_kat, grid_kat=case_grid_kat,
              pendulum_small=case_pendulum_small, config1=case_config1, lowdef=case_lowdef,
              pendulum_demo=case_pendulum_demo, cartpole_small=case_cartpole_small,

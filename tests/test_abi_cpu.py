@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libpyrovi.so does not export %s" % name
     assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
-    assert L.pvi_abi_version() == 1
+    assert L.pvi_abi_version() == 2
 
 
 def test_descriptor_layout_matches_header():

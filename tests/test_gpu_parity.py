@@ -1236,3 +1236,134 @@ def test_randomised_consistency_runs(script, args):
     from conftest import ROOT
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)] + args, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ----------------------------------------------------------- three-dimensional systems, fused (SURVEY 8 f3 remainder)
+from cases3d import CASES3D, case3d  # noqa: E402
+
+
+def _native3d(p, dtype="float64", flags=0):
+    from pyro_amd import _native
+    cost = dict(Q=p.Q, R=p.R, S=p.S, xbar=p.xbar, ubar=p.ubar, EPS=p.EPS, INF=p.INF, ontarget_check=p.ontarget_check)
+    if p.domain_check:
+        cost["kind"] = "quadratic_domain"
+    t = p.trig_tables()
+    trig = (t["c2"], t["s2"]) if p.dyn_id == O.DYN_KINCAR else ((t["z"], t["dz"]) if p.dyn_id == O.DYN_QUARTERCAR else ())
+    return _native.Problem(p.levels, p.u_levels, p.x_lb, p.x_ub, p.u_lb, p.u_ub, p.dt, dtype=dtype,
+                           dynamics_id=p.dyn_id, dyn_params=list(p.dyn_c), trig=trig, cost=cost,
+                           obstacles=p.obstacles, act_aux=p.act_aux, flags=flags)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES3D)
+def test_3d_systems_fused_kernels_match_reference(name):
+    """Helicopter tunnel, car parking, active suspension through the closed-form n = 3 kernels: the tables the
+    library builds equal the REFERENCE's x_next_table / masks bit for bit (G to the ulp of its BLAS dots, bit for bit
+    against the oracle); J / pi of the look-up-table class (INF + alpha*J on obstacle cells) and of the base class
+    (exactly INF) after 1 and 5 sweeps; float32 storage within 1e-5."""
+    from pyro_amd import _native
+    g, p, alpha = case3d(name)
+    h = _native3d(p)
+    assert h.describe().split()[0] == "path=exact-f64"
+    xn, xok, aok, G = h.build_tables()
+    assert np.array_equal(xn, g["x_next_table"])
+    assert np.array_equal(xok, g["x_next_isok"]) and np.array_equal(aok, g["action_isok"])
+    assert np.array_equal(G, O.cells(p, np.arange(p.nodes_n))[3])
+    np.testing.assert_allclose(G, g["G"], rtol=1e-14, atol=0)
+    h.terminal_cost()
+    assert np.array_equal(h.get_J(), O.terminal_cost(p))
+    np.testing.assert_allclose(h.get_J(), g["J0"], rtol=1e-14, atol=0)
+    for k in range(1, 6):
+        h.sweep(1, alpha, -1.0)
+        if k in (1, 5):
+            assert relerr(h.get_J(), g["J_%d" % k]) < 1e-12
+            assert np.array_equal(h.get_pi(), g["pi_%d" % k])
+    h.close()
+    hb = _native3d(p, flags=_native.FLAG_HARD_INF)                  # base class DynamicProgramming
+    hb.terminal_cost()
+    hb.sweep(5, alpha, -1.0)
+    assert relerr(hb.get_J(), g["Jbase_5"]) < 1e-12 and np.array_equal(hb.get_pi(), g["pibase_5"])
+    hb.close()
+    h32 = _native3d(p, dtype="float32")
+    h32.terminal_cost()
+    h32.sweep(5, alpha, -1.0)
+    assert relerr(h32.get_J(), g["J_5"]) <= REL_F32
+    h32.close()
+
+
+@pytest.mark.gpu
+def test_3d_systems_class_surface_runs_fused():
+    """The mirrors of the three systems pick the fused tier (no O(N*A) Python table build) through the reference's
+    class surface, with the demos' parameters; results equal the reference's own runs."""
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import drone, suspension, vehicle_steering
+    from pyro_amd.planning import discretizer, dynamicprogramming
+    with contextlib.redirect_stdout(io.StringIO()):
+        # helicopter_tunnel.py-style set-up (tests/golden/make_goldens.py case_helicopter)
+        s = drone.ConstantSpeedHelicopterTunnel()
+        s.obstacles = [[(2, 2), (4, 4)], [(8, 5), (10, 10)], [(14, 0), (16, 4)]]
+        s.mass, s.vx, s.width = 0.1, 5.0, 1.0
+        s.x_ub, s.x_lb = np.array([+60, 10, +20]), np.array([-60, 0, +0])
+        s.u_ub, s.u_lb = np.array([+20]), np.array([-20])
+        gs = discretizer.GridDynamicSystem(s, (11, 11, 11), [5], 0.05)
+        q = costfunction.QuadraticCostFunctionWithDomainCheck.from_sys(s)
+        q.xbar = np.array([0.0, 2.0, 20]); q.INF = 100000; q.EPS = 0.2
+        q.Q[0, 0] = 2.0; q.Q[1, 1] = 200.0; q.Q[2, 2] = 0.0; q.R[0, 0] = 5.0
+        q.S[0, 0] = 20.0; q.S[1, 1] = 50.0; q.S[2, 2] = 0.0
+        g = load("helicopter_11x11x11x5")
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(gs, q)
+        assert dp.tier == "fused"
+        dp.alpha = 0.999
+        dp.compute_steps(5)
+        assert relerr(dp.J, g["J_5"]) < 1e-12 and np.array_equal(dp.pi, g["pi_5"])
+        assert np.array_equal(gs.x_next_table, g["x_next_table"]) and np.array_equal(gs.x_next_isok, g["x_next_isok"])
+        np.testing.assert_allclose(dp.G, g["G"], rtol=1e-14)
+        db = dynamicprogramming.DynamicProgramming(gs, q)             # base class: exactly INF on obstacle cells
+        assert db.tier == "fused"
+        db.alpha = 0.999
+        db.compute_steps(5)
+        assert relerr(db.J, g["Jbase_5"]) < 1e-12 and np.array_equal(db.pi, g["pibase_5"])
+        # a domain check bound to ANOTHER system's validity is not this system's: table tier
+        q2 = costfunction.QuadraticCostFunctionWithDomainCheck.from_sys(drone.ConstantSpeedHelicopterTunnel())
+        q2.xbar = q.xbar
+        assert dynamicprogramming.DynamicProgrammingWithLookUpTable(gs, q2).tier == "table"
+        # car_parking.py
+        s = vehicle_steering.KinematicCarModelwithObstacles()
+        s.x_ub, s.x_lb = np.array([+35, +3, +3]), np.array([-5, -2, -3])
+        s.u_ub, s.u_lb = np.array([+3, +1]), np.array([-3, -1])
+        gs = discretizer.GridDynamicSystem(s, (21, 21, 11), (3, 3), 0.1)
+        cf = costfunction.QuadraticCostFunction.from_sys(s)
+        cf.xbar = np.array([0, 0, 0]); cf.INF = 1E8; cf.EPS = 0.00
+        cf.R = np.array([[0.1, 0], [0, 0]])
+        g = load("car_21x21x11x3x3")
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(gs, cf)
+        assert dp.tier == "fused"
+        dp.alpha = 0.99
+        dp.compute_steps(5)
+        assert relerr(dp.J, g["J_5"]) < 1e-12 and np.array_equal(dp.pi, g["pi_5"])
+        ctl = dp.get_lookup_table_controller()
+        assert np.all(np.isfinite(ctl.c(np.array([10.0, 0.5, 0.1]), 0)))
+        # active_suspension.py
+        s = suspension.QuarterCarOnRoughTerrain()
+        s.mass, s.b, s.k, s.vx = 0.5, 0.5, 8.0, 10.0
+        s.x_ub, s.x_lb = np.array([+12, +1, +40]), np.array([-12, -1, +0])
+        s.u_ub, s.u_lb = np.array([+40]), np.array([-40])
+        gs = discretizer.GridDynamicSystem(s, (13, 11, 21), [5], 0.05)
+        qcf = costfunction.QuadraticCostFunction.from_sys(s)
+        qcf.xbar = np.array([0.0, 0.0, 20]); qcf.INF = 100000; qcf.EPS = 0.5
+        qcf.Q[0, 0] = 2.0; qcf.Q[1, 1] = 5.0; qcf.Q[2, 2] = 0.0; qcf.R[0, 0] = 0.1
+        g = load("suspension_13x11x21x5")
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(gs, qcf, dtype="float32")
+        assert dp.tier == "fused"
+        dp.alpha = 0.99
+        dp.compute_steps(5)
+        assert relerr(dp.J, g["J_5"]) <= REL_F32
+
+        # overriding the obstacle test, or f, leaves the closed form: table tier, same answers as the reference loops
+        class Narrow(vehicle_steering.KinematicCarModelwithObstacles):
+            def isavalidstate(self, x):
+                return bool(abs(x[1]) < 1.5) and vehicle_steering.KinematicCarModelwithObstacles.isavalidstate(self, x)
+        n = Narrow()
+        gs2 = discretizer.GridDynamicSystem(n, (5, 5, 3), (2, 2), 0.1)
+        d2 = dynamicprogramming.DynamicProgrammingWithLookUpTable(gs2, costfunction.QuadraticCostFunction.from_sys(n))
+        assert d2.tier == "table"

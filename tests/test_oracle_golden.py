@@ -347,3 +347,31 @@ def test_spline_value_iteration_golden():
                 assert np.array_equal(pi[clear], g["%s_pi_%d" % (tag, k)][clear])
                 assert (pi != g["%s_pi_%d" % (tag, k)]).mean() < 0.02
             J = Jn
+
+
+# --------------------------------------------------------------- three-dimensional systems (SURVEY 8 f3 remainder)
+from cases3d import CASES3D, case3d  # noqa: E402
+
+
+@pytest.mark.parametrize("name", CASES3D)
+def test_3d_systems_tables_and_sweeps_match_reference(name):
+    """Helicopter tunnel (obstacles + domain-check cost), car parking (obstacles, two inputs, tan of the steering
+    angle), active suspension (ground-profile tables): x_next_table and the validity masks bit for bit, G to the last
+    ulp of the BLAS dot products, J / pi of the look-up-table class after 1 and 5 sweeps."""
+    g, p, alpha = case3d(name)
+    ids = np.arange(p.nodes_n)
+    xn, x_ok, a_ok, G = O.cells(p, ids)
+    assert np.array_equal(xn, g["x_next_table"])
+    assert np.array_equal(x_ok, g["x_next_isok"]) and np.array_equal(a_ok, g["action_isok"])
+    np.testing.assert_allclose(G, g["G"], rtol=1e-14, atol=0)
+    J = O.terminal_cost(p)
+    np.testing.assert_allclose(J, g["J0"], rtol=1e-14, atol=0)
+    for k in range(1, 6):
+        J, pi = O.sweep(p, J, alpha)
+        if k in (1, 5):
+            np.testing.assert_allclose(J, g["J_%d" % k], rtol=1e-12, atol=1e-12)
+            assert np.array_equal(pi, g["pi_%d" % k])
+    if "kat_X" in g.files:                          # f and isavalidstate at random points around the box
+        X, U = g["kat_X"], g["kat_U"]
+        valid = O.state_valid(p, tuple(X[:, d] for d in range(3)))
+        assert np.array_equal(valid, g["kat_valid"])
