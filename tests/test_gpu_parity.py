@@ -371,9 +371,12 @@ def test_f32_kernel_variants_agree(name, monkeypatch):
         ref, _ = O.sweep(p, ref, alpha)
     outs = {}
     for tag, env in [("lean", {}), ("lean_split", {"PVI_LSPLIT": "2"}), ("lean_nosplit", {"PVI_LSPLIT": "0"}),
+                     ("lean_persist", {"PVI_LSPLIT": "0", "PVI_PERSIST": "1"}),
+                     ("lean_1buf", {"PVI_LSPLIT": "0", "PVI_PERSIST": "1", "PVI_NBUF": "1", "PVI_WPC": "1"}),
+                     ("lean_allnear", {"PVI_LSPLIT": "0", "PVI_DBG": "128"}),
                      ("tile", {"PVI_NO_LEAN": "1", "PVI_TILE": "1"}), ("fast", {"PVI_NO_LEAN": "1"}),
                      ("exact32", {"PVI_NO_FAST": "1"})]:
-        for k in ("PVI_LSPLIT", "PVI_NO_LEAN", "PVI_TILE", "PVI_NO_FAST"):
+        for k in ("PVI_LSPLIT", "PVI_NO_LEAN", "PVI_TILE", "PVI_NO_FAST", "PVI_PERSIST", "PVI_NBUF", "PVI_WPC", "PVI_DBG"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -393,9 +396,19 @@ def test_f32_kernel_variants_agree(name, monkeypatch):
     if name == "twolink_11p4x3x3":
         assert path_of(outs["lean"][2]) == "path=exact-f32" and "float64 dynamics" in outs["lean"][2], outs["lean"][2]
     else:
-        for tag in ("lean", "lean_split", "lean_nosplit"):
-            assert path_of(outs[tag][2]) == "path=lean", (tag, outs[tag][2])
-        assert "lsplit=2" in outs["lean_split"][2] and "lsplit=0" in outs["lean_nosplit"][2]
+        assert path_of(outs["lean"][2]) == "path=lean", outs["lean"][2]
+        assert path_of(outs["lean_split"][2]) == "path=lean" and "lsplit=2" in outs["lean_split"][2]
+        assert path_of(outs["lean_nosplit"][2]) == "path=lean" and "lsplit=0" in outs["lean_nosplit"][2]
+        # the persistent form (opt-in experiment) walks several tiles per workgroup (strided tile lists, prefetch of the
+        # next tile, one or two window buffers): same arithmetic per node, so bit-identical to one tile per workgroup
+        for tag in ("lean_persist", "lean_1buf"):
+            assert path_of(outs[tag][2]) == "path=lean-persistent" and "lsplit=0" in outs[tag][2], outs[tag][2]
+            assert np.array_equal(outs[tag][0], outs["lean_nosplit"][0]) and np.array_equal(outs[tag][1], outs["lean_nosplit"][1])
+        assert "nbuf=1" in outs["lean_1buf"][2] and "wpc=1" in outs["lean_1buf"][2]
+        # exact pass only where set-up found a float32 validity that differs from the float64 one, against the exact
+        # pass on EVERY node with an action inside the guard band (round 1): the same J and pi, bit for bit
+        assert np.array_equal(outs["lean_allnear"][0], outs["lean_nosplit"][0])
+        assert np.array_equal(outs["lean_allnear"][1], outs["lean_nosplit"][1])
         assert path_of(outs["tile"][2]) == "path=tile" and path_of(outs["fast"][2]) == "path=fast"
     assert path_of(outs["exact32"][2]) == "path=exact-f32"
 
@@ -545,7 +558,7 @@ def test_full_size_sampled_against_c_oracle(name):
         tv0, tv1 = (int(v) for v in fields["tile"].split("x"))
         assert int(fields["dma16"]) == dma16 and int(fields["lsplit"]) == 0 and int(fields["tb_tile"]) == 1, desc
         assert tv0 * tv1 <= 512 and tv0 * tv1 > 256 and int(fields["lds_bytes"]) > 48 * 1024, desc
-        assert int(fields["grid"].split("x")[0]) >= p.dims[0] * p.dims[1] * 6, desc
+        assert int(fields["grid"].split("x")[0]) >= p.dims[0] * p.dims[1] * 6, desc        # tiles
     c = CO.CProblem(p)
     f32 = cfg["dtype"] == "float32"
     blocks = _sample_blocks(p.dims)
