@@ -83,6 +83,7 @@ struct SweepCtl {
     double tol;                // stop criterion (dynamicprogramming.py:305), < 0: never
     int k;                     // sweep index inside the batch
     unsigned nblocks;
+    int split_finish;          // 1: the statistics are folded by k_sweep_finish after the sweep kernel (large grids)
 };
 
 // order-preserving encoding of doubles for integer atomicMax
@@ -479,7 +480,9 @@ __device__ __forceinline__ int wave_max_key(int v) {
     v = dpp_imax_step<0x143, 0xc>(v);
     return __builtin_amdgcn_readlane(v, 63);
 }
-// `red`: 48 ints of LDS scratch
+// `red`: 48 ints of LDS scratch.  WAIT: the publishing threads consume the atomics' return values, i.e. they have been
+// performed when the function returns (needed by the in-kernel ticket of sweep_finish); without it they are fire and forget.
+template <bool WAIT = true>
 __device__ inline void block_stats_f32_at(int* red, float j, float dmax, float ndmin, unsigned long long* slot) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     const int kj = wave_max_key(f32_key(j)), kd = wave_max_key(f32_key(dmax)), kn = wave_max_key(f32_key(ndmin));
@@ -492,9 +495,14 @@ __device__ inline void block_stats_f32_at(int* red, float j, float dmax, float n
     if (threadIdx.x < 3) {
         int v = red[16 * threadIdx.x];
         for (int w = 1; w < nw; ++w) v = max(v, red[16 * threadIdx.x + w]);
-        const unsigned long long old =
-            atomicMax(&slot[4 * (blockIdx.x & (STAT_SHARDS - 1)) + threadIdx.x], enc_f64((double)f32_unkey(v)));
-        asm volatile("" ::"v"(old));  // consume the return value: the atomic has been performed
+        if constexpr (WAIT) {
+            const unsigned long long old =
+                atomicMax(&slot[4 * (blockIdx.x & (STAT_SHARDS - 1)) + threadIdx.x], enc_f64((double)f32_unkey(v)));
+            asm volatile("" ::"v"(old));  // consume the return value: the atomic has been performed
+        } else {
+            (void)__hip_atomic_fetch_max(&slot[4 * (blockIdx.x & (STAT_SHARDS - 1)) + threadIdx.x],
+                                         enc_f64((double)f32_unkey(v)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -558,6 +566,28 @@ __device__ inline void sweep_finish(const SweepCtl& sc) {
                 sc.ctrl->ticket = 0u;
             }
         }
+    }
+}
+
+// The fold of sweep_finish as its own one-wave launch (SweepCtl::split_finish).  With ~10^5..10^6 tiles and two workgroups
+// per CU, the ticket protocol keeps every workgroup's slot occupied for two dependent atomic round trips after its last
+// useful instruction (C3: 0.44 ms of 4.9 ms per sweep); a kernel boundary orders the statistics for free.
+__global__ void k_sweep_finish(SweepCtl sc) {
+    const int l = threadIdx.x;
+    double v0 = dec_f64(atomicMax(&sc.slot[4 * l + 0], 0ull));
+    double v1 = dec_f64(atomicMax(&sc.slot[4 * l + 1], 0ull));
+    double v2 = dec_f64(atomicMax(&sc.slot[4 * l + 2], 0ull));
+    v0 = wave_max(v0);
+    v1 = wave_max(v1);
+    v2 = wave_max(v2);
+    if (l == 0 && !sc.ctrl->done) {  // (a batch that has stopped leaves its record alone)
+        const double dmin = -v2, delta = fmax(fabs(v1), fabs(dmin));
+        sc.result[0] = v0;
+        sc.result[1] = v1;
+        sc.result[2] = dmin;
+        sc.result[3] = delta;
+        sc.ctrl->k_done = sc.k + 1;
+        if (sc.tol >= 0.0 && delta <= sc.tol) sc.ctrl->done = 1;
     }
 }
 
@@ -3007,6 +3037,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         if (h->lean_ok) {
             const float al = (float)alpha;
             sc.nblocks = h->lean_grid.x;
+            sc.split_finish = (sc.nblocks >= 16384u && !getenv("PVI_NO_SPLIT_FINISH")) ? 1 : 0;
 #define LEAN3(DYN, U, NP)                                                                                           \
     {                                                                                                               \
         auto kfn = k_sweep_lean<DYN, PI_T, U, NP>;                                                                  \
@@ -3016,6 +3047,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         }                                                                                                           \
         hipLaunchKernelGGL(kfn, h->lean_grid, h->lean_block, h->lean_lds, st, h->P, h->LP, h->F.act, h->LP.actc, Jin, Jout, pi, al, \
                            sc);                                                                                     \
+        if (sc.split_finish) hipLaunchKernelGGL(k_sweep_finish, 1, STAT_SHARDS, 0, st, sc);                         \
     }
 #define LEAN(DYN)              \
     if (h->LP.lsplit == 0)     \
@@ -3175,6 +3207,7 @@ static int launch_sweep(pvi_problem* h, int src, double alpha, hipStream_t st, i
     sc.tol = tol;
     sc.k = k;
     sc.nblocks = 0;
+    sc.split_finish = 0;
     if (h->d.dtype == PVI_F64)
         return h->pi_size == 1 ? launch_sweep_t<double, unsigned char>(h, src, alpha, st, sc)
                                : launch_sweep_t<double, unsigned short>(h, src, alpha, st, sc);
