@@ -791,6 +791,206 @@ __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ 
 
 
 // =================================================================================================
+// Float64 sweep, second form ("exact-f64v2"): the arithmetic of k_sweep -- every value the same bit for bit -- issued with
+// fewer instructions.  k_sweep is bound by SIMD issue of float64 work (C2 in float64: ~460 clk per 64 cells), so what is
+// cut is instructions, not memory traffic:
+//   * the state box equals the grid box (checked by the host), so ONE pair of compares per axis decides validity and fill;
+//     a node whose position row leaves the box skips its action loop (every Q is INF + alpha*0 = INF, arg 0);
+//   * per-action constants {u0, u1, gu, isavalidinput} sit in one 32-byte record: one scalar load per action;
+//   * the fraction (x - l0) / (l1 - l0) is formed with a tabulated reciprocal: r = RN(1/d) from the host, q = RN(t r),
+//     e = t - q d (one FMA, exact), y = RN(q + e r).  With a correctly rounded reciprocal this is the correctly rounded
+//     quotient (Markstein's theorem; the hardware's own division sequence is the same recurrence behind a scaled rcp),
+//     i.e. the bits of the reference's division -- 3 instructions instead of 13 per axis and cell;
+//   * grid levels and reciprocals share one LDS table ({level, reciprocal} per entry: one 16-byte read);
+//   * 4-D: the products of the position-axis weights -- the first two factors of scipy's weight product, the same for
+//     every action of a node -- are formed once per node;
+//   * 32-bit offsets into J while the stored slab is below 2 GiB (scalar base + 32-bit lane offset addressing).
+// =================================================================================================
+struct Act64 {
+    double u0, u1, gu, aok;
+};
+
+template <bool OFF32>
+struct JOff;
+template <>
+struct JOff<true> {
+    typedef unsigned T;
+};
+template <>
+struct JOff<false> {
+    typedef long long T;
+};
+
+template <bool OFF32>
+__device__ __forceinline__ const double* j_at(const double* __restrict__ J, typename JOff<OFF32>::T elem) {
+    if constexpr (OFF32)
+        return (const double*)((const char*)J + (size_t)(elem * 8u));  // zero-extended 32-bit byte offset
+    else
+        return J + elem;
+}
+
+// interval of x on a linspace axis (as find_interval_lv) from the {level, reciprocal} table, and the fraction by the
+// reciprocal recurrence above
+__device__ __forceinline__ int interval_frac64(const double2* __restrict__ tab, int N, double lo, double inv_step, double x,
+                                               double& y) {
+    const double t0 = floor((x - lo) * inv_step);
+    int i = (t0 < 0.0) ? 0 : (t0 > (double)(N - 2) ? N - 2 : (int)t0);
+    double2 e0;
+    double l1;
+    for (;;) {
+        e0 = tab[i];
+        l1 = tab[i + 1].x;
+        if (i > 0 && x < e0.x)
+            --i;
+        else if (i < N - 2 && x >= l1)
+            ++i;
+        else
+            break;
+    }
+    const double t = x - e0.x, d = l1 - e0.x, r = e0.y;
+    const double q = t * r;
+    const double e = __builtin_fma(-q, d, t);
+    y = __builtin_fma(e, r, q);
+    return i;
+}
+
+template <int DYN, typename PI_T, bool OFF32>
+__global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restrict__ Jin, double* __restrict__ Jout,
+                                                 PI_T* __restrict__ pi, double alpha, SweepCtl sc,
+                                                 const Act64* __restrict__ act64, const double2* __restrict__ levr) {
+    using D = Dyn<DYN>;
+    constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M;
+    typedef typename JOff<OFF32>::T off_t;
+    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+    if (sc.ctrl->done) return;
+    extern __shared__ __attribute__((aligned(16))) double2 lr_lds[];
+    const double2* tab[N];
+    {
+        int at = 0;
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+            for (int i = threadIdx.x; i < P.dim[d]; i += blockDim.x) lr_lds[at + i] = levr[at + i];
+            tab[d] = lr_lds + at;
+            at += P.dim[d];
+        }
+        __syncthreads();
+    }
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
+    double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
+    if (o < owned) {
+        int idx[N];
+        decode_node<N>(P, o, idx);
+        double x[N], dx[N];
+        long long self = (long long)(idx[0] - P.store_begin) * P.strd[0];
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+            x[d] = tab[d][idx[d]].x;
+            dx[d] = x[d] - P.xbar[d];
+            if (d > 0) self += idx[d] * P.strd[d];
+        }
+        const double gx = quad_form<N>(P.Q, dx);
+        const bool on_target = P.ontarget && (l2norm<N>(dx) < P.EPS);
+        // position rows of x_next: the same for every action (true division: once per node)
+        bool pos_in = true, halo_bad = false;
+        int ci[N];
+        double y[N];
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) {
+            const double xn = x[DOF + i] * P.dt + x[i];
+            pos_in = pos_in && !(xn < P.glo[i]) && !(xn > P.ghi[i]);
+            ci[i] = find_interval(P.lev[i], P.dim[i], P.glo[i], P.inv_step[i], xn);
+            const double l0 = tab[i][ci[i]].x;
+            y[i] = (xn - l0) / (tab[i][ci[i] + 1].x - l0);
+        }
+        double best = P.INF;  // position row outside the box: every action costs INF + alpha*0, the first one wins
+        int arg = 0;
+        if (pos_in) {
+            int r0 = ci[0];
+            if (r0 < P.store_begin || r0 + 1 >= P.store_end) {
+                halo_bad = true;
+                r0 = min(max(r0, P.store_begin), P.store_end - 2);
+            }
+            off_t base = (off_t)((long long)(r0 - P.store_begin) * P.strd[0]);
+#pragma unroll
+            for (int i = 1; i < DOF; ++i) base += (off_t)(ci[i] * P.strd[i]);
+            off_t vs[DOF];
+#pragma unroll
+            for (int i = 0; i < DOF; ++i) vs[i] = (off_t)P.strd[DOF + i];
+            const off_t s0 = (off_t)P.strd[0], s1 = DOF == 2 ? (off_t)P.strd[1] : (off_t)0;
+            // 4-D: scipy's weight product over the two position axes (1 * w0 * w1: the first factor is exact)
+            double wp[4] = {0.0, 0.0, 0.0, 0.0};
+            if constexpr (DOF == 2) {
+                const double a0 = 1.0 - y[0], a1 = 1.0 - y[1];
+                wp[0] = a0 * a1;
+                wp[1] = a0 * y[1];
+                wp[2] = y[0] * a1;
+                wp[3] = y[0] * y[1];
+            }
+            double tr[8];
+            D::trig_from_tables(P, idx, tr);
+            D dyn;
+            dyn.init(P.c, x, tr);
+            for (int a = 0; a < P.A; ++a) {
+                const Act64 ac = act64[a];  // wave-uniform: one scalar load
+                double u[2] = {ac.u0, ac.u1}, acc[DOF], xnv[DOF];
+                dyn.accel(u, acc);
+                bool inb = true;
+#pragma unroll
+                for (int i = 0; i < DOF; ++i) {
+                    const int d = DOF + i;
+                    xnv[i] = acc[i] * P.dt + x[d];
+                    inb = inb && !(xnv[i] < P.glo[d]) && !(xnv[i] > P.ghi[d]);
+                }
+                double Jn = 0.0;
+                if (inb) {
+                    off_t b = base;
+                    double yv[DOF];
+#pragma unroll
+                    for (int i = 0; i < DOF; ++i) {
+                        const int d = DOF + i;
+                        const int c = interval_frac64(tab[d], P.dim[d], P.glo[d], P.inv_step[d], xnv[i], yv[i]);
+                        b += (off_t)c * vs[i];
+                    }
+                    if constexpr (DOF == 1) {  // evaluate_linear_2d
+                        const d2u q0 = *(const d2u*)j_at<OFF32>(Jin, b), q1 = *(const d2u*)j_at<OFF32>(Jin, b + s0);
+                        const double a0 = 1.0 - y[0], a1 = 1.0 - yv[0];
+                        Jn = q0.x * a0 * a1 + q0.y * a0 * yv[0] + q1.x * y[0] * a1 + q1.y * y[0] * yv[0];
+                    } else {  // _evaluate_linear: corners with axis 0 slowest, weights multiplied axis by axis
+                        const double b2[2] = {1.0 - yv[0], yv[0]}, b3[2] = {1.0 - yv[1], yv[1]};
+#pragma unroll
+                        for (int pr = 0; pr < 8; ++pr) {
+                            const int c0 = pr >> 2, c1 = (pr >> 1) & 1, c2 = pr & 1;
+                            const off_t off = b + (c0 ? s0 : (off_t)0) + (c1 ? s1 : (off_t)0) + (c2 ? vs[0] : (off_t)0);
+                            const d2u r = *(const d2u*)j_at<OFF32>(Jin, off);
+                            const double w = wp[c0 * 2 + c1] * b2[c2];
+                            Jn = Jn + r.x * (w * b3[0]);
+                            Jn = Jn + r.y * (w * b3[1]);
+                        }
+                    }
+                }
+                const double g = on_target ? 0.0 : (gx + ac.gu);
+                const double G = (inb && ac.aok != 0.0) ? g * P.dt : P.INF;
+                const double q = G + alpha * Jn;
+                if (a == 0 || q < best) {
+                    best = q;
+                    arg = a;
+                }
+            }
+        }
+        if (halo_bad) atomicOr(&sc.ctrl->halo_err, 1);
+        Jout[self] = best;
+        pi[o] = (PI_T)arg;
+        const double d = best - Jin[self];
+        st_j = best;
+        st_dmax = d;
+        st_ndmin = -d;
+    }
+    block_stats(st_j, st_dmax, st_ndmin, sc.slot);
+    sweep_finish(sc);
+}
+
+// =================================================================================================
 // Three-dimensional systems (n = 3; the reference's helicopter / car-parking / active-suspension demos).  They are not
 // mechanical (no [q; dq] split), so they get their own closed forms and one thread-per-node sweep: x_next in float64 in
 // the reference's operation order, validity = box + obstacle list, look-up-table semantics Q = G + alpha*J_interp with
@@ -2104,6 +2304,10 @@ struct pvi_problem {
     bool march_lds_attr = false;
     int march_block = 256;
     const int* aok32 = nullptr;  // isavalidinput per action as int32 (scalar loads in the exact kernel)
+    const Act64* act64 = nullptr;   // float64 second form (k_sweep64): per-action records, {level, reciprocal} tables
+    const double2* levr = nullptr;
+    bool use64 = false;
+    size_t levr_bytes = 0;
     SplineP SP;               // bicubic-spline interpolation mode (sweep_spline.inc)
     bool spline = false;
 };
@@ -2699,6 +2903,29 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
         bool box_is_grid = true;
         for (int i = 0; i < d->n; ++i)
             box_is_grid = box_is_grid && d->x_lb[i] == P.glo[i] && d->x_ub[i] == P.ghi[i];
+        if (d->dtype == PVI_F64 && d->dynamics_id != PVI_DYN_TABLE && !is_dyn3(d->dynamics_id) && box_is_grid &&
+            !getenv("PVI_NO_SWEEP64")) {
+            // float64 second form: {u0, u1, gu, isavalidinput} per action, {level, RN(1 / (next level - level))} per level
+            std::vector<Act64> a64((size_t)A);
+            for (long long a = 0; a < A; ++a)
+                a64[a] = Act64{utab[a * d->m], d->m > 1 ? utab[a * d->m + 1] : 0.0, gu[a], aok[a] ? 1.0 : 0.0};
+            size_t nlev = 0;
+            for (int i = 0; i < d->n; ++i) nlev += (size_t)d->x_dim[i];
+            std::vector<double2> lr(nlev);
+            size_t at = 0;
+            for (int i = 0; i < d->n; ++i)
+                for (int k = 0; k < d->x_dim[i]; ++k, ++at) {
+                    const double l0 = d->x_level[i][k];
+                    const double dd = k + 1 < d->x_dim[i] ? d->x_level[i][k + 1] - l0 : 1.0;
+                    lr[at] = make_double2(l0, 1.0 / dd);  // IEEE division: the correctly rounded reciprocal
+                }
+            h->levr_bytes = nlev * sizeof(double2);
+            if (h->levr_bytes <= 48 * 1024) {
+                if ((rc = dev_upload(h, a64.data(), a64.size(), &h->act64))) return bail(rc);
+                if ((rc = dev_upload(h, lr.data(), lr.size(), &h->levr))) return bail(rc);
+                h->use64 = true;
+            }
+        }
         h->fast_ok = d->dtype == PVI_F32 && d->dynamics_id != PVI_DYN_TABLE && !is_dyn3(d->dynamics_id) && box_is_grid &&
                      h->stored < 0x7fffffffLL && !getenv("PVI_NO_FAST");
         // the per-sweep bounding-box tile kernel predates the lean kernel; where the lean window does not fit LDS its
@@ -2809,6 +3036,7 @@ extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
         return PVI_OK;
     }
     const char* path = h->d.dynamics_id == PVI_DYN_TABLE ? (h->packed ? "table-packed" : "table")
+                       : (h->d.dtype == PVI_F64 && h->use64) ? "exact-f64v2"
                        : h->d.dtype == PVI_F64 ? "exact-f64"
                        : h->march_ok ? "march"
                        : (h->lean_ok && h->lean_persist) ? "lean-persistent"
@@ -3124,6 +3352,29 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     else                                                                                                               \
         hipLaunchKernelGGL((k_sweep<DYN, REAL, PI_T, false>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha, sc, h->P.utab,   \
                            h->P.gu, h->aok32);
+    if constexpr (sizeof(REAL) == 8) {
+        if (h->use64) {
+            const bool off32 = (unsigned long long)h->stored * 8ull < (1ull << 32);
+#define S64(DYN)                                                                                                      \
+    if (off32)                                                                                                        \
+        hipLaunchKernelGGL((k_sweep64<DYN, PI_T, true>), g, 256, h->levr_bytes, st, h->P, Jin, Jout, pi, alpha, sc,   \
+                           h->act64, h->levr);                                                                        \
+    else                                                                                                              \
+        hipLaunchKernelGGL((k_sweep64<DYN, PI_T, false>), g, 256, h->levr_bytes, st, h->P, Jin, Jout, pi, alpha, sc,  \
+                           h->act64, h->levr);
+            switch (h->d.dynamics_id) {
+                case PVI_DYN_PENDULUM: S64(PVI_DYN_PENDULUM) break;
+                case PVI_DYN_CARTPOLE: S64(PVI_DYN_CARTPOLE) break;
+                case PVI_DYN_TWOLINK: S64(PVI_DYN_TWOLINK) break;
+                case PVI_DYN_NODE_1x1: S64(PVI_DYN_NODE_1x1) break;
+                case PVI_DYN_NODE_2x1: S64(PVI_DYN_NODE_2x1) break;
+                default: S64(PVI_DYN_NODE_2x2) break;
+            }
+#undef S64
+            HIPCHK(hipGetLastError());
+            return PVI_OK;
+        }
+    }
 #define SWEEP3(DYN)                                                                                                  \
     hipLaunchKernelGGL((k_sweep3<DYN, REAL, PI_T>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha, sc, h->P.utab, h->P.gu, \
                        h->aok32)
