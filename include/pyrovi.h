@@ -17,6 +17,7 @@
 #ifndef PYROVI_H
 #define PYROVI_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -233,6 +234,47 @@ int pvi_set_pi(pvi_handle h, const int64_t* pi_rows, int32_t row0, int32_t nrows
    with in-kernel dynamics. */
 int pvi_rollout(pvi_handle h, int64_t B, const double* X0, int32_t npts, double dt, double* X_traj, double* U_traj,
                 double* X_end);
+
+/* ---- multi-GPU: axis-0 slabs, one process per GPU, RCCL inside the library (no reference counterpart) ------ */
+/* Rank r owns a contiguous block of rows of axis 0 and stores `halo_rows` more on either side.  One sweep =
+   boundary kernels -> [halo exchange with the +-1 neighbours (ncclSend / ncclRecv in one group) || interior kernel];
+   the statistics (max J, max d, min d) are all-reduced (ncclAllReduce max, 3 doubles) for the stop test / the last
+   sweep.  Slabs thinner than the halo fall back to broadcasting every slab.  Results are those of pvi_sweep on the
+   whole grid, bit for bit.  RCCL is loaded at run time (librccl.so.1; PVI_RCCL_LIB overrides the name). */
+#define PVI_COMM_ID_BYTES 128
+typedef struct pvi_shard_s* pvi_shard;
+/* ncclGetUniqueId: call on ONE rank and hand the 128 bytes to the others by any means (MPI, a file, a TCP store) */
+int pvi_comm_unique_id(uint8_t* id128);
+/* `whole` describes the WHOLE grid (row_begin / row_end / halo_* / ext_* are ignored; device = this rank's GPU).
+   halo_rows = ceil(max |x_next_0 - x_0| / dx_0) + 1 (mechanical systems: max |dq_0| dt / dx_0).  id128 may be NULL when
+   world == 1 (no communicator).  overlap != 0: boundary-first schedule on two streams. */
+int pvi_shard_create(const pvi_desc* whole, int32_t rank, int32_t world, int32_t halo_rows, const uint8_t* id128,
+                     int32_t overlap, pvi_shard* out);
+/* Bring-your-own transport (MPI without RCCL, or a host-staged test harness): the same slab schedule with the two
+   inter-rank steps handed to the caller.  Both callbacks run on the calling host thread, synchronously.
+     sendrecv : exchange halo rows of the current cost-to-go with the +-1 neighbours.  The four buffers are DEVICE
+                pointers (NULL where there is no neighbour); the data to send is complete once `stream` has drained, so
+                a host-staged implementation synchronises `stream` first; received rows must be in place on return.
+     max3     : in-place maximum over all ranks of three host doubles.
+   Slabs must be at least `halo_rows` thick (no broadcast fall-back on this path). */
+typedef struct pvi_transport {
+    void* user;
+    int (*sendrecv)(void* user, const void* send_lo, void* recv_lo, size_t lo_send_bytes, size_t lo_recv_bytes,
+                    const void* send_hi, void* recv_hi, size_t hi_send_bytes, size_t hi_recv_bytes, void* stream);
+    int (*max3)(void* user, double v[3]);
+} pvi_transport;
+int pvi_shard_create_with_transport(const pvi_desc* whole, int32_t rank, int32_t world, int32_t halo_rows,
+                                    const pvi_transport* transport, int32_t overlap, pvi_shard* out);
+void pvi_shard_destroy(pvi_shard s);
+int pvi_shard_rows(pvi_shard s, int32_t* row_begin, int32_t* row_end);
+int pvi_shard_terminal_cost(pvi_shard s);
+/* compute_steps / solve_bellman_equation on the sharded grid (dynamicprogramming.py:265-314): up to max_sweeps backups,
+   stop when tol >= 0 and delta <= tol (every rank stops at the same sweep: the statistics are all-reduced).
+   stats4 = (max J, max d, min d, delta) of the WHOLE grid for the last executed sweep. */
+int pvi_shard_sweep(pvi_shard s, int32_t max_sweeps, double alpha, double tol, double* stats4, int32_t* sweeps_done);
+int pvi_shard_get_J(pvi_shard s, double* J_owned_rows);   /* this rank's rows, float64 */
+int pvi_shard_get_pi(pvi_shard s, int64_t* pi_owned_rows);
+int pvi_shard_describe(pvi_shard s, char* buf, int32_t n);
 
 /* ---- batched dynamics ------------------------------------------------------------------------ */
 /* dX[b] = f(X[b], U[b]) for B states (mechanical.py:238-263); host pointers, float64 */

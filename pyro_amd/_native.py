@@ -81,7 +81,21 @@ SYMBOLS = {
     "pvi_set_pi": (C.c_int, [_h, C.POINTER(C.c_int64), C.c_int32, C.c_int32]),
     "pvi_rollout": (C.c_int, [_h, C.c_int64, _dp, C.c_int32, C.c_double, _dp, _dp, _dp]),
     "pvi_eval_f": (C.c_int, [C.c_int32, _dp, C.c_int32, C.c_int32, C.c_int64, _dp, _dp, _dp]),
+    # multi-GPU: slabs of axis 0 with RCCL inside the library
+    "pvi_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "pvi_shard_create": (C.c_int, [C.POINTER(pvi_desc), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint8), C.c_int32,
+                                   C.POINTER(_h)]),
+    "pvi_shard_create_with_transport": (C.c_int, [C.POINTER(pvi_desc), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                                  C.POINTER(_h)]),
+    "pvi_shard_destroy": (None, [_h]),
+    "pvi_shard_rows": (C.c_int, [_h, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "pvi_shard_terminal_cost": (C.c_int, [_h]),
+    "pvi_shard_sweep": (C.c_int, [_h, C.c_int32, C.c_double, C.c_double, _dp, C.POINTER(C.c_int32)]),
+    "pvi_shard_get_J": (C.c_int, [_h, _dp]),
+    "pvi_shard_get_pi": (C.c_int, [_h, C.POINTER(C.c_int64)]),
+    "pvi_shard_describe": (C.c_int, [_h, C.c_char_p, C.c_int32]),
 }
+COMM_ID_BYTES = 128
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpyrovi.so")
 _lib = None
@@ -145,7 +159,7 @@ class Problem:
 
     def __init__(self, x_levels, u_levels, x_lb, x_ub, u_lb, u_ub, dt, dtype="float64", dynamics_id=DYN_TABLE,
                  dyn_params=(), trig=(), cost=None, rows=None, halo=(0, 0), device=0, ext_J=None, ext_pi=None,
-                 table_inf=0.0, flags=0, obstacles=None, act_aux=None):
+                 table_inf=0.0, flags=0, obstacles=None, act_aux=None, _create=True):
         L = lib()
         self._keep = []                      # host buffers the descriptor points to
         d = pvi_desc()
@@ -220,6 +234,11 @@ class Problem:
         self.rows = (int(r0), int(r1))
         self.store_rows = (max(0, r0 - halo[0]), min(self.dims[0], r1 + halo[1]))
         self._h = _h()
+        self._desc = d
+        self.actions_n = int(np.prod(self.u_dims))
+        if not _create:                      # descriptor only (ShardedProblem hands it to pvi_shard_create)
+            self.plane = int(np.prod(self.dims[1:]))
+            return
         check(L.pvi_create(C.byref(d), C.byref(self._h)))
         self.plane = L.pvi_plane_size(self._h)
         self.owned_nodes = L.pvi_owned_nodes(self._h)
@@ -361,3 +380,87 @@ class Problem:
         out = np.empty(tuple(self.dims), dtype=np.float64)
         check(lib().pvi_spline_coefficients(self._h, _ptr(out)))
         return out
+
+
+SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
+                          C.c_size_t, C.c_size_t, C.c_void_p)
+MAX3_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double))
+
+
+class pvi_transport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("sendrecv", SENDRECV_FN), ("max3", MAX3_FN)]
+
+
+def comm_unique_id():
+    """128 opaque bytes naming a new RCCL communicator (pvi_comm_unique_id): create on one rank, give to all."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    check(lib().pvi_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class ShardedProblem:
+    """One rank's slab of a grid cut along axis 0, with the halo exchange and the statistics all-reduce done by RCCL
+    inside the library (pvi_shard_*).  `problem_kwargs` are the arguments of Problem for the WHOLE grid."""
+
+    def __init__(self, rank, world, halo_rows, comm_id=None, overlap=True, transport=None, **problem_kwargs):
+        self._desc_owner = Problem(_create=False, **problem_kwargs)     # keeps the host buffers alive during create
+        self.rank, self.world = int(rank), int(world)
+        self.plane = self._desc_owner.plane
+        self.dtype = self._desc_owner.dtype
+        self._h = _h()
+        idp = None
+        if comm_id is not None:
+            if len(comm_id) != COMM_ID_BYTES:
+                raise ValueError("comm_id must be %d bytes" % COMM_ID_BYTES)
+            idp = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(comm_id)
+        if transport is not None:
+            # (sendrecv(send_lo, recv_lo, lo_send_bytes, lo_recv_bytes, send_hi, recv_hi, hi_send_bytes, hi_recv_bytes,
+            #  stream) -> 0, max3(ctypes double[3]) -> 0): the caller moves the halos, e.g. over MPI or host-staged
+            sr, mx = transport
+            self._transport = pvi_transport(None, SENDRECV_FN(lambda u, *a: int(sr(*a) or 0)),
+                                            MAX3_FN(lambda u, v: int(mx(v) or 0)))
+            check(lib().pvi_shard_create_with_transport(C.byref(self._desc_owner._desc), self.rank, self.world,
+                                                        int(halo_rows), C.addressof(self._transport), int(bool(overlap)),
+                                                        C.byref(self._h)))
+        else:
+            check(lib().pvi_shard_create(C.byref(self._desc_owner._desc), self.rank, self.world, int(halo_rows), idp,
+                                         int(bool(overlap)), C.byref(self._h)))
+        r0, r1 = C.c_int32(), C.c_int32()
+        check(lib().pvi_shard_rows(self._h, C.byref(r0), C.byref(r1)))
+        self.rows = (r0.value, r1.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pvi_shard_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def terminal_cost(self):
+        check(lib().pvi_shard_terminal_cost(self._h))
+
+    def sweep(self, max_sweeps, alpha=1.0, tol=-1.0):
+        """-> (stats4 of the whole grid for the last sweep, sweeps done)."""
+        st = np.zeros(4)
+        done = C.c_int32(0)
+        check(lib().pvi_shard_sweep(self._h, int(max_sweeps), float(alpha), float(tol), _ptr(st), C.byref(done)))
+        return st, done.value
+
+    def get_J(self):
+        out = np.empty((self.rows[1] - self.rows[0]) * self.plane)
+        check(lib().pvi_shard_get_J(self._h, _ptr(out)))
+        return out
+
+    def get_pi(self):
+        out = np.empty((self.rows[1] - self.rows[0]) * self.plane, dtype=np.int64)
+        check(lib().pvi_shard_get_pi(self._h, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
+
+    def describe(self):
+        buf = C.create_string_buffer(1024)
+        check(lib().pvi_shard_describe(self._h, buf, 1024))
+        return buf.value.decode()

@@ -3981,3 +3981,5 @@ extern "C" int pvi_eval_f(int32_t dyn, const double* params, int32_t n, int32_t 
     if (e != hipSuccess) return fail(PVI_EHIP, "pvi_eval_f failed: %s", hipGetErrorString(e));
     return PVI_OK;
 }
+
+#include "shard.inc"

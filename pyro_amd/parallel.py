@@ -8,9 +8,14 @@ The reference has no counterpart (single thread); the partition follows SURVEY.m
     rank r owns rows [r0, r1), stores [r0-h, r1+h) clipped to the grid;
     h = ceil(max|x_next_0 - x_0| / dx_0) + 1; for mechanical systems x_next_0 - x_0 = dq_0*dt exactly.
 
-The compute backend is pluggable so that the exchange logic can be exercised on CPU:
-  HipSlab     -- product path: libpyrovi handle over caller-owned torch buffers (ext_J / ext_pi)
-  (tests inject an oracle-backed slab; the product never imports the oracle)
+Two drivers:
+  RcclValueIteration    -- the product path: slab, halo exchange (ncclSend / ncclRecv), statistics all-reduce and the
+                           boundary-first overlap all live INSIDE libpyrovi (pvi_shard_*, include/pyrovi.h); the host
+                           only hands every rank the communicator id.  No torch anywhere.
+  ShardedValueIteration -- the same schedule driven from Python over torch.distributed, with a pluggable compute
+                           backend so that the partition / exchange logic runs on CPU (gloo; tests inject an
+                           oracle-backed slab -- the product never imports the oracle) and on one shared GPU:
+                             HipSlab -- libpyrovi handles over caller-owned torch buffers (ext_J / ext_pi)
 """
 import math
 
@@ -265,3 +270,35 @@ class ShardedValueIteration:
         objs = [None] * self.world
         self.dist.all_gather_object(objs, (J, pi))
         return np.concatenate([o[0] for o in objs]), np.concatenate([o[1] for o in objs])
+
+
+class RcclValueIteration:
+    """Value iteration on this rank's slab with everything between the sweeps done by RCCL inside libpyrovi.
+
+    `comm_id`: the 128 bytes of `_native.comm_unique_id()` created on ONE rank and distributed by the caller (the bench
+    uses torch.distributed's store for that; MPI or a file do as well).  world == 1 needs none."""
+
+    def __init__(self, grid_sys, cost_function, rank, world, comm_id=None, dtype="float32", device=0, halo=None,
+                 overlap=True, transport=None):
+        self.rank, self.world = int(rank), int(world)
+        self.grid_sys = grid_sys
+        self.halo = halo_rows(grid_sys) if halo is None else int(halo)
+        cost = cost_function.device_cost() if hasattr(cost_function, "device_cost") else cost_function
+        self.shard = grid_sys._shard_problem(self.rank, self.world, self.halo, comm_id=comm_id, overlap=overlap, cost=cost,
+                                             dtype=dtype, device=device, transport=transport)
+        self.rows = self.shard.rows
+        self.shard.terminal_cost()
+
+    def run(self, max_sweeps, alpha=1.0, tol=-1.0):
+        """compute_steps (tol < 0) / solve_bellman_equation (tol >= 0): -> ((max J, max d, min d, delta), sweeps done)."""
+        return self.shard.sweep(max_sweeps, alpha, tol)
+
+    def owned(self):
+        """(J, pi) of this rank's rows."""
+        return self.shard.get_J(), self.shard.get_pi()
+
+    def describe(self):
+        return self.shard.describe()
+
+    def close(self):
+        self.shard.close()

@@ -19,7 +19,14 @@ def run(args):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    # torch.distributed is the launcher-side harness only (rendezvous, the communicator id, barrier and max of the timed
+    # region): the data path -- halo exchange and statistics all-reduce -- is RCCL inside libpyrovi (pvi_shard_*).
+    # PVI_TORCH_COLLECTIVES=1 selects the older Python-driven schedule over torch.distributed's nccl backend.
+    via_torch = bool(int(os.environ.get("PVI_TORCH_COLLECTIVES", "0")))
+    if via_torch:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     name = args.workload or "c4"
     steps = args.steps if args.steps is not None else 20
     warmup = args.warmup if args.warmup is not None else 2
@@ -45,17 +52,28 @@ def run(args):
         p.close()
         del dp
 
-    vi = parallel.ShardedValueIteration(g, cfg["cf"], dist, dtype=cfg["dtype"], device=local)
+    if via_torch:
+        vi = parallel.ShardedValueIteration(g, cfg["cf"], dist, dtype=cfg["dtype"], device=local)
+        run = lambda n: vi.run(n, 1.0, -1.0)
+        halo, p2p, overlap, describe = vi.halo, vi.p2p, vi.overlap, vi.slab.describe
+    else:
+        from pyro_amd import _native
+        ids = [_native.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        vi = parallel.RcclValueIteration(g, cfg["cf"], rank, world, comm_id=ids[0], dtype=cfg["dtype"], device=local)
+        run = lambda n: list(vi.run(n, 1.0, -1.0)[0])
+        desc = vi.describe()
+        halo, p2p, overlap, describe = vi.halo, "send/recv" in desc, "+overlap" in desc, vi.describe
     if warmup:
-        vi.run(warmup, 1.0, -1.0)
+        run(warmup)
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
-    st = vi.run(steps, 1.0, -1.0)          # fixed sweep count: statistics of the last sweep only
-    torch.cuda.synchronize()
+    st = run(steps)                        # fixed sweep count: statistics of the last sweep only
+    torch.cuda.synchronize()               # (pvi_shard_sweep has synchronised its own streams already)
     dist.barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if via_torch else "cpu")
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     if rank == 0:
@@ -68,16 +86,17 @@ def run(args):
             "dtype": "f32" if w == 4 else "f64", "data": "synthetic",
             "config": {"workload": "%s: %s" % (cfg["name"], cfg["description"]), "nodes": N, "actions": A,
                        "cells_per_sweep": N * A, "dt": g.dt, "alpha": 1.0,
-                       "parallelism": "axis-0 slabs x%d, halo %d rows, %s%s" % (
-                           world, vi.halo, "p2p send/recv" if vi.p2p else "all-gather",
-                           ", exchange overlapped with the interior kernel" if vi.overlap else "")},
+                       "parallelism": "axis-0 slabs x%d, halo %d rows, %s%s, collectives: %s" % (
+                           world, halo, "p2p send/recv" if p2p else "slab broadcast",
+                           ", exchange overlapped with the interior kernel" if overlap else "",
+                           "torch.distributed (nccl)" if via_torch else "RCCL inside libpyrovi (pvi_shard_*)")},
             "sweeps_per_sec": steps / dt,
             "roofline": {"bound": "hbm", "achieved": alg * steps / dt / 1e9, "peak": 8000.0 * world, "unit": "GB/s",
                          "frac": alg * steps / dt / 1e9 / (8000.0 * world), "traffic": None,
                          "note": "whole-step rate incl. halo exchange; per-kernel figures are in the N=1 line"},
             "value_1gpu_same_workload": one_gpu,
             "strong_scaling_speedup": (N * A * steps / dt) / one_gpu if one_gpu else None,
-            "last_stats": list(st), "kernel_path": vi.slab.describe(),
+            "last_stats": [float(v) for v in st], "kernel_path": describe(),
         }
         print(json.dumps(out))
     dist.destroy_process_group()

@@ -113,6 +113,15 @@ class GridDynamicSystem:
     # ------------------------------------------------------------------ device handle for table builds
     def _device_problem(self, cost=None, dtype="float64", **kw):
         """libpyrovi problem for this grid; `cost` = dict from CostFunction.device_cost()."""
+        return _native.Problem(**self._problem_kwargs(cost, dtype, **kw))
+
+    def _shard_problem(self, rank, world, halo_rows, comm_id=None, overlap=True, cost=None, dtype="float32", transport=None,
+                       **kw):
+        """This rank's slab of the grid with the halo exchange inside the library (pvi_shard_*, RCCL)."""
+        return _native.ShardedProblem(rank, world, halo_rows, comm_id=comm_id, overlap=overlap, transport=transport,
+                                      **self._problem_kwargs(cost, dtype, **kw))
+
+    def _problem_kwargs(self, cost=None, dtype="float64", **kw):
         s = self.sys
         dd = device_dynamics_of(s)
         if dd is None:
@@ -138,8 +147,8 @@ class GridDynamicSystem:
             kw.setdefault("obstacles", s.device_obstacles())
         if dd is not None and hasattr(s, "device_act_aux"):
             kw.setdefault("act_aux", s.device_act_aux(self.input_from_action_id))
-        return _native.Problem(self.x_level, self.u_level, s.x_lb, s.x_ub, s.u_lb, s.u_ub, self.dt, dtype=dtype,
-                               dynamics_id=dyn_id, dyn_params=params, trig=trig, cost=cost, **kw)
+        return dict(x_levels=self.x_level, u_levels=self.u_level, x_lb=s.x_lb, x_ub=s.x_ub, u_lb=s.u_lb, u_ub=s.u_ub,
+                    dt=self.dt, dtype=dtype, dynamics_id=dyn_id, dyn_params=params, trig=trig, cost=cost, **kw)
 
     # ------------------------------------------------------------------ look-up tables (discretizer.py:314-376)
     def compute_xnext_table(self):

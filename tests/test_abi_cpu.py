@@ -400,3 +400,30 @@ def test_per_node_table_cache_follows_the_system_parameters():
     k2 = D._fingerprint(s, lv, 0.05)
     k3 = D._fingerprint(s, [np.linspace(0, 1, 6), lv[1]], 0.05)
     assert len({k0, k1, k2, k3}) == 4
+
+
+def test_rccl_entry_points_the_library_binds_exist():
+    """pyro_amd/csrc/shard.inc loads RCCL at run time (dlopen) and binds its collectives by name: every name it asks
+    for must be exported by the RCCL of this image (the link check of the multi-GPU path; no GPU needed)."""
+    import ctypes
+    src = open(os.path.join(ROOT, "pyro_amd", "csrc", "shard.inc")).read()
+    names = re.findall(r'RCCL_SYM\(\w+, "(nccl\w+)"\)', src)
+    assert {"ncclGetUniqueId", "ncclCommInitRank", "ncclSend", "ncclRecv", "ncclAllReduce", "ncclGroupStart",
+            "ncclGroupEnd", "ncclBroadcast", "ncclCommDestroy"} <= set(names)
+    lib = None
+    for cand in ("librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"):
+        try:
+            lib = ctypes.CDLL(cand)
+            break
+        except OSError:
+            continue
+    if lib is None:
+        pytest.skip("no RCCL in this image")
+    for n in names:
+        assert hasattr(lib, n), n
+    # the id the ABI passes around has RCCL's size
+    hdr = open("/opt/rocm/include/rccl/rccl.h").read() if os.path.exists("/opt/rocm/include/rccl/rccl.h") else ""
+    m = re.search(r"#define NCCL_UNIQUE_ID_BYTES (\d+)", hdr)
+    if m:
+        from pyro_amd import _native
+        assert int(m.group(1)) == _native.COMM_ID_BYTES == 128

@@ -1420,3 +1420,206 @@ def test_3d_systems_class_surface_runs_fused():
         gs2 = discretizer.GridDynamicSystem(n, (5, 5, 3), (2, 2), 0.1)
         d2 = dynamicprogramming.DynamicProgrammingWithLookUpTable(gs2, costfunction.QuadraticCostFunction.from_sys(n))
         assert d2.tier == "table"
+
+
+# --------------------------------------------------------------------------- multi-GPU path inside the C ABI (RCCL)
+_RCCL_RANK = r"""
+import contextlib, io, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from pyro_amd import _native, configs, parallel
+rank, world, case, idfile, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+with contextlib.redirect_stdout(io.StringIO()):
+    cfg = configs.build(case)
+if rank == 0:
+    with open(idfile + ".tmp", "wb") as f:
+        f.write(_native.comm_unique_id())
+    os.replace(idfile + ".tmp", idfile)
+else:
+    import time
+    while not os.path.exists(idfile):
+        time.sleep(0.05)
+comm_id = open(idfile, "rb").read()
+vi = parallel.RcclValueIteration(cfg["grid_sys"], cfg["cf"], rank, world, comm_id=comm_id, dtype=cfg["dtype"],
+                                 overlap=bool(int(sys.argv[6])))
+st5, n5 = vi.run(5, 1.0, -1.0)
+st, n = vi.run(400, 1.0, float(sys.argv[7]))
+J, pi = vi.owned()
+np.savez(out, J=J, pi=pi, st5=st5, st=st, n=n, rows=np.array(vi.rows), desc=vi.describe())
+vi.close()
+print("RCCL-RANK-OK", rank)
+"""
+
+
+def _run_rccl_ranks(tmp_path, case, world, overlap, tol):
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_rank.py"
+    script.write_text(_RCCL_RANK % dict(root=root))
+    idfile = str(tmp_path / "comm.id")
+    procs = [subprocess.Popen([_sys.executable, str(script), str(r), str(world), case, idfile,
+                               str(tmp_path / ("r%d.npz" % r)), str(int(overlap)), repr(tol)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o))
+    return outs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,overlap", [("cartpole:21,21,21,21:7:float32", True), ("pendulum:101,101:11:float64", False)])
+def test_rccl_shard_world1_equals_plain_handle(tmp_path, case, overlap):
+    """pvi_shard_* with a real RCCL communicator of one rank (ncclCommInitRank, the statistics path, the streams and
+    events of the boundary-first schedule): same J, pi, statistics and stop sweep as the plain whole-grid handle."""
+    from pyro_amd import configs
+    outs = _run_rccl_ranks(tmp_path, case, 1, overlap, 0.5)
+    assert outs[0][0] == 0 and "RCCL-RANK-OK 0" in outs[0][1], outs[0][1][-2000:]
+    r = np.load(tmp_path / "r0.npz")
+    assert "comm=rccl" in str(r["desc"]) and "rank=0/1" in str(r["desc"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg = configs.build(case)
+        h = cfg["grid_sys"]._device_problem(cost=cfg["cf"].device_cost(), dtype=cfg["dtype"])
+    h.terminal_cost()
+    st5, _ = h.sweep(5, 1.0, -1.0)
+    st, n = h.sweep(400, 1.0, 0.5)
+    assert np.allclose(r["st5"], st5[-1], rtol=1e-12) and int(r["n"]) == n and np.allclose(r["st"], st[-1], rtol=1e-12)
+    assert np.array_equal(r["J"], h.get_J()) and np.array_equal(r["pi"], h.get_pi())
+    h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,world,overlap", [("cartpole:21,21,21,21:7:float32", 2, True),
+                                                ("cartpole:21,21,21,21:7:float32", 3, True),
+                                                ("pendulum:101,101:11:float32", 2, False)])
+def test_rccl_shard_ranks_sharing_one_gpu(tmp_path, case, world, overlap):
+    """2-3 ranks of the in-library RCCL path on the ONE GPU of the test box (RCCL refuses that on some builds: then
+    the test reports a skip with RCCL's message -- the world-1 test above and the gloo tests of the same partition
+    logic still cover the pieces).  Where it runs: the concatenated slabs equal the whole-grid handle bit for bit."""
+    from pyro_amd import configs
+    outs = _run_rccl_ranks(tmp_path, case, world, overlap, -1.0)
+    if any(rc != 0 for rc, _ in outs):
+        text = "\n".join(o[-600:] for _, o in outs)
+        if "Duplicate GPU" in text or "invalid usage" in text.lower() or "ncclCommInitRank" in text:
+            pytest.skip("RCCL does not accept several ranks on one GPU here: " + text[-300:])
+        raise AssertionError(text)
+    parts = [np.load(tmp_path / ("r%d.npz" % r)) for r in range(world)]
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg = configs.build(case)
+        h = cfg["grid_sys"]._device_problem(cost=cfg["cf"].device_cost(), dtype=cfg["dtype"])
+    h.terminal_cost()
+    h.sweep(5, 1.0, -1.0)
+    st, n = h.sweep(400, 1.0, -1.0)
+    assert np.array_equal(np.concatenate([p["J"] for p in parts]), h.get_J())
+    assert np.array_equal(np.concatenate([p["pi"] for p in parts]), h.get_pi())
+    for p in parts:
+        assert np.allclose(p["st"], st[-1], rtol=1e-12)
+    h.close()
+
+
+_TRANSPORT_RANK = r"""
+import contextlib, ctypes as C, io, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from pyro_amd import configs, parallel
+rank, world, case, port, out, overlap = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world)
+hip = C.CDLL("libamdhip64.so")
+hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+D2H, H2D = 2, 1
+
+
+def sendrecv(send_lo, recv_lo, lo_s, lo_r, send_hi, recv_hi, hi_s, hi_r, stream):
+    # host-staged halo exchange over gloo: what an MPI transport without GPU-aware buffers would do
+    assert hip.hipStreamSynchronize(stream) == 0
+    ops, landing = [], []
+    for sp, nb, peer in ((send_lo, lo_s, rank - 1), (send_hi, hi_s, rank + 1)):
+        if sp:
+            buf = torch.empty(nb, dtype=torch.uint8)
+            assert hip.hipMemcpy(buf.data_ptr(), sp, nb, D2H) == 0
+            ops.append(dist.P2POp(dist.isend, buf, peer))
+    for rp, nb, peer in ((recv_lo, lo_r, rank - 1), (recv_hi, hi_r, rank + 1)):
+        if rp:
+            buf = torch.empty(nb, dtype=torch.uint8)
+            ops.append(dist.P2POp(dist.irecv, buf, peer))
+            landing.append((rp, buf, nb))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    for rp, buf, nb in landing:
+        assert hip.hipMemcpy(rp, buf.data_ptr(), nb, H2D) == 0
+    return 0
+
+
+def max3(v):
+    t = torch.tensor([v[0], v[1], v[2]], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    for i in range(3):
+        v[i] = float(t[i])
+    return 0
+
+
+with contextlib.redirect_stdout(io.StringIO()):
+    cfg = configs.build(case)
+vi = parallel.RcclValueIteration(cfg["grid_sys"], cfg["cf"], rank, world, dtype=cfg["dtype"], overlap=bool(overlap),
+                                 transport=(sendrecv, max3))
+st5, n5 = vi.run(5, 1.0, -1.0)
+st, n = vi.run(400, 1.0, float(sys.argv[7]))
+J, pi = vi.owned()
+np.savez(out, J=J, pi=pi, st5=st5, st=st, n=n, rows=np.array(vi.rows), desc=vi.describe())
+vi.close()
+dist.destroy_process_group()
+print("TRANSPORT-RANK-OK", rank)
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,world,overlap,tol", [("cartpole:21,21,21,21:7:float32", 2, True, -1.0),
+                                                    ("cartpole:21,21,21,21:7:float32", 3, True, 0.5),
+                                                    ("pendulum:101,101:11:float64", 2, False, 0.5),
+                                                    ("pendulum:101,101:11:float32", 4, True, -1.0)])
+def test_c_shard_schedule_with_caller_transport_on_one_gpu(tmp_path, case, world, overlap, tol):
+    """The slab schedule of pvi_shard_sweep itself -- partition, boundary / interior handles over shared buffers, the
+    two streams and events, which rows go to which neighbour, the stop test on all-reduced statistics -- with 2-4 ranks
+    sharing the one GPU of the test box.  RCCL refuses several ranks per GPU, so the two inter-rank steps go through
+    pvi_shard_create_with_transport (host-staged over gloo); everything else is the code the RCCL path runs.  The
+    concatenated slabs must equal the whole-grid handle bit for bit, and every rank must stop at the same sweep."""
+    import subprocess
+    import sys as _sys
+    from pyro_amd import configs
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "transport_rank.py"
+    script.write_text(_TRANSPORT_RANK % dict(root=root))
+    port = str(29600 + (os.getpid() + world * 7 + int(overlap)) % 300)
+    procs = [subprocess.Popen([_sys.executable, str(script), str(r), str(world), case, port, str(tmp_path / ("t%d.npz" % r)),
+                               str(int(overlap)), repr(tol)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    for r, p in enumerate(procs):
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0 and ("TRANSPORT-RANK-OK %d" % r) in o, o[-3000:]
+    parts = [np.load(tmp_path / ("t%d.npz" % r)) for r in range(world)]
+    assert "comm=caller" in str(parts[0]["desc"]) and ("+overlap" in str(parts[0]["desc"])) == bool(overlap)
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg = configs.build(case)
+        h = cfg["grid_sys"]._device_problem(cost=cfg["cf"].device_cost(), dtype=cfg["dtype"])
+    h.terminal_cost()
+    st5, _ = h.sweep(5, 1.0, -1.0)
+    st, n = h.sweep(400, 1.0, tol)
+    assert np.array_equal(np.concatenate([p["J"] for p in parts]), h.get_J())
+    assert np.array_equal(np.concatenate([p["pi"] for p in parts]), h.get_pi())
+    for p in parts:
+        assert int(p["n"]) == n and np.allclose(p["st"], st[-1], rtol=1e-12) and np.allclose(p["st5"], st5[-1], rtol=1e-12)
+    h.close()
