@@ -854,12 +854,18 @@ __device__ __forceinline__ int interval_frac64(const double2* __restrict__ tab, 
     return i;
 }
 
-template <int DYN, typename PI_T, bool OFF32>
+//   * 4-D, PATCH: a wave owns an 8 x 8 patch of the (i2, i3) velocity plane of one position node instead of 64
+//     consecutive nodes along i3.  The expensive part of a cell -- two interval searches, 8 gathers, the 16-corner sum --
+//     is only needed where x_next lands inside the box, but a wave pays for it as soon as ONE of its lanes does; for an
+//     action the in-box nodes form a rectangle of the velocity plane, which a compact patch meets far less often than
+//     a 64-node line does (two-link 101^4 x 121: 7 % of the cells are in the box, ~40 % of the (line, action) pairs hit it).
+template <int DYN, typename PI_T, bool OFF32, bool PATCH>
 __global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restrict__ Jin, double* __restrict__ Jout,
                                                  PI_T* __restrict__ pi, double alpha, SweepCtl sc,
                                                  const Act64* __restrict__ act64, const double2* __restrict__ levr) {
     using D = Dyn<DYN>;
     constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M;
+    static_assert(!PATCH || DOF == 2, "patches tile the velocity plane of 4-D grids");
     typedef typename JOff<OFF32>::T off_t;
     typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
     if (sc.ctrl->done) return;
@@ -875,12 +881,27 @@ __global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restric
         }
         __syncthreads();
     }
-    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
-    double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
-    if (o < owned) {
-        int idx[N];
+    bool live = o < owned;
+    int idx[N];
+    if constexpr (PATCH) {
+        const int np2 = (P.dim[2] + 7) >> 3, np3 = (P.dim[3] + 7) >> 3;
+        const long long wid = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave-uniform
+        const long long pl = wid / (np2 * np3);  // position node (owned rows x dim[1])
+        const int rem = (int)(wid - pl * (np2 * np3)), p2 = rem / np3, p3 = rem - p2 * np3, lane = threadIdx.x & 63;
+        const long long row = pl / P.dim[1];
+        idx[0] = P.row_begin + (int)row;
+        idx[1] = (int)(pl - row * P.dim[1]);
+        idx[2] = p2 * 8 + (lane >> 3);
+        idx[3] = p3 * 8 + (lane & 7);
+        live = row < (P.row_end - P.row_begin) && idx[2] < P.dim[2] && idx[3] < P.dim[3];
+        o = pl * ((long long)P.dim[2] * P.dim[3]) + (long long)idx[2] * P.dim[3] + idx[3];
+    } else if (live) {
         decode_node<N>(P, o, idx);
+    }
+    double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
+    if (live) {
         double x[N], dx[N];
         long long self = (long long)(idx[0] - P.store_begin) * P.strd[0];
 #pragma unroll
@@ -2307,6 +2328,7 @@ struct pvi_problem {
     const Act64* act64 = nullptr;   // float64 second form (k_sweep64): per-action records, {level, reciprocal} tables
     const double2* levr = nullptr;
     bool use64 = false;
+    int patch64 = -1;         // 4-D wave mapping of k_sweep64: 1 = 8 x 8 velocity patches, 0 = consecutive nodes (timed at set-up)
     size_t levr_bytes = 0;
     SplineP SP;               // bicubic-spline interpolation mode (sweep_spline.inc)
     bool spline = false;
@@ -3019,6 +3041,49 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
     HCHK(hipStreamSynchronize(h->stream));
 #undef HCHK
     if ((rc = lean_setup(h))) return bail(rc);
+    if (h->use64 && d->n == 4) {
+        // Wave mapping of the float64 sweep on 4-D grids, timed like the float32 tile shapes: patches win where few
+        // cells land in the box (two-link 101^4 x 121: 33.0 -> 22.5 ms), lines where most do and the velocity plane does
+        // not divide by 8 (cart-pole 51^4: 0.77 against 0.88 ms).  One warm-up and one timed sweep per mapping; the
+        // results do not depend on it.  PVI_PATCH=0 / 1 pins it.
+        if (const char* e = getenv("PVI_PATCH")) {
+            h->patch64 = atoi(e) ? 1 : 0;
+        } else {
+            float best_ms = 1e30f;
+            int best = 1;
+            for (int pm = 0; pm < 2; ++pm) {
+                h->patch64 = pm;
+                float ms = 0.f;
+                rc = [&]() -> int {
+                    for (int rep = 0; rep < 2; ++rep) {
+                        if (rep == 1) HIPCHK(hipEventRecord(h->ev0, h->stream));
+                        hipLaunchKernelGGL(k_reset_stats, 1, STAT_WORDS, 0, h->stream, h->slots, STAT_WORDS);
+                        hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, h->stream, h->ctrl);
+                        int r = launch_sweep(h, h->cur, 1.0, h->stream, 0, -1.0);
+                        if (r) return r;
+                    }
+                    HIPCHK(hipEventRecord(h->ev1, h->stream));
+                    HIPCHK(hipStreamSynchronize(h->stream));
+                    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+                    return PVI_OK;
+                }();
+                if (rc) return bail(rc);
+                if (ms < best_ms) {
+                    best_ms = ms;
+                    best = pm;
+                }
+            }
+            h->patch64 = best;
+            rc = [&]() -> int {  // the timed sweeps wrote into the second J buffer, pi and the control block
+                HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream));
+                HIPCHK(hipMemsetAsync(h->pi, 0, (size_t)h->owned * h->pi_size, h->stream));
+                HIPCHK(hipMemsetAsync(h->J[h->cur ^ 1], 0, (size_t)h->stored * 8, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                return PVI_OK;
+            }();
+            if (rc) return bail(rc);
+        }
+    }
     *out = h;
     return PVI_OK;
 }
@@ -3044,6 +3109,11 @@ extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
                        : h->tile_ok ? "tile"
                        : (h->fast_ok && !is_node_dyn(h->d.dynamics_id)) ? "fast"
                        : (h->d.dynamics_id == PVI_DYN_TABLE ? (h->packed ? "table-packed" : "table") : "exact-f32");
+    if (h->d.dtype == PVI_F64 && h->use64 && h->d.dynamics_id != PVI_DYN_TABLE) {
+        snprintf(buf, (size_t)n, "path=exact-f64v2 mapping=%s off32=%d note=", h->P.n == 4 ? (h->patch64 ? "patch8x8" : "line64") : "line64",
+                 (int)((unsigned long long)h->stored * 8ull < (1ull << 32)));
+        return PVI_OK;
+    }
     snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d wgs=%u wpc=%d nbuf=%d reach=%d opmag=%d note=%s",
              path, h->LP.TV0, h->LP.TV1, h->lean_grid.x, h->lean_grid.y, h->lean_grid.z, h->lean_block, h->lean_pw1,
              h->lean_lds, h->lean_ok ? h->LP.lsplit : h->F.lsplit, h->LP.tb_tile, h->lean_ok ? h->LP.dma16 : 0,
@@ -3355,13 +3425,32 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     if constexpr (sizeof(REAL) == 8) {
         if (h->use64) {
             const bool off32 = (unsigned long long)h->stored * 8ull < (1ull << 32);
-#define S64(DYN)                                                                                                      \
+            // 4-D: 8 x 8 velocity patches per wave (PVI_PATCH=0: consecutive nodes)
+            const bool patch = h->P.n == 4 && h->patch64 != 0;
+            unsigned gp = g;
+            if (patch) {
+                const long long waves = (long long)(h->P.row_end - h->P.row_begin) * h->P.dim[1] *
+                                        ((h->P.dim[2] + 7) / 8) * ((h->P.dim[3] + 7) / 8);
+                gp = (unsigned)((waves + 3) / 4);
+                sc.nblocks = gp;
+            }
+#define S64P(DYN, PT)                                                                                                 \
     if (off32)                                                                                                        \
-        hipLaunchKernelGGL((k_sweep64<DYN, PI_T, true>), g, 256, h->levr_bytes, st, h->P, Jin, Jout, pi, alpha, sc,   \
-                           h->act64, h->levr);                                                                        \
+        hipLaunchKernelGGL((k_sweep64<DYN, PI_T, true, PT>), gp, 256, h->levr_bytes, st, h->P, Jin, Jout, pi, alpha,  \
+                           sc, h->act64, h->levr);                                                                    \
     else                                                                                                              \
-        hipLaunchKernelGGL((k_sweep64<DYN, PI_T, false>), g, 256, h->levr_bytes, st, h->P, Jin, Jout, pi, alpha, sc,  \
-                           h->act64, h->levr);
+        hipLaunchKernelGGL((k_sweep64<DYN, PI_T, false, PT>), gp, 256, h->levr_bytes, st, h->P, Jin, Jout, pi, alpha, \
+                           sc, h->act64, h->levr);
+#define S64(DYN)                                   \
+    if constexpr (Dyn<DYN>::DOF == 2) {            \
+        if (patch) {                               \
+            S64P(DYN, true)                        \
+        } else {                                   \
+            S64P(DYN, false)                       \
+        }                                          \
+    } else {                                       \
+        S64P(DYN, false)                           \
+    }
             switch (h->d.dynamics_id) {
                 case PVI_DYN_PENDULUM: S64(PVI_DYN_PENDULUM) break;
                 case PVI_DYN_CARTPOLE: S64(PVI_DYN_CARTPOLE) break;
@@ -3371,6 +3460,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
                 default: S64(PVI_DYN_NODE_2x2) break;
             }
 #undef S64
+#undef S64P
             HIPCHK(hipGetLastError());
             return PVI_OK;
         }

@@ -428,12 +428,15 @@ def test_f64_second_form_is_bit_identical(name, monkeypatch):
         alpha = float(g["alpha"]) if "alpha" in g.files else 1.0
         nsw = 6
     outs = {}
-    for tag, env in (("v1", {"PVI_NO_SWEEP64": "1"}), ("v2", {})):
+    for tag, env in (("v1", {"PVI_NO_SWEEP64": "1"}), ("v2", {"PVI_PATCH": "1"}), ("v2line", {"PVI_PATCH": "0"}), ("v2auto", {})):
         monkeypatch.delenv("PVI_NO_SWEEP64", raising=False)
+        monkeypatch.delenv("PVI_PATCH", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         h = native_problem(p)
         assert h.describe().split()[0] == ("path=exact-f64" if tag == "v1" else "path=exact-f64v2")
+        if p.n == 4 and tag in ("v2", "v2line"):
+            assert ("mapping=patch8x8" if tag == "v2" else "mapping=line64") in h.describe()
         h.terminal_cost()
         stats, n = h.sweep(nsw, alpha, -1.0)
         outs[tag] = (h.get_J(), h.get_pi(), stats.copy())
@@ -448,9 +451,11 @@ def test_f64_second_form_is_bit_identical(name, monkeypatch):
         outs[tag + "_slab"] = (hs.get_J(), hs.get_pi())
         hs.close()
     monkeypatch.delenv("PVI_NO_SWEEP64", raising=False)
-    for a, b in (("v1", "v2"), ("v1_slab", "v2_slab")):
-        assert np.array_equal(outs[a][0], outs[b][0]) and np.array_equal(outs[a][1], outs[b][1]), (name, a)
-    assert np.array_equal(outs["v1"][2], outs["v2"][2])
+    monkeypatch.delenv("PVI_PATCH", raising=False)
+    for b in ("v2", "v2line", "v2auto"):
+        for a, c in (("v1", b), ("v1_slab", b + "_slab")):
+            assert np.array_equal(outs[a][0], outs[c][0]) and np.array_equal(outs[a][1], outs[c][1]), (name, c)
+        assert np.array_equal(outs["v1"][2], outs[b][2])
 
 
 # ------------------------------------------------------------------------------------- full size (BASELINE configs[1])
@@ -594,6 +599,8 @@ def test_full_size_sampled_against_c_oracle(name):
     desc = h.describe()
     fields = dict(kv.split("=", 1) for kv in desc.split(" note=")[0].split())
     assert fields["path"] == path, desc
+    if name == "c5":        # 93 % of the two-link cells leave the box: set-up timing must pick the patch mapping
+        assert fields["mapping"] == "patch8x8" and fields["off32"] == "1", desc
     if path == "lean":
         tv0, tv1 = (int(v) for v in fields["tile"].split("x"))
         assert int(fields["dma16"]) == dma16 and int(fields["lsplit"]) == 0 and int(fields["tb_tile"]) == 1, desc
