@@ -835,17 +835,14 @@ __device__ __forceinline__ int interval_frac64(const double2* __restrict__ tab, 
                                                double& y) {
     const double t0 = floor((x - lo) * inv_step);
     int i = (t0 < 0.0) ? 0 : (t0 > (double)(N - 2) ? N - 2 : (int)t0);
-    double2 e0;
-    double l1;
-    for (;;) {
+    // the estimate is the interval itself except when rounding put x across a level: straight-line reads first (so that
+    // the reads of several cells can be in flight together), the search loop only for lanes that still have to move
+    double2 e0 = tab[i];
+    double l1 = tab[i + 1].x;
+    while ((i > 0 && x < e0.x) || (i < N - 2 && x >= l1)) {
+        i += (i > 0 && x < e0.x) ? -1 : 1;
         e0 = tab[i];
         l1 = tab[i + 1].x;
-        if (i > 0 && x < e0.x)
-            --i;
-        else if (i < N - 2 && x >= l1)
-            ++i;
-        else
-            break;
     }
     const double t = x - e0.x, d = l1 - e0.x, r = e0.y;
     const double q = t * r;
@@ -952,7 +949,47 @@ __global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restric
             D::trig_from_tables(P, idx, tr);
             D dyn;
             dyn.init(P.c, x, tr);
-            for (int a = 0; a < P.A; ++a) {
+            int a_first = 0;
+            if constexpr (DOF == 1) {
+                // 2-D: two actions per trip, staged (both x_next, both intervals, all four gathers, then the two sums), so
+                // that the LDS and memory latencies of the second cell overlap those of the first
+                const off_t s0 = (off_t)P.strd[0];
+                const double a0 = 1.0 - y[0];
+                for (; a_first + 1 < P.A; a_first += 2) {
+                    const Act64 ac0 = act64[a_first], ac1 = act64[a_first + 1];
+                    double u0[2] = {ac0.u0, ac0.u1}, u1[2] = {ac1.u0, ac1.u1}, acc0[1], acc1[1];
+                    dyn.accel(u0, acc0);
+                    dyn.accel(u1, acc1);
+                    const double xa = acc0[0] * P.dt + x[1], xb = acc1[0] * P.dt + x[1];
+                    const bool ina = !(xa < P.glo[1]) && !(xa > P.ghi[1]), inb_ = !(xb < P.glo[1]) && !(xb > P.ghi[1]);
+                    double Ja = 0.0, Jb = 0.0;
+                    if (ina || inb_) {
+                        double ya, yb;  // (a lane with only one of the two cells in the box evaluates the other at the box edge)
+                        const int ca = interval_frac64(tab[1], P.dim[1], P.glo[1], P.inv_step[1], ina ? xa : P.glo[1], ya);
+                        const int cb = interval_frac64(tab[1], P.dim[1], P.glo[1], P.inv_step[1], inb_ ? xb : P.glo[1], yb);
+                        const off_t ba = base + (off_t)ca, bb = base + (off_t)cb;
+                        const d2u qa0 = *(const d2u*)j_at<OFF32>(Jin, ba), qa1 = *(const d2u*)j_at<OFF32>(Jin, ba + s0);
+                        const d2u qb0 = *(const d2u*)j_at<OFF32>(Jin, bb), qb1 = *(const d2u*)j_at<OFF32>(Jin, bb + s0);
+                        const double a1 = 1.0 - ya, b1 = 1.0 - yb;
+                        Ja = qa0.x * a0 * a1 + qa0.y * a0 * ya + qa1.x * y[0] * a1 + qa1.y * y[0] * ya;
+                        Jb = qb0.x * a0 * b1 + qb0.y * a0 * yb + qb1.x * y[0] * b1 + qb1.y * y[0] * yb;
+                        Ja = ina ? Ja : 0.0;
+                        Jb = inb_ ? Jb : 0.0;
+                    }
+                    const double ga = on_target ? 0.0 : (gx + ac0.gu), gb = on_target ? 0.0 : (gx + ac1.gu);
+                    const double Ga = (ina && ac0.aok != 0.0) ? ga * P.dt : P.INF, Gb = (inb_ && ac1.aok != 0.0) ? gb * P.dt : P.INF;
+                    const double qa = Ga + alpha * Ja, qb = Gb + alpha * Jb;
+                    if (a_first == 0 || qa < best) {
+                        best = qa;
+                        arg = a_first;
+                    }
+                    if (qb < best) {
+                        best = qb;
+                        arg = a_first + 1;
+                    }
+                }
+            }
+            for (int a = a_first; a < P.A; ++a) {
                 const Act64 ac = act64[a];  // wave-uniform: one scalar load
                 double u[2] = {ac.u0, ac.u1}, acc[DOF], xnv[DOF];
                 dyn.accel(u, acc);
