@@ -80,11 +80,21 @@ extern "C" {
                                 over the levels of axis 2 (the system's own ground profile);
                                 dyn_params = [1/mass, k, b, vx] */
 
+#define PVI_DYN_HOLONOMIC 10 /* vehicle_steering.py:201 HolonomicMobileRobot (+ :336 withObstacles), x = [x, y], u = [vx, vy]:
+                                f = [u0, u1]; obstacles: obs_half = 0 (a point robot) */
+#define PVI_DYN_LONGCAR 11   /* pyro/dynamic/vehicle_propulsion.py:23 LongitudinalFrontWheelDriveCarWithWheelSlipInput,
+                                x = [x, v], u = [slip]: f = [v, (mu m g rr - fd) / (m (1 + mu ry))]; its isavalidinput also
+                                rejects negative wheel loads (evaluated per cell in-kernel).  trig[0] = drag force fd over
+                                the levels of axis 1; act_aux = [A][2] = {mu m g rr, m (1 + mu ry)} (host NumPy);
+                                dyn_params = [m, ry, m g rr, m g rf] */
+
 /* cost evaluated in-kernel */
 #define PVI_COST_TABLE 0      /* G supplied by the host */
 #define PVI_COST_QUADRATIC 1  /* pyro/analysis/costfunction.py:101 QuadraticCostFunction */
 #define PVI_COST_TIME 2       /* costfunction.py:287 TimeCostFunction: g = 1 (0 inside the target ball), h = 0;
                                  uses xbar, EPS, INF, ontarget_check; Q, R, S, ubar are ignored */
+#define PVI_COST_REACHABILITY 4 /* costfunction.py:421 Reachability with the default target test: g = 0 on states the system's
+                                  isavalidstate accepts else INF, h = 0 inside ||x - xbar|| < EPS else INF; uses xbar, EPS, INF */
 #define PVI_COST_QUADRATIC_DOMAIN 3 /* costfunction.py:339 QuadraticCostFunctionWithDomainCheck: the quadratic g / h, INF on
                                  states the system's isavalidstate rejects (box + obstacles), 0 on target (applied last) */
 
@@ -137,12 +147,12 @@ typedef struct pvi_desc {
     /* isavalidstate beyond the box (drone.py:590-611, vehicle_steering.py:1004-1021): x is invalid when, for some box b,
          x[obs_axis[0]] + obs_half[0] > obs_box[b][0]  and  x[obs_axis[1]] + obs_half[1] > obs_box[b][1]  and
          x[obs_axis[0]] - obs_half[0] < obs_box[b][2]  and  x[obs_axis[1]] - obs_half[1] < obs_box[b][3].
-       Only read for the PVI_DYN_HELICOPTER / KINCAR / QUARTERCAR dynamics. */
+       Only read for the explicit dynamics PVI_DYN_HELICOPTER .. PVI_DYN_LONGCAR. */
     int32_t n_obs;
     int32_t obs_axis[2];
     double obs_half[2];
     double obs_box[PVI_MAX_OBS][4];
-    const double* act_aux;           /* per-action constants of the dynamics ([A] doubles, see PVI_DYN_KINCAR) or NULL */
+    const double* act_aux;           /* per-action constants of the dynamics (PVI_DYN_KINCAR: [A], PVI_DYN_LONGCAR: [A][2]) or NULL */
 } pvi_desc;
 
 /* ---- library ------------------------------------------------------------------------------ */

@@ -15,8 +15,9 @@ PVI_F32, PVI_F64 = 0, 1
 DYN_TABLE, DYN_PENDULUM, DYN_CARTPOLE, DYN_TWOLINK = 0, 1, 2, 3
 DYN_NODE_1x1, DYN_NODE_2x1, DYN_NODE_2x2 = 4, 5, 6        # any MechanicalSystem through per-node tables
 DYN_HELICOPTER, DYN_KINCAR, DYN_QUARTERCAR = 7, 8, 9      # the reference's three-dimensional demo systems (n = 3)
+DYN_HOLONOMIC, DYN_LONGCAR = 10, 11                       # point robot with obstacles, longitudinal car (n = 2)
 CLOSED_FORM_IDS = (DYN_PENDULUM, DYN_CARTPOLE, DYN_TWOLINK)    # dynamics pvi_eval_f / pvi_rollout can evaluate anywhere
-COST_TABLE, COST_QUADRATIC, COST_TIME, COST_QUADRATIC_DOMAIN = 0, 1, 2, 3
+COST_TABLE, COST_QUADRATIC, COST_TIME, COST_QUADRATIC_DOMAIN, COST_REACHABILITY = 0, 1, 2, 3, 4
 INTERP_LINEAR, INTERP_BICUBIC_SPLINE = 0, 1
 PVI_EHALO = -5
 FLAG_EXT_J_SLACK = 1
@@ -189,8 +190,8 @@ class Problem:
             if t is not None:
                 a = _f64(t); self._keep.append(a)
                 d.trig[i] = _ptr(a)
-        if cost is not None and cost.get("kind") == "time":
-            d.cost_id = COST_TIME
+        if cost is not None and cost.get("kind") in ("time", "reachability"):
+            d.cost_id = COST_TIME if cost["kind"] == "time" else COST_REACHABILITY
             d.xbar[:d.n] = [float(v) for v in cost["xbar"]]
             d.EPS, d.INF = float(cost["EPS"]), float(cost["INF"])
             d.ontarget_check = int(bool(cost.get("ontarget_check", True)))

@@ -153,6 +153,16 @@ class Reachability(CostFunction):
     def norm_test(self, x, t=0):
         return np.linalg.norm(np.asarray(x, dtype=float) - self.xbar) < self.EPS
 
+    def device_cost(self):
+        """In-kernel (PVI_COST_REACHABILITY) with the default target test and a system's own bound isavalidstate
+        (DynamicProgramming._make_engine checks that it is the system of the grid)."""
+        if type(self) is not Reachability or getattr(self.isontarget, "__func__", None) is not Reachability.norm_test:
+            return None
+        if getattr(self.isavalidestate, "__self__", None) is None or self.xbar is None:
+            return None
+        return dict(kind="reachability", xbar=np.array(self.xbar, dtype=float), EPS=float(self.EPS), INF=float(self.INF),
+                    ontarget_check=False, validity_of=self.isavalidestate.__self__)
+
     def h(self, x, t=0):
         return 0 if self.isontarget(x, t) else self.INF
 

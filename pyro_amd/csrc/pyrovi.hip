@@ -55,7 +55,7 @@ struct DevP {
     int ontarget;
     // isavalidstate beyond the box: axis-aligned obstacles (include/pyrovi.h pvi_desc.obs_*), and the cost functions
     // that test the NODE state against it (QuadraticCostFunctionWithDomainCheck)
-    int nobs, obs_ax[2], domain_check, hard_inf;
+    int nobs, obs_ax[2], domain_check, hard_inf, reach;
     double obs_half[2];
     double obs[PVI_MAX_OBS][4];
     const double* aux;          // [A] per-action constants of the dynamics (PVI_DYN_KINCAR)
@@ -655,6 +655,7 @@ __global__ void k_terminal_cost(DevP P, REAL* __restrict__ J) {
     double h = quad_form<N>(P.S, dx);
     if (P.domain_check && !state_valid<N>(P, x)) h = P.INF;  // costfunction.py:385-387
     if (P.ontarget && l2norm<N>(dx) < P.EPS) h = 0.0;
+    if (P.reach) h = (l2norm<N>(dx) < P.EPS) ? 0.0 : P.INF;   // Reachability.h (costfunction.py:454-466): target set or INF
     J[s] = (REAL)h;
 }
 
@@ -1061,7 +1062,8 @@ struct Dyn3;
 // ConstantSpeedHelicopterTunnel (drone.py:613-636): dx = [1/mass * u, x0, vx].  c = [1/mass, vx]
 template <>
 struct Dyn3<PVI_DYN_HELICOPTER> {
-    static constexpr int M = 1, UDEP = 1;
+    static constexpr int N = 3, M = 1, UDEP = 1;
+    __device__ bool action_ok(const DevP&, const double*, int) const { return true; }
     __device__ void init(const DevP&, const int*, const double*) {}
     __device__ void f(const DevP& P, const double* x, const double* u, int, double* dx) const {
         dx[0] = P.c[0] * u[0];
@@ -1073,8 +1075,9 @@ struct Dyn3<PVI_DYN_HELICOPTER> {
 // KinematicBicyleModel (vehicle_steering.py:64-86): dx = [u0 cos x2, u0 sin x2, u0 tan(u1) (1/length)]
 template <>
 struct Dyn3<PVI_DYN_KINCAR> {
-    static constexpr int M = 2, UDEP = 7;
+    static constexpr int N = 3, M = 2, UDEP = 7;
     double c2, s2;
+    __device__ bool action_ok(const DevP&, const double*, int) const { return true; }
     __device__ void init(const DevP& P, const int* idx, const double*) {
         c2 = P.trig[0][idx[2]];
         s2 = P.trig[1][idx[2]];
@@ -1090,8 +1093,9 @@ struct Dyn3<PVI_DYN_KINCAR> {
 // c = [1/mass, k, b, vx]; z, dz = ground height / slope at the node's x2 (host tables)
 template <>
 struct Dyn3<PVI_DYN_QUARTERCAR> {
-    static constexpr int M = 1, UDEP = 1;
+    static constexpr int N = 3, M = 1, UDEP = 1;
     double ks, bs;  // k (x1 - z), b (x0 - dz)
+    __device__ bool action_ok(const DevP&, const double*, int) const { return true; }
     __device__ void init(const DevP& P, const int* idx, const double* x) {
         ks = P.c[1] * (x[1] - P.trig[0][idx[2]]);
         bs = P.c[2] * (x[0] - P.trig[1][idx[2]]);
@@ -1103,13 +1107,46 @@ struct Dyn3<PVI_DYN_QUARTERCAR> {
     }
 };
 
+// HolonomicMobileRobot (vehicle_steering.py:238-259; :336-382 adds obstacle boxes around the point robot): dx = [u0, u1]
+template <>
+struct Dyn3<PVI_DYN_HOLONOMIC> {
+    static constexpr int N = 2, M = 2, UDEP = 3;
+    __device__ bool action_ok(const DevP&, const double*, int) const { return true; }
+    __device__ void init(const DevP&, const int*, const double*) {}
+    __device__ void f(const DevP&, const double*, const double* u, int, double* dx) const {
+        dx[0] = u[0];
+        dx[1] = u[1];
+    }
+};
+
+// LongitudinalFrontWheelDriveCarWithWheelSlipInput (vehicle_propulsion.py:130-223), x = [x, v], u = [slip]:
+//   mu = mu_max (2 / (1 + exp(-mu_slope slip)) - 1);  fd = 0.5 rho cdA v |v|;  a = (mu m g rr - fd) / (m (1 + mu ry))
+//   dx = [v, a];  isavalidinput also rejects negative normal forces:  m g rr - m a ry < 0  or  m g rf + m a ry < 0.
+// Per action (host NumPy, the reference's own expressions): aux[2a] = mu m g rr, aux[2a+1] = m (1 + mu ry); per level of
+// axis 1: trig[0] = fd.  c = [m, ry, m g rr, m g rf]
+template <>
+struct Dyn3<PVI_DYN_LONGCAR> {
+    static constexpr int N = 2, M = 1, UDEP = 2;
+    double fd;
+    __device__ void init(const DevP& P, const int* idx, const double*) { fd = P.trig[0][idx[1]]; }
+    __device__ double acc(const DevP& P, int a) const { return (P.aux[2 * a] - fd) / P.aux[2 * a + 1]; }
+    __device__ bool action_ok(const DevP& P, const double*, int a) const {
+        const double ma_ry = (P.c[0] * acc(P, a)) * P.c[1];
+        return !((P.c[2] - ma_ry) < 0.0) && !((P.c[3] + ma_ry) < 0.0);
+    }
+    __device__ void f(const DevP& P, const double* x, const double*, int a, double* dx) const {
+        dx[0] = x[1];
+        dx[1] = acc(P, a);
+    }
+};
+
 template <int DYN, typename REAL, typename PI_T>
 __global__ __launch_bounds__(256) void k_sweep3(DevP P, const REAL* __restrict__ Jin, REAL* __restrict__ Jout,
                                                 PI_T* __restrict__ pi, double alpha, SweepCtl sc,
                                                 const double* __restrict__ utab, const double* __restrict__ gutab,
                                                 const int* __restrict__ aoktab) {
     using D = Dyn3<DYN>;
-    constexpr int N = 3, M = D::M;
+    constexpr int N = D::N, M = D::M;
     if (sc.ctrl->done) return;
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
@@ -1167,7 +1204,7 @@ __global__ __launch_bounds__(256) void k_sweep3(DevP P, const REAL* __restrict__
                     inb = inb && !(xn[d] < P.glo[d]) && !(xn[d] > P.ghi[d]);
                 }
             }
-            const bool ok = aoktab[a] != 0 && state_valid<N>(P, xn);
+            const bool ok = aoktab[a] != 0 && dyn.action_ok(P, x, a) && state_valid<N>(P, xn);
             REAL Jn = (REAL)0;
             if (inb) {
                 long long b = 0;
@@ -1220,7 +1257,7 @@ __global__ void k_build_tables3(DevP P, long long node0, long long nnodes, doubl
                                 unsigned char* __restrict__ xok, unsigned char* __restrict__ aok,
                                 double* __restrict__ G) {
     using D = Dyn3<DYN>;
-    constexpr int N = 3, M = D::M;
+    constexpr int N = D::N, M = D::M;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nnodes * P.A) return;
     const long long ln = t / P.A;
@@ -1243,17 +1280,18 @@ __global__ void k_build_tables3(DevP P, long long node0, long long nnodes, doubl
 #pragma unroll
     for (int d = 0; d < N; ++d) xn[d] = fa[d] * P.dt + x[d];
     const bool ok = state_valid<N>(P, xn);
+    const bool a_ok = P.aok[a] && dyn.action_ok(P, x, a);
     if (xnext) {
 #pragma unroll
         for (int d = 0; d < N; ++d) xnext[t * N + d] = xn[d];
     }
     if (xok) xok[t] = ok;
-    if (aok) aok[t] = P.aok[a];
+    if (aok) aok[t] = a_ok;
     if (G) {
         const bool on_target = P.ontarget && (l2norm<N>(dx) < P.EPS);
         const bool node_bad = P.domain_check && !state_valid<N>(P, x);
         const double g = on_target ? 0.0 : (node_bad ? P.INF : (quad_form<N>(P.Q, dx) + P.gu[a]));
-        G[t] = (ok && P.aok[a]) ? g * P.dt : P.INF;
+        G[t] = (ok && a_ok) ? g * P.dt : P.INF;
     }
 }
 
@@ -2753,9 +2791,9 @@ extern "C" int pvi_device_count(int* count) {
 }
 
 static inline bool is_node_dyn(int dyn) { return dyn >= PVI_DYN_NODE_1x1 && dyn <= PVI_DYN_NODE_2x2; }
-static inline bool is_dyn3(int dyn) { return dyn >= PVI_DYN_HELICOPTER && dyn <= PVI_DYN_QUARTERCAR; }
+static inline bool is_dyn3(int dyn) { return dyn >= PVI_DYN_HELICOPTER && dyn <= PVI_DYN_LONGCAR; }  // the explicit (non-mechanical) systems
 static inline bool is_cost_in_kernel(int c) {
-    return c == PVI_COST_QUADRATIC || c == PVI_COST_TIME || c == PVI_COST_QUADRATIC_DOMAIN;
+    return c == PVI_COST_QUADRATIC || c == PVI_COST_TIME || c == PVI_COST_QUADRATIC_DOMAIN || c == PVI_COST_REACHABILITY;
 }
 
 static int dyn_shape(int dyn, int* n, int* m) {
@@ -2769,6 +2807,8 @@ static int dyn_shape(int dyn, int* n, int* m) {
         case PVI_DYN_HELICOPTER: *n = 3; *m = 1; return 0;
         case PVI_DYN_KINCAR: *n = 3; *m = 2; return 0;
         case PVI_DYN_QUARTERCAR: *n = 3; *m = 1; return 0;
+        case PVI_DYN_HOLONOMIC: *n = 2; *m = 2; return 0;
+        case PVI_DYN_LONGCAR: *n = 2; *m = 1; return 0;
     }
     return -1;
 }
@@ -2806,6 +2846,8 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
                     return fail(PVI_EINVAL, "obs_axis[%d]=%d is not a state axis", k, d->obs_axis[k]);
             if (d->dynamics_id == PVI_DYN_QUARTERCAR && (!d->trig[0] || !d->trig[1]))
                 return fail(PVI_EINVAL, "PVI_DYN_QUARTERCAR needs the ground tables z, dz in trig[0], trig[1]");
+            if (d->dynamics_id == PVI_DYN_LONGCAR && (!d->trig[0] || !d->act_aux))
+                return fail(PVI_EINVAL, "PVI_DYN_LONGCAR needs the drag table in trig[0] and act_aux = [A][2]");
         }
     }
     long long plane = 1, A = 1;
@@ -2888,14 +2930,18 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
     // row-major n x n -> dense n x n at the front of the 16-slot arrays
     memcpy(P.Q, d->Q, sizeof(double) * d->n * d->n);
     memcpy(P.S, d->S, sizeof(double) * d->n * d->n);
-    if (d->cost_id == PVI_COST_TIME) {
+    if (d->cost_id == PVI_COST_TIME || d->cost_id == PVI_COST_REACHABILITY) {
         memset(P.Q, 0, sizeof(P.Q));
         memset(P.S, 0, sizeof(P.S));
     }
     P.EPS = d->EPS;
     P.INF = d->INF;
     P.ontarget = d->ontarget_check;
-    P.domain_check = d->cost_id == PVI_COST_QUADRATIC_DOMAIN;
+    P.domain_check = d->cost_id == PVI_COST_QUADRATIC_DOMAIN || d->cost_id == PVI_COST_REACHABILITY;
+    if (d->cost_id == PVI_COST_REACHABILITY) {  // g = 0 on valid states else INF (no on-target zeroing); h: see k_terminal_cost
+        P.ontarget = 0;
+        P.reach = 1;
+    }
     P.hard_inf = (d->flags & PVI_FLAG_HARD_INF) != 0;
     if (is_dyn3(d->dynamics_id)) {
         P.nobs = d->n_obs;
@@ -2923,7 +2969,7 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
         }
         // TimeCostFunction (costfunction.py:318-334): g = 1 outside the target ball -- the constant rides in the
         // per-action term, the state term and the terminal cost are zero (Q = S = 0 below)
-        gu[a] = d->cost_id == PVI_COST_TIME ? 1.0 : quad_form_host(d->R, du, d->m);
+        gu[a] = d->cost_id == PVI_COST_TIME ? 1.0 : (d->cost_id == PVI_COST_REACHABILITY ? 0.0 : quad_form_host(d->R, du, d->m));
         aok[a] = ok;
     }
     if ((rc = dev_upload(h, utab.data(), utab.size(), &P.utab))) return bail(rc);
@@ -3035,6 +3081,9 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
         if ((rc = dev_upload(h, aux.data(), aux.size(), &P.aux))) return bail(rc);
     } else if (d->dynamics_id == PVI_DYN_QUARTERCAR) {
         if ((rc = table(0, 2, fsin)) || (rc = table(1, 2, fcos))) return bail(rc);  // (both supplied: checked above)
+    } else if (d->dynamics_id == PVI_DYN_LONGCAR) {
+        if ((rc = table(0, 1, fsin))) return bail(rc);  // drag force over the velocity levels (supplied: checked above)
+        if ((rc = dev_upload(h, d->act_aux, (size_t)A * 2, &P.aux))) return bail(rc);
     } else if (is_node_dyn(d->dynamics_id)) {
         if (!d->trig[0] || !d->trig[1]) return bail(fail(PVI_EINVAL, "PVI_DYN_NODE_* needs the a0 / Bn tables in trig[0], trig[1]"));
         const int dof = d->n / 2;
@@ -3509,6 +3558,8 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         case PVI_DYN_HELICOPTER: SWEEP3(PVI_DYN_HELICOPTER); break;
         case PVI_DYN_KINCAR: SWEEP3(PVI_DYN_KINCAR); break;
         case PVI_DYN_QUARTERCAR: SWEEP3(PVI_DYN_QUARTERCAR); break;
+        case PVI_DYN_HOLONOMIC: SWEEP3(PVI_DYN_HOLONOMIC); break;
+        case PVI_DYN_LONGCAR: SWEEP3(PVI_DYN_LONGCAR); break;
         case PVI_DYN_PENDULUM: EXACT(PVI_DYN_PENDULUM) break;
         case PVI_DYN_CARTPOLE: EXACT(PVI_DYN_CARTPOLE) break;
         case PVI_DYN_TWOLINK: EXACT(PVI_DYN_TWOLINK) break;
@@ -3858,6 +3909,14 @@ extern "C" int pvi_build_tables(pvi_handle h, int32_t row0, int32_t nrows, doubl
                 break;
             case PVI_DYN_QUARTERCAR:
                 hipLaunchKernelGGL((k_build_tables3<PVI_DYN_QUARTERCAR>), g, 256, 0, h->stream, h->P, node0 + s, c, dx, dxo,
+                                   dao, dG);
+                break;
+            case PVI_DYN_HOLONOMIC:
+                hipLaunchKernelGGL((k_build_tables3<PVI_DYN_HOLONOMIC>), g, 256, 0, h->stream, h->P, node0 + s, c, dx, dxo,
+                                   dao, dG);
+                break;
+            case PVI_DYN_LONGCAR:
+                hipLaunchKernelGGL((k_build_tables3<PVI_DYN_LONGCAR>), g, 256, 0, h->stream, h->P, node0 + s, c, dx, dxo,
                                    dao, dG);
                 break;
             case PVI_DYN_PENDULUM:

@@ -7,6 +7,59 @@ from pyro_amd import _native
 from pyro_amd.dynamic import system
 
 
+class HolonomicMobileRobot(system.ContinuousDynamicSystem):
+    """Holonomic 2-D point robot: dx = u0, dy = u1 (vehicle_steering.py:201-259)."""
+
+    def __init__(self):
+        super().__init__(2, 2, 2)
+        self.name = "Holonomic Mobile Robot"
+        self.state_label, self.state_units = ["x", "y"], ["[m]", "[m]"]
+        self.input_label, self.input_units = ["vx", "vy"], ["[m/sec]", "[m/sec]"]
+        self.output_label, self.output_units = ["x", "y"], ["[m]", "[m]"]
+        self.x_ub = np.array([10, 10])
+        self.x_lb = np.array([-10, -10])
+
+    def f(self, x=np.zeros(3), u=np.zeros(2), t=0):
+        dx = np.zeros(self.n)
+        dx[0] = u[0]
+        dx[1] = u[1]
+        return dx
+
+    def device_dynamics(self):
+        if not self.stock_model(HolonomicMobileRobot, ("f",)):
+            return None
+        return _native.DYN_HOLONOMIC, []
+
+
+class HolonomicMobileRobotwithObstacles(HolonomicMobileRobot):
+    """The point robot with forbidden boxes (vehicle_steering.py:336-382; 2D_navigation.py)."""
+
+    def __init__(self):
+        super().__init__()
+        self.name = "Holonomic Mobile Robot with Obstacles"
+        self.x_ub = np.array([10, 10])
+        self.x_lb = np.array([-10, -10])
+        self.obstacles = [[(2, 2), (4, 10)], [(6, -8), (8, 8)], [(-8, -8), (-1, 8)]]
+
+    def isavalidstate(self, x):
+        ans = False
+        for i in range(self.n):
+            ans = ans or (x[i] < self.x_lb[i])
+            ans = ans or (x[i] > self.x_ub[i])
+        for obs in self.obstacles:
+            on_obs = ((x[0] > obs[0][0]) and (x[1] > obs[0][1]) and (x[0] < obs[1][0]) and (x[1] < obs[1][1]))
+            ans = ans or on_obs
+        return not ans
+
+    _OBSTACLE_OWNER = None
+
+    def device_obstacles(self):
+        return dict(axes=(0, 1), half=(0.0, 0.0), boxes=[[o[0][0], o[0][1], o[1][0], o[1][1]] for o in self.obstacles])
+
+
+HolonomicMobileRobotwithObstacles._OBSTACLE_OWNER = HolonomicMobileRobotwithObstacles
+
+
 class KinematicBicyleModel(system.ContinuousDynamicSystem):
     """dx = v cos(theta), dy = v sin(theta), dtheta = v tan(beta) / length."""
 

@@ -343,8 +343,12 @@ def device_dynamics_of(sys):
         return None
     # the kernels implement the plain inclusive box: a subclass override AND an instance attribute (the reference
     # itself assigns sys.isavalidstate on instances, manipulator.py:441) both send the system to the table tier
-    if getattr(sys.isavalidinput, "__func__", None) is not Base.isavalidinput:
-        return None
+    vi = getattr(sys.isavalidinput, "__func__", None)
+    if vi is not Base.isavalidinput:
+        # a state-dependent input test is in-kernel only as the stock test of the class the kernel was written for
+        owner = getattr(type(sys), "_INPUT_VALIDITY_OWNER", None)
+        if owner is None or vi is not owner.__dict__.get("isavalidinput"):
+            return None
     vs = getattr(sys.isavalidstate, "__func__", None)
     if vs is not Base.isavalidstate:
         # box + obstacle boxes: in-kernel when it is exactly the test of the class that describes its obstacles to the

@@ -80,9 +80,10 @@ class DynamicProgramming:
     def _make_engine(self):
         dd = device_dynamics_of(self.sys)
         cost = self.cf.device_cost() if hasattr(self.cf, "device_cost") else None
-        if cost is not None and cost.get("kind") == "quadratic_domain":
+        if cost is not None and cost.get("kind") in ("quadratic_domain", "reachability"):
             # the in-kernel domain check tests the node against the SYSTEM's validity: it must be this system's own
-            if cost.pop("validity_of", None) is not self.sys or getattr(self.cf.isavalidstate, "__func__", None) is not getattr(self.sys.isavalidstate, "__func__", 0):
+            test = self.cf.isavalidstate if cost["kind"] == "quadratic_domain" else self.cf.isavalidestate
+            if cost.pop("validity_of", None) is not self.sys or getattr(test, "__func__", None) is not getattr(self.sys.isavalidstate, "__func__", 0):
                 cost = None
         self.tier = "fused" if (dd is not None and cost is not None) else "table"
         if self.INTERPOLATION != "linear" and dd is not None and dd[0] != _native.DYN_PENDULUM:

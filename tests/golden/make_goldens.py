@@ -421,6 +421,27 @@ def case_suspension():
     save("suspension_13x11x21x5", **out)
 
 
+def case_longcar():
+    """LongitudinalFrontWheelDriveCarWithWheelSlipInput 31x31 x 7 with the car_braking.py bounds / weights: a
+    state-dependent isavalidinput (negative wheel loads), tables, LUT and base class."""
+    from pyro.dynamic import vehicle_propulsion
+    with quiet():
+        s = vehicle_propulsion.LongitudinalFrontWheelDriveCarWithWheelSlipInput()
+        s.x_ub[1] = 15; s.x_lb[1] = 0
+        s.yc = 1.5                  # a high centre of gravity: hard braking would lift the rear axle -> isavalidinput bites
+        g = discretizer.GridDynamicSystem(s, [31, 31], [7], 0.05)
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+        q.xbar = np.array([45, 0]); q.Q[0, 0] = 0.1; q.Q[1, 1] = 0.1; q.INF = 1000000
+    out = _meta(s, g, q)
+    out.update(_lut_and_base(g, q, 5, (1, 5)))
+    rng = np.random.default_rng(4)
+    X = rng.uniform(s.x_lb - 1.0, s.x_ub + 1.0, size=(64, 2)); U = rng.uniform(s.u_lb * 1.3, s.u_ub * 1.3, size=(64, 1))
+    out.update(kat_X=X, kat_U=U, kat_dX=np.array([s.f(X[i], U[i]) for i in range(64)]),
+               kat_uvalid=np.array([bool(s.isavalidinput(X[i], U[i])) for i in range(64)]),
+               params=np.array([s.lenght, s.xc, s.yc, s.mass, s.gravity, s.rho, s.cdA, s.mu_max, s.mu_slope], dtype=float))
+    save("longcar_31x31x7", **out)
+
+
 def _kat3(s):
     """64 random (x, u) around the state box -> f, isavalidstate of a three-dimensional system."""
     rng = np.random.default_rng(3)
@@ -639,7 +660,7 @@ def case_floatmass():
     save("floatmass_51x51x21", **out)
 
 
-CASES = dict(car=case_car, suspension=case_suspension, floatmass=case_floatmass, acrobot=case_acrobot, mintime=case_mintime, mountaincar=case_mountaincar, spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
+CASES = dict(longcar=case_longcar, car=case_car, suspension=case_suspension, floatmass=case_floatmass, acrobot=case_acrobot, mintime=case_mintime, mountaincar=case_mountaincar, spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
              policy_eval=case_policy_eval, cost_kat=case_cost_kat, grid_kat=case_grid_kat,
              pendulum_small=case_pendulum_small, config1=case_config1, lowdef=case_lowdef,
              pendulum_demo=case_pendulum_demo, cartpole_small=case_cartpole_small,

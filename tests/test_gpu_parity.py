@@ -1308,7 +1308,8 @@ def _native3d(p, dtype="float64", flags=0):
     if p.domain_check:
         cost["kind"] = "quadratic_domain"
     t = p.trig_tables()
-    trig = (t["c2"], t["s2"]) if p.dyn_id == O.DYN_KINCAR else ((t["z"], t["dz"]) if p.dyn_id == O.DYN_QUARTERCAR else ())
+    trig = {O.DYN_KINCAR: lambda: (t["c2"], t["s2"]), O.DYN_QUARTERCAR: lambda: (t["z"], t["dz"]),
+            O.DYN_LONGCAR: lambda: (t["fd"],)}.get(p.dyn_id, lambda: ())()
     return _native.Problem(p.levels, p.u_levels, p.x_lb, p.x_ub, p.u_lb, p.u_ub, p.dt, dtype=dtype,
                            dynamics_id=p.dyn_id, dyn_params=list(p.dyn_c), trig=trig, cost=cost,
                            obstacles=p.obstacles, act_aux=p.act_aux, flags=flags)
@@ -1630,3 +1631,59 @@ def test_c_shard_schedule_with_caller_transport_on_one_gpu(tmp_path, case, world
     for p in parts:
         assert int(p["n"]) == n and np.allclose(p["st"], st[-1], rtol=1e-12) and np.allclose(p["st5"], st5[-1], rtol=1e-12)
     h.close()
+
+
+@pytest.mark.gpu
+def test_remaining_dp_demos_run_fused():
+    """2D_navigation.py (point robot with obstacles), car_braking.py (longitudinal car: its isavalidinput rejects inputs
+    that lift an axle, tested per cell in-kernel) and pendulum_reachability.py (Reachability cost) through the class
+    surface: fused tier, the reference's own tables and results."""
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import pendulum, vehicle_propulsion, vehicle_steering
+    from pyro_amd.planning import discretizer, dynamicprogramming
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = vehicle_steering.HolonomicMobileRobotwithObstacles()
+        gs = discretizer.GridDynamicSystem(s, [21, 21], [3, 3])
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+        q.xbar = np.array([10.0, 0.0]); q.R[0, 0] = 0.0; q.R[1, 1] = 0.0; q.S[0, 0] = 10.0; q.S[1, 1] = 10.0; q.INF = 8000
+        g = load("obstacles_21x21x3x3")
+        for cls, key in ((dynamicprogramming.DynamicProgrammingWithLookUpTable, "J_5"), (dynamicprogramming.DynamicProgramming, "Jbase_5")):
+            dp = cls(gs, q)
+            assert dp.tier == "fused"
+            dp.compute_steps(5)
+            assert relerr(dp.J, g[key]) < 1e-12 and np.array_equal(dp.pi, g[key.replace("J", "pi")])
+        assert int(g["differs"]) > 0                       # the two classes really differ on this case
+        assert np.array_equal(gs.x_next_table, g["x_next_table"]) and np.array_equal(gs.x_next_isok, g["x_next_isok"])
+
+        s = vehicle_propulsion.LongitudinalFrontWheelDriveCarWithWheelSlipInput()
+        s.x_ub[1] = 15; s.x_lb[1] = 0; s.yc = 1.5
+        gs = discretizer.GridDynamicSystem(s, [31, 31], [7], 0.05)
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+        q.xbar = np.array([45, 0]); q.Q[0, 0] = 0.1; q.Q[1, 1] = 0.1; q.INF = 1000000
+        g = load("longcar_31x31x7")
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(gs, q)
+        assert dp.tier == "fused"
+        dp.compute_steps(5)
+        assert relerr(dp.J, g["J_5"]) < 1e-12 and np.array_equal(dp.pi, g["pi_5"])
+        assert np.array_equal(gs.x_next_table, g["x_next_table"])
+        xn, xok, aok, G = dp._p.build_tables()
+        assert np.array_equal(aok, g["action_isok"]) and not aok.all() and np.array_equal(xok, g["x_next_isok"])
+        np.testing.assert_allclose(G, g["G"], rtol=1e-14)
+        db = dynamicprogramming.DynamicProgramming(gs, q, dtype="float32")
+        db.compute_steps(5)
+        assert relerr(db.J, g["Jbase_5"]) <= REL_F32
+
+        s = pendulum.SinglePendulum()
+        s.xbar = np.array([-3.14, 0])
+        gs = discretizer.GridDynamicSystem(s, [41, 41], [3])
+        cf = costfunction.Reachability(s.isavalidstate, s.xbar)
+        g = load("reachability_41x41x3")
+        for dtype, tol in (("float64", 1e-12), ("float32", REL_F32)):
+            dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(gs, cf, dtype=dtype)
+            assert dp.tier == "fused"
+            assert np.array_equal(dp.J, g["J0"])
+            dp.compute_steps(20)
+            assert relerr(dp.J, g["J_20"]) <= tol
+        # a custom target test is arbitrary Python: table tier
+        cf2 = costfunction.Reachability(s.isavalidstate, s.xbar, isontarget=lambda x, t=0: bool(abs(x[0] + 3.14) < 0.3))
+        assert dynamicprogramming.DynamicProgrammingWithLookUpTable(gs, cf2).tier == "table"

@@ -371,7 +371,25 @@ def test_3d_systems_tables_and_sweeps_match_reference(name):
         if k in (1, 5):
             np.testing.assert_allclose(J, g["J_%d" % k], rtol=1e-12, atol=1e-12)
             assert np.array_equal(pi, g["pi_%d" % k])
-    if "kat_X" in g.files:                          # f and isavalidstate at random points around the box
-        X, U = g["kat_X"], g["kat_U"]
-        valid = O.state_valid(p, tuple(X[:, d] for d in range(3)))
+    if "kat_valid" in g.files:                      # isavalidstate at random points around the box
+        X = g["kat_X"]
+        valid = O.state_valid(p, tuple(X[:, d] for d in range(p.n)))
         assert np.array_equal(valid, g["kat_valid"])
+
+
+def test_reachability_cost_restatement_matches_reference():
+    """costfunction.Reachability on the pendulum (pendulum_reachability.py): G = 0 on valid cells | INF, J0 = 0 inside the
+    target ball | INF, J after 1 and 20 sweeps of the look-up-table class."""
+    g = load("reachability_41x41x3")
+    lv = O.make_levels(g["x_lb"], g["x_ub"], g["dims"])
+    ul = O.make_levels(g["u_lb"], g["u_ub"], g["udims"])
+    p = O.Problem(lv, ul, float(g["dt"]), O.DYN_PENDULUM, O.pendulum_consts(), np.zeros((2, 2)), np.zeros((1, 1)),
+                  np.zeros((2, 2)), g["xbar"], np.zeros(1), float(g["INF"]), float(g["EPS"]), reachability=True)
+    xn, x_ok, a_ok, G = O.cells(p, np.arange(p.nodes_n))
+    assert np.array_equal(xn, g["x_next_table"]) and np.array_equal(G, g["G"])
+    J = O.terminal_cost(p)
+    assert np.array_equal(J, g["J0"])
+    for k in range(1, 21):
+        J, pi = O.sweep(p, J)
+        if k in (1, 20):
+            np.testing.assert_allclose(J, g["J_%d" % k], rtol=1e-12, atol=1e-12)
