@@ -207,6 +207,13 @@ int pvi_device_J(pvi_handle h, int which /*0 current, 1 previous*/, void** dev_p
 int pvi_device_pi(pvi_handle h, void** dev_ptr);
 int pvi_synchronize(pvi_handle h);
 
+/* diagnostics (sanitizer-style cross check): one backup of the CURRENT cost-to-go computed twice -- by the handle's
+   production kernel path (LDS windows, set-up tables, float32 displacement, ...) and by the plain-gather kernel with
+   float64 dynamics -- and compared on the device: max |J_a - J_b| / max |J_b| and the number of nodes whose action
+   differs.  The current cost-to-go is left alone; the previous-sweep buffer and the policy are overwritten as by a sweep
+   that is not counted.  float64 handles: both paths are exact, the result must be 0 / 0. */
+int pvi_self_check(pvi_handle h, double alpha, double* max_rel_diff, int64_t* pi_mismatches);
+
 /* ---- tables (tier B and reference attributes) ---------------------------------------------- */
 /* compute_xnext_table / compute_action_set_table / compute_cost_lookuptable for rows
    [row0,row0+nrows) (discretizer.py:342-376, :314-338; dynamicprogramming.py:517-553).

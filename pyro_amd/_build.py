@@ -33,6 +33,34 @@ def up_to_date():
     return all(os.path.getmtime(p) <= t for p in sources())
 
 
+OUT_SAN = os.path.join(PKG, "libpyrovi_ubsan.so")
+
+
+def sanitizer_runtime():
+    """Path of clang's shared UndefinedBehaviorSanitizer runtime (to LD_PRELOAD under python)."""
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    return subprocess.run([clang, "-print-file-name=libclang_rt.ubsan_standalone-x86_64.so"], capture_output=True,
+                          text=True, check=True).stdout.strip()
+
+
+def build_sanitized(force=False, verbose=True):
+    """The same translation unit with the HOST side of the C ABI instrumented (device code untouched):
+    pyro_amd/libpyrovi_ubsan.so, loaded instead of the product library when PYROVI_LIB points to it.
+    UndefinedBehaviorSanitizer with bounds checks, every report fatal.  (AddressSanitizer was the first choice, and the
+    library builds with it -- but ROCm's ASan runtime intercepts hsa_amd_memory_pool_allocate to put DEVICE memory under
+    its allocator and aborts with "out of memory" on the GPU boxes, with or without HSA_XNACK=1: it cannot be preloaded
+    under python there.)"""
+    if not force and os.path.exists(OUT_SAN) and all(os.path.getmtime(p) <= os.path.getmtime(OUT_SAN) for p in sources()):
+        return OUT_SAN
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-fsanitize=undefined,bounds", "-fno-sanitize=vptr,function", "-fno-sanitize-recover=undefined",
+           "-fno-gpu-sanitize", "-shared-libsan", "-o", OUT_SAN] + SRC
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=ROOT)
+    return OUT_SAN
+
+
 def build(force=False, verbose=True):
     if not force and up_to_date():
         return OUT

@@ -75,6 +75,7 @@ SYMBOLS = {
     "pvi_device_J": (C.c_int, [_h, C.c_int, C.POINTER(C.c_void_p)]),
     "pvi_device_pi": (C.c_int, [_h, C.POINTER(C.c_void_p)]),
     "pvi_synchronize": (C.c_int, [_h]),
+    "pvi_self_check": (C.c_int, [_h, C.c_double, _dp, C.POINTER(C.c_int64)]),
     "pvi_build_tables": (C.c_int, [_h, C.c_int32, C.c_int32, _dp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), _dp]),
     "pvi_set_tables": (C.c_int, [_h, _dp, _dp, C.POINTER(C.c_uint8)]),
     "pvi_set_interpolation": (C.c_int, [_h, C.c_int32]),
@@ -98,7 +99,8 @@ SYMBOLS = {
 }
 COMM_ID_BYTES = 128
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpyrovi.so")
+# (PYROVI_LIB: another build of the same library, e.g. the sanitizer host build pyro_amd/libpyrovi_ubsan.so)
+LIB_PATH = os.environ.get("PYROVI_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpyrovi.so")
 _lib = None
 
 
@@ -342,6 +344,13 @@ class Problem:
 
     def synchronize(self):
         check(lib().pvi_synchronize(self._h))
+
+    def self_check(self, alpha=1.0):
+        """(max relative difference of J, nodes whose action differs) between the production kernel path and the
+        plain-gather kernel, for one backup of the current cost-to-go (pvi_self_check)."""
+        d, n = C.c_double(0), C.c_int64(0)
+        check(lib().pvi_self_check(self._h, float(alpha), C.byref(d), C.byref(n)))
+        return d.value, n.value
 
     def build_tables(self, row0=None, nrows=None, x_next=True, x_next_isok=True, action_isok=True, G=True):
         row0, nrows = self._rows(row0, nrows, (0, self.dims[0]))

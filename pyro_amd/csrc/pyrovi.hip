@@ -2402,6 +2402,7 @@ struct pvi_problem {
     const int* aok32 = nullptr;  // isavalidinput per action as int32 (scalar loads in the exact kernel)
     const Act64* act64 = nullptr;   // float64 second form (k_sweep64): per-action records, {level, reciprocal} tables
     const double2* levr = nullptr;
+    bool force_exact = false; // pvi_self_check: route the next launch to the plain-gather kernel k_sweep
     bool use64 = false;
     int patch64 = -1;         // 4-D wave mapping of k_sweep64: 1 = 8 x 8 velocity patches, 0 = consecutive nodes (timed at set-up)
     size_t levr_bytes = 0;
@@ -3384,7 +3385,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         return PVI_OK;
     }
     if constexpr (sizeof(REAL) == 4) {
-        if (h->march_ok) {
+        if (h->march_ok && !h->force_exact) {
             const float al = (float)alpha;
             sc.nblocks = (unsigned)h->MP.ncols;
 #define MARCH(DYN)                                                                                                  \
@@ -3405,7 +3406,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             HIPCHK(hipGetLastError());
             return PVI_OK;
         }
-        if (h->lean_ok && h->lean_persist) {
+        if (h->lean_ok && h->lean_persist && !h->force_exact) {
             float al = (float)alpha;
             sc.nblocks = h->lean_pgrid;
             const float4* actp = h->F.act;
@@ -3418,7 +3419,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
                                    h->lean_lds * h->LP.nbuf, st));
             return PVI_OK;
         }
-        if (h->lean_ok) {
+        if (h->lean_ok && !h->force_exact) {
             const float al = (float)alpha;
             sc.nblocks = h->lean_grid.x;
             sc.split_finish = (sc.nblocks >= 16384u && !getenv("PVI_NO_SPLIT_FINISH")) ? 1 : 0;
@@ -3456,7 +3457,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             HIPCHK(hipGetLastError());
             return PVI_OK;
         }
-        if (h->tile_ok) {
+        if (h->tile_ok && !h->force_exact) {
             const int blk = h->tile_block;
             const unsigned gf = grid_for(h->owned << h->T.lsplit, blk);
             const size_t lds = (size_t)h->T.lds_floats * 4;
@@ -3478,7 +3479,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             HIPCHK(hipGetLastError());
             return PVI_OK;
         }
-        if (h->fast_ok && !is_node_dyn(h->d.dynamics_id)) {
+        if (h->fast_ok && !is_node_dyn(h->d.dynamics_id) && !h->force_exact) {
             const unsigned gf = grid_for(h->owned << h->F.lsplit);
             const float al = (float)alpha;
             sc.nblocks = gf;
@@ -3509,7 +3510,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         hipLaunchKernelGGL((k_sweep<DYN, REAL, PI_T, false>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha, sc, h->P.utab,   \
                            h->P.gu, h->aok32);
     if constexpr (sizeof(REAL) == 8) {
-        if (h->use64) {
+        if (h->use64 && !h->force_exact) {
             const bool off32 = (unsigned long long)h->stored * 8ull < (1ull << 32);
             // 4-D: 8 x 8 velocity patches per wave (PVI_PATCH=0: consecutive nodes)
             const bool patch = h->P.n == 4 && h->patch64 != 0;
@@ -3727,6 +3728,94 @@ extern "C" int pvi_sweep_stats(pvi_handle h, double stats3[3], void* stream) {
     stats3[1] = res[1];
     stats3[2] = res[2];
     return PVI_OK;
+}
+
+// ---- self check: production kernel path against the plain-gather kernel (sanitizer-style cross check) -----------
+template <typename REAL, typename PI_T>
+__global__ void k_compare(const REAL* __restrict__ Ja, const REAL* __restrict__ Jb, const PI_T* __restrict__ pa,
+                          const PI_T* __restrict__ pb, long long n, long long joff, unsigned long long* out) {
+    // out[0] = max |Ja - Jb|, out[1] = max |Jb| (order-preserving encodings), out[2] = nodes whose action differs
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    double d = 0.0, m = 0.0;
+    int diff = 0;
+    if (i < n) {
+        const double a = (double)Ja[joff + i], b = (double)Jb[joff + i];
+        d = fabs(a - b);
+        m = fabs(b);
+        diff = pa[i] != pb[i];
+    }
+    d = wave_max(d);
+    m = wave_max(m);
+    const unsigned long long nd = __popcll(__ballot(diff));
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&out[0], enc_f64(d));
+        atomicMax(&out[1], enc_f64(m));
+        if (nd) atomicAdd(&out[2], nd);
+    }
+}
+
+extern "C" int pvi_self_check(pvi_handle h, double alpha, double* max_rel_diff, int64_t* pi_mismatches) {
+    if (!h || !max_rel_diff || !pi_mismatches) return fail(PVI_EINVAL, "NULL argument");
+    if (h->spline) return fail(PVI_ESTATE, "self check covers the linear interpolant");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t esz = h->d.dtype == PVI_F64 ? 8 : 4;
+    void *Jb = nullptr, *pb = nullptr;
+    unsigned long long* out = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(Jb);
+        (void)hipFree(pb);
+        (void)hipFree(out);
+    };
+    hipError_t e = hipMalloc(&Jb, (size_t)h->stored * esz + 64);
+    if (e == hipSuccess) e = hipMalloc(&pb, (size_t)h->owned * h->pi_size);
+    if (e == hipSuccess) e = hipMalloc((void**)&out, 3 * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        cleanup();
+        return fail(PVI_ENOMEM, "self check scratch: %s", hipGetErrorString(e));
+    }
+    const unsigned long long init[3] = {enc_f64(0.0), enc_f64(0.0), 0ull};
+    int rc = [&]() -> int {
+        HIPCHK(hipMemcpyAsync(out, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+        // (1) the handle's production path: J_cur -> the other buffer, pi
+        hipLaunchKernelGGL(k_reset_stats, 1, STAT_WORDS, 0, h->stream, h->slots, STAT_WORDS);
+        hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, h->stream, h->ctrl);
+        int r = launch_sweep(h, h->cur, alpha, h->stream, 0, -1.0);
+        if (r) return r;
+        // (2) the plain-gather kernel (float64 dynamics, no windows, no set-up tables) into scratch buffers
+        void* Ja = h->J[h->cur ^ 1];
+        void* pa = h->pi;
+        h->J[h->cur ^ 1] = Jb;
+        h->pi = pb;
+        h->force_exact = true;
+        hipLaunchKernelGGL(k_reset_stats, 1, STAT_WORDS, 0, h->stream, h->slots, STAT_WORDS);
+        hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, h->stream, h->ctrl);
+        r = launch_sweep(h, h->cur, alpha, h->stream, 0, -1.0);
+        h->force_exact = false;
+        h->J[h->cur ^ 1] = Ja;
+        h->pi = pa;
+        if (r) return r;
+        const long long joff = (long long)(h->P.row_begin - h->P.store_begin) * h->plane;
+        const unsigned g = grid_for(h->owned);
+#define CMP(REAL, PI_T) \
+    hipLaunchKernelGGL((k_compare<REAL, PI_T>), g, 256, 0, h->stream, (const REAL*)Ja, (const REAL*)Jb, (const PI_T*)pa, \
+                       (const PI_T*)pb, (long long)h->owned, joff, out)
+        if (esz == 8) {
+            if (h->pi_size == 1) CMP(double, unsigned char); else CMP(double, unsigned short);
+        } else {
+            if (h->pi_size == 1) CMP(float, unsigned char); else CMP(float, unsigned short);
+        }
+#undef CMP
+        HIPCHK(hipGetLastError());
+        unsigned long long res[3];
+        HIPCHK(hipMemcpyAsync(res, out, sizeof(res), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const double d = dec_f64(res[0]), m = dec_f64(res[1]);
+        *max_rel_diff = m > 0.0 ? d / m : d;
+        *pi_mismatches = (int64_t)res[2];
+        return PVI_OK;
+    }();
+    cleanup();
+    return rc;
 }
 
 // ---- interpolation mode ---------------------------------------------------------------------------------

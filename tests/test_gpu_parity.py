@@ -1687,3 +1687,47 @@ def test_remaining_dp_demos_run_fused():
         # a custom target test is arbitrary Python: table tier
         cf2 = costfunction.Reachability(s.isavalidstate, s.xbar, isontarget=lambda x, t=0: bool(abs(x[0] + 3.14) < 0.3))
         assert dynamicprogramming.DynamicProgrammingWithLookUpTable(gs, cf2).tier == "table"
+
+
+@pytest.mark.gpu
+def test_sanitized_host_build_runs_clean():
+    """the host side of the C ABI under a sanitizer.  tools/abi_tour.py (every handle kind, sweeps with a stop,
+    up/downloads, tables, packed tables, spline mode, rollouts, obstacle systems, self check, one-rank shards with and
+    without RCCL, error paths) runs against pyro_amd/libpyrovi_ubsan.so (UBSan + bounds, every report fatal) preloaded
+    under python: it must finish and report nothing."""
+    import subprocess
+    import sys as _sys
+    from pyro_amd import _build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "pyro_amd", "libpyrovi_ubsan.so")
+    if not os.path.exists(lib):
+        lib = _build.build_sanitized(verbose=False)
+    env = dict(os.environ, LD_PRELOAD=_build.sanitizer_runtime(), PYROVI_LIB=lib,
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([_sys.executable, os.path.join(root, "tools", "abi_tour.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "ABI-TOUR-OK" in out and "runtime error" not in out, out[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["pendulum:201,201:21:float32", "cartpole:21,21,21,21:7:float32", "twolink:9,9,9,9:3,3:float64",
+                                  "pendulum:101,101:11:float64"])
+def test_self_check_production_path_against_plain_gather(case):
+    """pvi_self_check: one backup by the handle's production path (LDS windows, set-up tables, float32 displacement / the
+    float64 second form) and by the plain-gather kernel, compared on the device.  float64: identical; float32: within the
+    stated tolerance, few policy differences (near-ties)."""
+    from pyro_amd import configs
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg = configs.build(case)
+        h = cfg["grid_sys"]._device_problem(cost=cfg["cf"].device_cost(), dtype=cfg["dtype"])
+    h.terminal_cost()
+    h.sweep(6, 1.0, -1.0)
+    J = h.get_J()
+    d, n = h.self_check(1.0)
+    assert np.array_equal(h.get_J(), J)                     # the current cost-to-go is left alone
+    if cfg["dtype"] == "float64":
+        assert d == 0.0 and n == 0
+    else:
+        assert d <= 2e-6 and n <= 0.02 * J.size, (d, n)
+    h.close()
