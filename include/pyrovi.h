@@ -289,6 +289,10 @@ int pvi_shard_terminal_cost(pvi_shard s);
    stop when tol >= 0 and delta <= tol (every rank stops at the same sweep: the statistics are all-reduced).
    stats4 = (max J, max d, min d, delta) of the WHOLE grid for the last executed sweep. */
 int pvi_shard_sweep(pvi_shard s, int32_t max_sweeps, double alpha, double tol, double* stats4, int32_t* sweeps_done);
+/* tier B on a slab (dynamics_id == PVI_DYN_TABLE): the look-up tables and the initial cost-to-go of THIS rank's rows;
+   pvi_shard_set_J also exchanges the halos (call it on every rank) */
+int pvi_shard_set_tables(pvi_shard s, const double* x_next_rows, const double* G_rows, const uint8_t* ok_rows);
+int pvi_shard_set_J(pvi_shard s, const double* J_owned_rows);
 int pvi_shard_get_J(pvi_shard s, double* J_owned_rows);   /* this rank's rows, float64 */
 int pvi_shard_get_pi(pvi_shard s, int64_t* pi_owned_rows);
 int pvi_shard_describe(pvi_shard s, char* buf, int32_t n);

@@ -93,6 +93,8 @@ SYMBOLS = {
     "pvi_shard_rows": (C.c_int, [_h, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "pvi_shard_terminal_cost": (C.c_int, [_h]),
     "pvi_shard_sweep": (C.c_int, [_h, C.c_int32, C.c_double, C.c_double, _dp, C.POINTER(C.c_int32)]),
+    "pvi_shard_set_tables": (C.c_int, [_h, _dp, _dp, C.POINTER(C.c_uint8)]),
+    "pvi_shard_set_J": (C.c_int, [_h, _dp]),
     "pvi_shard_get_J": (C.c_int, [_h, _dp]),
     "pvi_shard_get_pi": (C.c_int, [_h, C.POINTER(C.c_int64)]),
     "pvi_shard_describe": (C.c_int, [_h, C.c_char_p, C.c_int32]),
@@ -464,6 +466,25 @@ class ShardedProblem:
         out = np.empty((self.rows[1] - self.rows[0]) * self.plane)
         check(lib().pvi_shard_get_J(self._h, _ptr(out)))
         return out
+
+    def set_tables(self, x_next, G, ok=None):
+        """Tier B: tables of this rank's rows ([owned nodes, A, n], [owned nodes, A]; ok mask: base-class semantics)."""
+        x_next, G = _f64(x_next), _f64(G)
+        nodes = (self.rows[1] - self.rows[0]) * self.plane
+        A, n = self._desc_owner.actions_n, self._desc_owner.n
+        if x_next.shape != (nodes, A, n) or G.shape != (nodes, A):
+            raise ValueError("table shapes do not match this rank's rows")
+        okp = None
+        if ok is not None:
+            ok = np.ascontiguousarray(ok, dtype=np.uint8)
+            okp = ok.ctypes.data_as(C.POINTER(C.c_uint8))
+        check(lib().pvi_shard_set_tables(self._h, _ptr(x_next), _ptr(G), okp))
+
+    def set_J(self, J):
+        J = _f64(J).ravel()
+        if J.size != (self.rows[1] - self.rows[0]) * self.plane:
+            raise ValueError("Grid size does not match data")
+        check(lib().pvi_shard_set_J(self._h, _ptr(J)))
 
     def get_pi(self):
         out = np.empty((self.rows[1] - self.rows[0]) * self.plane, dtype=np.int64)

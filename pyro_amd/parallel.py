@@ -33,14 +33,30 @@ def partition_rows(n_rows, world):
     return out
 
 
-def halo_rows(grid_sys):
-    """Rows of axis 0 a gather can reach beyond a node's own row (+1 for the upper corner)."""
+def halo_rows(grid_sys, rows=None):
+    """Rows of axis 0 a gather can reach beyond a node's own row (+1 for the upper corner).  Mechanical systems:
+    x_next_0 - x_0 = dq_0 dt exactly, so the bound is analytic.  Any other system: the largest |x_next_0 - x_0| over
+    the cells whose x_next stays in the grid box, taken from the x_next table of `rows` (default: the whole grid) --
+    for the table tier that table exists anyway; a rank that looks at its own rows only gets a LOCAL bound, and the
+    library reports PVI_EHALO if a gather ever leaves the stored rows."""
     s = grid_sys.sys
     dof = getattr(s, "dof", None)
-    if dof is None:
-        raise NotImplementedError("halo width is only known analytically for mechanical systems (x_next_0 = q_0 + dq_0 dt)")
-    vmax = max(abs(float(s.x_lb[dof])), abs(float(s.x_ub[dof])))
-    return int(math.ceil(vmax * grid_sys.dt / float(grid_sys.x_step_size[0]))) + 1
+    if dof is not None:
+        vmax = max(abs(float(s.x_lb[dof])), abs(float(s.x_ub[dof])))
+        return int(math.ceil(vmax * grid_sys.dt / float(grid_sys.x_step_size[0]))) + 1
+    plane = int(np.prod(grid_sys.x_grid_dim[1:]))
+    if rows is None:
+        xn, lo = grid_sys.x_next_table, 0
+    else:
+        lo = rows[0] * plane
+        xn = grid_sys._xnext_rows(lo, rows[1] * plane)[0]
+    x0 = np.repeat(grid_sys.x_level[0], plane)[lo:lo + xn.shape[0]]
+    inside = np.ones(xn.shape[:2], dtype=bool)
+    for d in range(s.n):
+        inside &= (xn[:, :, d] >= grid_sys.x_level[d][0]) & (xn[:, :, d] <= grid_sys.x_level[d][-1])
+    reach = np.abs(xn[:, :, 0] - x0[:, None])[inside]
+    r = float(reach.max()) if reach.size else 0.0
+    return int(math.ceil(r / float(grid_sys.x_step_size[0]))) + 1
 
 
 class HipSlab:
@@ -280,14 +296,43 @@ class RcclValueIteration:
 
     def __init__(self, grid_sys, cost_function, rank, world, comm_id=None, dtype="float32", device=0, halo=None,
                  overlap=True, transport=None):
+        from pyro_amd.planning.discretizer import device_dynamics_of
         self.rank, self.world = int(rank), int(world)
         self.grid_sys = grid_sys
-        self.halo = halo_rows(grid_sys) if halo is None else int(halo)
         cost = cost_function.device_cost() if hasattr(cost_function, "device_cost") else cost_function
-        self.shard = grid_sys._shard_problem(self.rank, self.world, self.halo, comm_id=comm_id, overlap=overlap, cost=cost,
-                                             dtype=dtype, device=device, transport=transport)
+        fused = device_dynamics_of(grid_sys.sys) is not None and isinstance(cost, dict)
+        if fused:
+            cost.pop("validity_of", None)
+            self.halo = halo_rows(grid_sys) if halo is None else int(halo)
+            self.shard = grid_sys._shard_problem(self.rank, self.world, self.halo, comm_id=comm_id, overlap=overlap,
+                                                 cost=cost, dtype=dtype, device=device, transport=transport)
+            self.rows = self.shard.rows
+            self.shard.terminal_cost()
+            return
+        # table tier (arbitrary Python sys.f / cf.g): every rank builds the reference's look-up tables for ITS rows only
+        # (the O(N*A) host loops of discretizer.py:342-376 and dynamicprogramming.py:517-553, split over the ranks) and
+        # the sweeps run sharded like the fused ones
+        n0 = int(grid_sys.x_grid_dim[0])
+        r0, r1 = partition_rows(n0, self.world)[self.rank]
+        plane = int(np.prod(grid_sys.x_grid_dim[1:]))
+        lo, hi = r0 * plane, r1 * plane
+        xn, xok = grid_sys._xnext_rows(lo, hi)
+        self.halo = (halo_rows(grid_sys, (r0, r1)) if halo is None else int(halo))
+        X, U, s = grid_sys.state_from_node_id, grid_sys.input_from_action_id, grid_sys.sys
+        aok = np.array([[s.isavalidinput(X[i], U[a]) for a in range(grid_sys.actions_n)] for i in range(lo, hi)], dtype=bool)
+        ok = aok & xok
+        G = np.full(ok.shape, float(cost_function.INF))
+        for i, a in zip(*np.nonzero(ok)):
+            G[i, a] = cost_function.g(X[lo + i], U[a], 0) * grid_sys.dt
+        kw = dict(x_levels=grid_sys.x_level, u_levels=grid_sys.u_level, x_lb=s.x_lb, x_ub=s.x_ub, u_lb=s.u_lb, u_ub=s.u_ub,
+                  dt=grid_sys.dt, dtype=dtype, dynamics_id=0, table_inf=float(cost_function.INF), device=device)
+        from pyro_amd import _native
+        self.shard = _native.ShardedProblem(self.rank, self.world, self.halo, comm_id=comm_id, overlap=overlap,
+                                            transport=transport, **kw)
         self.rows = self.shard.rows
-        self.shard.terminal_cost()
+        assert self.rows == (r0, r1)
+        self.shard.set_tables(xn, G, None)
+        self.shard.set_J(np.array([cost_function.h(X[i], 0) for i in range(lo, hi)], dtype=float))
 
     def run(self, max_sweeps, alpha=1.0, tol=-1.0):
         """compute_steps (tol < 0) / solve_bellman_equation (tol >= 0): -> ((max J, max d, min d, delta), sweeps done)."""
