@@ -2594,7 +2594,8 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
         rs = (summary[1] + 3) & ~3;
         L.rs_magic = magic32((unsigned)rs);
     }
-    const long long need = (long long)summary[0] * rs + 128;
+    // (2-D windows are staged as pairs -- 8 bytes per column, sweep_lean.inc lds_corners -- 4-D windows as single floats)
+    const long long need = (long long)summary[0] * rs * (DOF == 1 ? 2 : 1) + 128;
     if (need <= lds_budget_floats) {
         L.RS = rs;
         h->lean_pw1 = rs;
