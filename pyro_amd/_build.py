@@ -74,3 +74,5 @@ def build(force=False, verbose=True):
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print("built", OUT)
+    if "--no-sanitized" not in sys.argv:
+        print("built", build_sanitized(force="--force" in sys.argv))

@@ -24,6 +24,19 @@ def test_library_exports_every_declared_symbol():
     assert L.pvi_abi_version() == 2
 
 
+def test_sanitized_library_is_rebuilt_with_the_product_library():
+    """pyro_amd/libpyrovi_ubsan.so (the GPU suite's sanitizer run) is built from the same sources: a stale copy would miss
+    entry points added since.  build_sanitized() refreshes it when any source is newer; it must export the whole header."""
+    import ctypes
+    from pyro_amd import _build, _native
+    if not os.path.exists(_build.sanitizer_runtime()):
+        pytest.skip("no UBSan runtime in this toolchain")
+    ctypes.CDLL(_build.sanitizer_runtime(), mode=ctypes.RTLD_GLOBAL)
+    L = ctypes.CDLL(_build.build_sanitized(verbose=False))
+    for name in _native.SYMBOLS:
+        assert hasattr(L, name), "libpyrovi_ubsan.so does not export %s" % name
+
+
 def test_descriptor_layout_matches_header():
     """ctypes struct vs the C struct: compile a tiny probe with gcc and compare sizeof/offsets."""
     import ctypes

@@ -1716,9 +1716,7 @@ def test_sanitized_host_build_runs_clean():
     import sys as _sys
     from pyro_amd import _build
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lib = os.path.join(root, "pyro_amd", "libpyrovi_ubsan.so")
-    if not os.path.exists(lib):
-        lib = _build.build_sanitized(verbose=False)
+    lib = _build.build_sanitized(verbose=False)        # no-op when newer than every source file, rebuilt when stale
     env = dict(os.environ, LD_PRELOAD=_build.sanitizer_runtime(), PYROVI_LIB=lib,
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     r = subprocess.run([_sys.executable, os.path.join(root, "tools", "abi_tour.py")], env=env, capture_output=True, text=True,
