@@ -258,7 +258,9 @@ def run_single(args):
     head, cfg, p = measure(args.workload, args.steps, args.warmup, keep_handle=True)
     out = {"metric": "vi_state_action_cell_updates_per_sec", "value": head.pop("value"), "unit": head.pop("unit"),
            "n_gpus": 1, "steps": head.pop("steps"), "warmup": head.pop("warmup"),
-           "ms_per_step": head.pop("ms_per_step"), "higher_is_better": True, "scaling": "strong",
+           "ms_per_step": head.pop("ms_per_step"), "higher_is_better": True,
+           # N = 1 of the weak-scaling family of the N > 1 lines (C3 per GPU, pyro_amd/parallel_bench.py)
+           "scaling": "weak",
            "vs_baseline": None, "dtype": head.pop("dtype"), "data": "synthetic", "config": head.pop("config")}
     out.update(head)
     out["head"] = git_head()

@@ -30,9 +30,11 @@ def _pendulum(xdims, udims, dtype, demo=False):
     return s, g, cf, dtype
 
 
-def _cartpole(xdims, udims, dtype):
+def _cartpole(xdims, udims, dtype, rail=1):
     s = cartpole.CartPole()
     s.xbar = np.array([0.0, np.pi, 0.0, 0.0])          # upright (examples/.../cartpole_with_lqr.py)
+    if rail != 1:                                      # a rail `rail` times as long (the dynamics do not depend on x0)
+        s.x_lb[0], s.x_ub[0] = s.x_lb[0] * rail, s.x_ub[0] * rail
     g = _quiet(discretizer.GridDynamicSystem, s, list(xdims), list(udims))
     cf = costfunction.QuadraticCostFunction.from_sys(s)
     cf.INF = 1000
@@ -71,9 +73,19 @@ def _custom(spec):
     return "custom " + spec, (lambda: fn(xd, ud, dtype))
 
 
-def build(name):
+def weak_c3(world):
+    """The weak-scaling family of bench.py --gpus N: C3's spacing on every axis, 100 N + 1 rows of axis 0 on a rail N
+    times as long, so that every rank owns 100-101 rows of 101^3 nodes.  world = 1 is C3 itself."""
+    world = int(world)
+    return ("cart-pole (100*%d+1)x101^3 x 21 actions, f32: BASELINE configs[2] per GPU, rail x%d at the same spacing"
+            % (world, world), lambda: _cartpole((100 * world + 1, 101, 101, 101), (21,), "float32", rail=world))
+
+
+def build(name, world=1):
     if ":" in name:
         CONFIGS[name] = _custom(name)
+    if name == "c3w":
+        CONFIGS[name] = weak_c3(world)
     desc, fn = CONFIGS[name]
     s, g, cf, dtype = fn()
     return dict(name=name, description=desc, sys=s, grid_sys=g, cf=cf, dtype=dtype)

@@ -2517,7 +2517,7 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
     L.nty = (L.V0 + tv0 - 1) / tv0;
     L.TV0 = (L.V0 + L.nty - 1) / L.nty;
     L.tv1_magic = ((1 << 20) + L.TV1 - 1) / L.TV1;
-    L.half = L.npt == 2 ? ((L.TV0 + 1) / 2) * L.TV1 : L.TV0 * L.TV1;
+    L.half = ((L.TV0 + L.npt - 1) / L.npt) * L.TV1;  // nodes per band: thread t owns tile nodes t + k * half, k < npt
     L.posdim1 = DOF == 2 ? P.dim[1] : 1;
     L.pd_magic = magic32((unsigned)L.posdim1);
     L.vplane = (long long)L.V0 * L.V1;
@@ -2670,7 +2670,11 @@ static int lean_setup(pvi_problem* h) {
     // per-wave fixed work and fit 1001^2 into one round of resident waves (A = 1: 21 -> 15 us), but the two
     // register-resident node contexts cost the action loop more than that (C2 43.7 -> 49 us at 71 VGPRs / 7 waves,
     // 55 us squeezed to 63 VGPRs): opt-in for experiments, PVI_NPT=2
-    L.npt = (DOF == 1 && ls == 0 && getenv("PVI_NPT") && atoi(getenv("PVI_NPT")) == 2) ? 2 : 1;
+    L.npt = 1;
+    if (DOF == 1 && ls == 0 && getenv("PVI_NPT")) {
+        const int want = atoi(getenv("PVI_NPT"));
+        if (want == 2 || want == 4) L.npt = want;
+    }
     // 4-D: the best tile shape depends on how the grid divides (101^4: 15x34 beats 10x51 by 8 %, 151^4: 19x26 beats
     // 16x31 by 7 %) -- time the candidates (widths V1/k, as many rows as fit 512 threads) with two real sweeps each and
     // keep the fastest.  Results do not depend on the shape (same arithmetic per node).  PVI_TUNE=0 switches it off.
@@ -2727,9 +2731,9 @@ static int lean_setup(pvi_problem* h) {
         if (rc < 0) return rc;
         if (rc == 2) break;
         if (rc == 0) {
-            const int threads = L.npt == 2 ? L.half : ((L.TV0 * L.TV1) << L.lsplit);
+            const int threads = L.npt > 1 ? L.half : ((L.TV0 * L.TV1) << L.lsplit);
             h->lean_block = ((threads + 63) / 64) * 64;
-            if (h->lean_block > (L.npt == 2 ? 256 : 512)) continue;
+            if (h->lean_block > (L.npt > 1 ? 256 : 512)) continue;
             h->lean_ok = true;
             h->lean_lds_attr = false;
             if ((rc = lean_persist_setup(h))) return rc;
@@ -3444,6 +3448,8 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
                 case PVI_DYN_PENDULUM:
                     if (h->LP.npt == 2)
                         LEAN3(PVI_DYN_PENDULUM, true, 2)
+                    else if (h->LP.npt == 4)
+                        LEAN3(PVI_DYN_PENDULUM, true, 4)
                     else
                         LEAN(PVI_DYN_PENDULUM)
                     break;

@@ -1,4 +1,10 @@
-"""bench.py for N > 1: one process per GPU (torchrun), axis-0 slabs, halo exchange over RCCL."""
+"""bench.py for N > 1: one process per GPU (torchrun), axis-0 slabs, halo exchange + statistics all-reduce over RCCL.
+
+Headline (weak scaling, the family the N = 1 line belongs to): cart-pole, 101^3 x 21 actions per row of axis 0 and
+100 N + 1 rows on a rail N times as long -- the same spacing on every axis as BASELINE configs[2] (C3), every rank owns
+100-101 rows, N = 1 IS C3.  Secondary: BASELINE configs[3] (C4, 151^4 x 31) split over the same ranks (strong scaling,
+with its one-GPU rate measured on rank 0 beside it).
+"""
 import contextlib
 import io
 import json
@@ -7,11 +13,140 @@ import time
 
 import numpy as np
 
+MIN_REGION_S = 0.3
+
+
+def _quiet_build(name, **kw):
+    from pyro_amd import configs
+    with contextlib.redirect_stdout(io.StringIO()):
+        return configs.build(name, **kw)
+
+
+def _one_gpu_rate(cfg, local, sweeps):
+    """The same grid on ONE GPU (rank 0 only): cells/s."""
+    from pyro_amd.planning import dynamicprogramming
+    g = cfg["grid_sys"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, cfg["cf"], dtype=cfg["dtype"], device=local)
+    p = dp._p
+    p.sweep(2, 1.0, -1.0)
+    p.synchronize()
+    t0 = time.perf_counter()
+    p.sweep(sweeps, 1.0, -1.0)
+    p.synchronize()
+    rate = g.nodes_n * g.actions_n * sweeps / (time.perf_counter() - t0)
+    p.close()
+    return rate
+
+
+def _barrier(dist, torch):
+    """Host-side barrier (a one-element all-reduce of a CPU tensor: the gloo half of the process group)."""
+    dist.all_reduce(torch.zeros(1, dtype=torch.int32))
+
+
+def _agree(dist, torch, ok):
+    """True when every rank says ok (host-side all-reduce)."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+class _Driver:
+    """One sharded solver behind run(n) -> statistics of the last sweep; in-library RCCL first, torch.distributed's nccl
+    backend (the Python-driven schedule of pyro_amd.parallel.ShardedValueIteration) when that cannot start on some rank."""
+
+    def __init__(self, cfg, dist, torch, rank, world, local, via_torch):
+        from pyro_amd import _native, parallel
+        g = cfg["grid_sys"]
+        self.fallback_reason = None
+        self.vi = None
+        if not via_torch:
+            err = None
+            try:
+                ids = [_native.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                self.vi = parallel.RcclValueIteration(g, cfg["cf"], rank, world, comm_id=ids[0], dtype=cfg["dtype"], device=local)
+                self.vi.run(1, 1.0, -1.0)                 # one whole sweep: exchange + all-reduce have run
+            except Exception as e:                        # noqa: BLE001 -- any failure selects the other transport
+                err = "%s: %s" % (type(e).__name__, e)
+            if _agree(dist, torch, err is None):
+                vi = self.vi
+                self.run = lambda n: list(vi.run(n, 1.0, -1.0)[0])
+                desc = vi.describe()
+                self.halo, self.p2p, self.overlap, self.describe = vi.halo, "send/recv" in desc, "+overlap" in desc, vi.describe
+                self.collectives = "RCCL inside libpyrovi (pvi_shard_*)"
+                return
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            self.fallback_reason = next((e for e in errs if e), "unknown")
+            if self.vi is not None:
+                with contextlib.suppress(Exception):
+                    self.vi.close()
+        vi = parallel.ShardedValueIteration(g, cfg["cf"], dist, dtype=cfg["dtype"], device=local)
+        self.vi = vi
+        self.run = lambda n: vi.run(n, 1.0, -1.0)
+        self.halo, self.p2p, self.overlap, self.describe = vi.halo, vi.p2p, vi.overlap, vi.slab.describe
+        self.collectives = "torch.distributed (nccl)"
+
+    def close(self):
+        with contextlib.suppress(Exception):
+            if hasattr(self.vi, "close"):
+                self.vi.close()
+            elif hasattr(self.vi, "slab"):
+                self.vi.slab.close()
+
+
+def _timed(drv, dist, torch, steps, warmup):
+    """W warm-up sweeps, then batches of exactly K sweeps, each bracketed by barrier + synchronize on both sides and
+    reduced with max over the ranks, until the region reaches MIN_REGION_S (every rank takes the same decisions: they
+    are made on the all-reduced times)."""
+    if warmup:
+        drv.run(warmup)
+    torch.cuda.synchronize()
+    batches, elapsed, st = 0, 0.0, None
+    while batches == 0 or elapsed < MIN_REGION_S:
+        _barrier(dist, torch)
+        t0 = time.perf_counter()
+        st = drv.run(steps)                    # fixed sweep count: statistics (one all-reduce) for the last sweep only
+        torch.cuda.synchronize()               # (pvi_shard_sweep has synchronised its own streams already)
+        _barrier(dist, torch)
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed += float(t.item())
+        batches += 1
+    return elapsed, batches, st
+
+
+def _fragment(cfg, drv, world, steps, warmup, elapsed, batches, st, setup_s):
+    g = cfg["grid_sys"]
+    N, A = g.nodes_n, g.actions_n
+    w = 4 if cfg["dtype"] == "float32" else 8
+    timed = steps * batches
+    alg = N * (2 * w + (1 if A <= 256 else 2))
+    par = "axis-0 slabs x%d, halo %d rows, %s%s, collectives: %s" % (
+        world, drv.halo, "p2p send/recv" if drv.p2p else "slab broadcast",
+        ", exchange overlapped with the interior kernel" if drv.overlap else "", drv.collectives)
+    out = {
+        "value": N * A * timed / elapsed, "unit": "cells/s", "steps": steps, "warmup": warmup,
+        "batches": batches, "timed_steps": timed, "timed_region_s": elapsed, "ms_per_step": elapsed / timed * 1e3,
+        "sweeps_per_sec": timed / elapsed, "setup_ms": setup_s * 1e3, "dtype": "f32" if w == 4 else "f64",
+        "config": {"workload": "%s: %s" % (cfg["name"], cfg["description"]), "nodes": N, "actions": A,
+                   "cells_per_sweep": N * A, "dt": g.dt, "alpha": 1.0, "parallelism": par},
+        "roofline": {"bound": "hbm", "achieved": alg * timed / elapsed / 1e9, "peak": 8000.0 * world, "unit": "GB/s",
+                     "frac": alg * timed / elapsed / 1e9 / (8000.0 * world), "traffic": None,
+                     "algorithmic_bytes_per_launch": alg,
+                     "note": "whole-step rate of all ranks incl. halo exchange and all-reduce against N x 8 TB/s; "
+                             "per-kernel figures and counters are in the N=1 line"},
+        "last_stats": [float(v) for v in st], "kernel_path": drv.describe(),
+    }
+    if drv.fallback_reason:
+        out["in_library_rccl_error"] = drv.fallback_reason
+    return out
+
 
 def run(args):
     import torch
     import torch.distributed as dist
-    from pyro_amd import configs, parallel
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -19,84 +154,59 @@ def run(args):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     torch.cuda.set_device(local)
-    # torch.distributed is the launcher-side harness only (rendezvous, the communicator id, barrier and max of the timed
-    # region): the data path -- halo exchange and statistics all-reduce -- is RCCL inside libpyrovi (pvi_shard_*).
-    # PVI_TORCH_COLLECTIVES=1 selects the older Python-driven schedule over torch.distributed's nccl backend.
+    # torch.distributed is the launcher-side harness (rendezvous, the communicator id, barriers, max of the timed region,
+    # all on host tensors over gloo): the data path -- halo exchange and statistics all-reduce -- is RCCL inside libpyrovi
+    # (pvi_shard_*).  The process group also carries an nccl backend for device tensors; it is only ever initialised when
+    # PVI_TORCH_COLLECTIVES=1 selects the Python-driven schedule, or when the in-library communicator fails to start.
     via_torch = bool(int(os.environ.get("PVI_TORCH_COLLECTIVES", "0")))
-    if via_torch:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    else:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    name = args.workload or "c4"
+    dist.init_process_group("cpu:gloo,cuda:nccl" if world > 1 else "gloo", rank=rank, world_size=world)
     steps = args.steps if args.steps is not None else 20
     warmup = args.warmup if args.warmup is not None else 2
-    with contextlib.redirect_stdout(io.StringIO()):
-        cfg = configs.build(name)
-    g = cfg["grid_sys"]
-    N, A = g.nodes_n, g.actions_n
-    w = 4 if cfg["dtype"] == "float32" else 8
+    headline = args.workload or "c3w"
+    out = None
 
-    # single-GPU reference of the SAME workload on rank 0 (strong-scaling denominator)
-    one_gpu = None
-    if rank == 0 and not args.no_cpu:
-        from pyro_amd.planning import dynamicprogramming
-        with contextlib.redirect_stdout(io.StringIO()):
-            dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, cfg["cf"], dtype=cfg["dtype"], device=local)
-        p = dp._p
-        p.sweep(2, 1.0, -1.0)
-        p.synchronize()
+    def one(name, steps, warmup, ref_sweeps):
+        cfg = _quiet_build(name, world=world)
+        ref = None
+        if rank == 0 and not args.no_cpu and ref_sweeps:
+            ref_cfg = _quiet_build("c3") if name == "c3w" else cfg      # c3w: per-GPU work = C3
+            ref = _one_gpu_rate(ref_cfg, local, ref_sweeps)
         t0 = time.perf_counter()
-        p.sweep(max(3, steps // 4), 1.0, -1.0)
-        p.synchronize()
-        one_gpu = N * A * max(3, steps // 4) / (time.perf_counter() - t0)
-        p.close()
-        del dp
+        drv = _Driver(cfg, dist, torch, rank, world, local, via_torch)
+        torch.cuda.synchronize()
+        setup_s = time.perf_counter() - t0
+        elapsed, batches, st = _timed(drv, dist, torch, steps, warmup)
+        frag = _fragment(cfg, drv, world, steps, warmup, elapsed, batches, st, setup_s)
+        drv.close()
+        return frag, ref
 
-    if via_torch:
-        vi = parallel.ShardedValueIteration(g, cfg["cf"], dist, dtype=cfg["dtype"], device=local)
-        run = lambda n: vi.run(n, 1.0, -1.0)
-        halo, p2p, overlap, describe = vi.halo, vi.p2p, vi.overlap, vi.slab.describe
-    else:
-        from pyro_amd import _native
-        ids = [_native.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        vi = parallel.RcclValueIteration(g, cfg["cf"], rank, world, comm_id=ids[0], dtype=cfg["dtype"], device=local)
-        run = lambda n: list(vi.run(n, 1.0, -1.0)[0])
-        desc = vi.describe()
-        halo, p2p, overlap, describe = vi.halo, "send/recv" in desc, "+overlap" in desc, vi.describe
-    if warmup:
-        run(warmup)
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    st = run(steps)                        # fixed sweep count: statistics of the last sweep only
-    torch.cuda.synchronize()               # (pvi_shard_sweep has synchronised its own streams already)
-    dist.barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if via_torch else "cpu")
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    frag, ref = one(headline, steps, warmup, max(3, steps // 4))
     if rank == 0:
-        pbytes = 1 if A <= 256 else 2
-        alg = N * (2 * w + pbytes)
-        out = {
-            "metric": "vi_state_action_cell_updates_per_sec", "value": N * A * steps / dt, "unit": "cells/s",
-            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32" if w == 4 else "f64", "data": "synthetic",
-            "config": {"workload": "%s: %s" % (cfg["name"], cfg["description"]), "nodes": N, "actions": A,
-                       "cells_per_sweep": N * A, "dt": g.dt, "alpha": 1.0,
-                       "parallelism": "axis-0 slabs x%d, halo %d rows, %s%s, collectives: %s" % (
-                           world, halo, "p2p send/recv" if p2p else "slab broadcast",
-                           ", exchange overlapped with the interior kernel" if overlap else "",
-                           "torch.distributed (nccl)" if via_torch else "RCCL inside libpyrovi (pvi_shard_*)")},
-            "sweeps_per_sec": steps / dt,
-            "roofline": {"bound": "hbm", "achieved": alg * steps / dt / 1e9, "peak": 8000.0 * world, "unit": "GB/s",
-                         "frac": alg * steps / dt / 1e9 / (8000.0 * world), "traffic": None,
-                         "note": "whole-step rate incl. halo exchange; per-kernel figures are in the N=1 line"},
-            "value_1gpu_same_workload": one_gpu,
-            "strong_scaling_speedup": (N * A * steps / dt) / one_gpu if one_gpu else None,
-            "last_stats": [float(v) for v in st], "kernel_path": describe(),
-        }
+        weak = headline == "c3w"
+        out = {"metric": "vi_state_action_cell_updates_per_sec", "value": frag.pop("value"), "unit": frag.pop("unit"),
+               "n_gpus": world, "steps": frag.pop("steps"), "warmup": frag.pop("warmup"),
+               "ms_per_step": frag.pop("ms_per_step"), "higher_is_better": True,
+               "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": frag.pop("dtype"),
+               "data": "synthetic", "config": frag.pop("config")}
+        out.update(frag)
+        if weak:
+            out["value_1gpu_c3"] = ref                # one rank's share of the work, alone on one GPU (N = 1 line)
+        else:
+            out["value_1gpu_same_workload"] = ref
+            out["strong_scaling_speedup"] = out["value"] / ref if ref else None
+    if args.workload is None and not args.no_secondary:
+        # BASELINE configs[3] over the same ranks: strong scaling
+        try:
+            frag, ref = one("c4", max(5, steps // 2), 2, 3)
+            if rank == 0:
+                frag["scaling"] = "strong"
+                frag["value_1gpu_same_workload"] = ref
+                frag["strong_scaling_speedup"] = frag["value"] / ref if ref else None
+                out["secondary"] = {"c4": frag}
+        except Exception as e:                            # noqa: BLE001 -- a secondary line must not take the headline down
+            if rank == 0:
+                out["secondary"] = {"c4": {"error": "%s: %s" % (type(e).__name__, e)}}
+    if rank == 0:
         print(json.dumps(out))
+    _barrier(dist, torch)
     dist.destroy_process_group()
