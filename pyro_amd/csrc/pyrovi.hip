@@ -2726,23 +2726,61 @@ static int lean_setup(pvi_problem* h) {
         HIPCHK(hipMemsetAsync(h->pi, 0, (size_t)h->owned * h->pi_size, h->stream));
         HIPCHK(hipMemsetAsync(h->J[h->cur ^ 1], 0, (size_t)h->stored * (h->d.dtype == PVI_F64 ? 8 : 4), h->stream));
     }
-    for (int k = 0; k < ns; ++k) {
-        rc = lean_try(h, shapes[k][0] * L.npt, shapes[k][1], budget);
-        if (rc < 0) return rc;
-        if (rc == 2) break;
-        if (rc == 0) {
-            const int threads = L.npt > 1 ? L.half : ((L.TV0 * L.TV1) << L.lsplit);
-            h->lean_block = ((threads + 63) / 64) * 64;
-            if (h->lean_block > (L.npt > 1 ? 256 : 512)) continue;
-            h->lean_ok = true;
-            h->lean_lds_attr = false;
-            if ((rc = lean_persist_setup(h))) return rc;
-            if (L.tb_tile) {  // tB lives per tile: the per-node copy is not needed any more
-                dev_release(h, L.tB);
-                L.tB = nullptr;
+    // first candidate shape that fits the LDS budget (rc: 0 taken / lean_ok set, < 0 error)
+    auto take_shape = [&]() -> int {
+        for (int k = 0; k < ns; ++k) {
+            int r = lean_try(h, shapes[k][0] * L.npt, shapes[k][1], budget);
+            if (r < 0) return r;
+            if (r == 2) break;
+            if (r == 0) {
+                const int threads = L.npt > 1 ? L.half : ((L.TV0 * L.TV1) << L.lsplit);
+                h->lean_block = ((threads + 63) / 64) * 64;
+                if (h->lean_block > (L.npt > 1 ? 256 : 512)) continue;
+                h->lean_ok = true;
+                h->lean_lds_attr = false;
+                return lean_persist_setup(h);
             }
-            break;
         }
+        return 0;
+    };
+    // 2-D grids walked uniformly: one or two nodes per thread?  Two halve the waves (dispatch, per-wave set-up, one
+    // round of resident waves instead of two) but leave less to overlap; which wins depends on the action count
+    // (2001^2 x 21: 67.7 -> 59.1 us with two, 1001^2 x 51: 35.4 -> 37.5 us), so both run a few timed sweeps here and
+    // the faster stays.  Results do not depend on it (same arithmetic per node).  PVI_NPT fixes it, PVI_TUNE=0 keeps 1.
+    if (DOF == 1 && ls == 0 && !getenv("PVI_NPT") && h->owned >= (1 << 17) && !(getenv("PVI_TUNE") && !atoi(getenv("PVI_TUNE")))) {
+        // (clocks ramp up during the first sweeps after a create: the candidates alternate, two rounds of 40 timed
+        //  sweeps behind 20 untimed ones each, and a candidate is judged by its faster round)
+        float best_of[3] = {0.f, 1e30f, 1e30f};
+        for (int round = 0; round < 2; ++round)
+            for (int cand = 1; cand <= 2; ++cand) {
+                L.npt = cand;
+                h->lean_ok = false;
+                if ((rc = take_shape()) < 0) return rc;
+                if (!h->lean_ok) continue;
+                float ms = 0.f;
+                for (int rep = 0; rep < 60 && rc == 0; ++rep) {
+                    if (rep == 20) HIPCHK(hipEventRecord(h->ev0, h->stream));
+                    hipLaunchKernelGGL(k_reset_stats, 1, STAT_WORDS, 0, h->stream, h->slots, STAT_WORDS);
+                    hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, h->stream, h->ctrl);
+                    rc = launch_sweep(h, h->cur, 1.0, h->stream, 0, -1.0);
+                }
+                h->lean_ok = false;
+                if (rc) return rc;
+                HIPCHK(hipEventRecord(h->ev1, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+                best_of[cand] = std::min(best_of[cand], ms);
+            }
+        const int best_npt = best_of[2] < 0.98f * best_of[1] ? 2 : 1;  // two nodes per thread must win by 2 %
+        L.npt = best_npt;
+        HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream));
+        HIPCHK(hipMemsetAsync(h->pi, 0, (size_t)h->owned * h->pi_size, h->stream));
+        HIPCHK(hipMemsetAsync(h->J[h->cur ^ 1], 0, (size_t)h->stored * (h->d.dtype == PVI_F64 ? 8 : 4), h->stream));
+    }
+    if ((rc = take_shape()) < 0) return rc;
+    if (h->lean_ok && L.tb_tile) {  // tB lives per tile: the per-node copy is not needed any more
+        dev_release(h, L.tB);
+        L.tB = nullptr;
     }
     // float32 accuracy guard: the displacement rel = ta + sum tB u is formed from float32 copies of ta and tB.  When
     // those operands are hundreds of cells and cancel (light links with strong actuators: the default two-link arm has
@@ -3206,11 +3244,11 @@ extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
                  (int)((unsigned long long)h->stored * 8ull < (1ull << 32)));
         return PVI_OK;
     }
-    snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d wgs=%u wpc=%d nbuf=%d reach=%d opmag=%d note=%s",
+    snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d wgs=%u wpc=%d nbuf=%d npt=%d reach=%d opmag=%d note=%s",
              path, h->LP.TV0, h->LP.TV1, h->lean_grid.x, h->lean_grid.y, h->lean_grid.z, h->lean_block, h->lean_pw1,
              h->lean_lds, h->lean_ok ? h->LP.lsplit : h->F.lsplit, h->LP.tb_tile, h->lean_ok ? h->LP.dma16 : 0,
              (h->lean_ok && h->lean_persist) ? h->lean_pgrid : 0u, (h->lean_ok && h->lean_persist) ? h->lean_wpc : 0,
-             (h->lean_ok && h->lean_persist) ? h->LP.nbuf : 0, h->lean_reach, h->lean_opmag, h->lean_why);
+             (h->lean_ok && h->lean_persist) ? h->LP.nbuf : 0, h->lean_ok ? h->LP.npt : 1, h->lean_reach, h->lean_opmag, h->lean_why);
     return PVI_OK;
 }
 

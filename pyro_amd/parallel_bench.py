@@ -154,6 +154,11 @@ def run(args):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     torch.cuda.set_device(local)
+    # gloo and RCCL print banners on stdout from C: the ONE JSON line goes to the real stdout, everything else to stderr
+    import sys
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     # torch.distributed is the launcher-side harness (rendezvous, the communicator id, barriers, max of the timed region,
     # all on host tensors over gloo): the data path -- halo exchange and statistics all-reduce -- is RCCL inside libpyrovi
     # (pvi_shard_*).  The process group also carries an nccl backend for device tensors; it is only ever initialised when
@@ -207,6 +212,6 @@ def run(args):
             if rank == 0:
                 out["secondary"] = {"c4": {"error": "%s: %s" % (type(e).__name__, e)}}
     if rank == 0:
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     _barrier(dist, torch)
     dist.destroy_process_group()

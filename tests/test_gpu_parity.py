@@ -374,9 +374,10 @@ def test_f32_kernel_variants_agree(name, monkeypatch):
                      ("lean_persist", {"PVI_LSPLIT": "0", "PVI_PERSIST": "1"}),
                      ("lean_1buf", {"PVI_LSPLIT": "0", "PVI_PERSIST": "1", "PVI_NBUF": "1", "PVI_WPC": "1"}),
                      ("lean_allnear", {"PVI_LSPLIT": "0", "PVI_DBG": "128"}),
+                     ("lean_npt2", {"PVI_LSPLIT": "0", "PVI_NPT": "2"}), ("lean_npt4", {"PVI_LSPLIT": "0", "PVI_NPT": "4"}),
                      ("tile", {"PVI_NO_LEAN": "1", "PVI_TILE": "1"}), ("fast", {"PVI_NO_LEAN": "1"}),
                      ("exact32", {"PVI_NO_FAST": "1"})]:
-        for k in ("PVI_LSPLIT", "PVI_NO_LEAN", "PVI_TILE", "PVI_NO_FAST", "PVI_PERSIST", "PVI_NBUF", "PVI_WPC", "PVI_DBG"):
+        for k in ("PVI_LSPLIT", "PVI_NO_LEAN", "PVI_TILE", "PVI_NO_FAST", "PVI_PERSIST", "PVI_NBUF", "PVI_WPC", "PVI_DBG", "PVI_NPT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -409,6 +410,10 @@ def test_f32_kernel_variants_agree(name, monkeypatch):
         # pass on EVERY node with an action inside the guard band (round 1): the same J and pi, bit for bit
         assert np.array_equal(outs["lean_allnear"][0], outs["lean_nosplit"][0])
         assert np.array_equal(outs["lean_allnear"][1], outs["lean_nosplit"][1])
+        # several nodes per thread (2-D grids; bands of the tile walked one after the other): the same arithmetic per node
+        for tag, npt in (("lean_npt2", 2), ("lean_npt4", 4)):
+            assert ("npt=%d" % (npt if len(p.levels) == 2 else 1)) in outs[tag][2], outs[tag][2]
+            assert np.array_equal(outs[tag][0], outs["lean_nosplit"][0]) and np.array_equal(outs[tag][1], outs["lean_nosplit"][1])
         assert path_of(outs["tile"][2]) == "path=tile" and path_of(outs["fast"][2]) == "path=fast"
     assert path_of(outs["exact32"][2]) == "path=exact-f32"
 
