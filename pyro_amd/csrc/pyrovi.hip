@@ -84,6 +84,7 @@ struct SweepCtl {
     int k;                     // sweep index inside the batch
     unsigned nblocks;
     int split_finish;          // 1: the statistics are folded by k_sweep_finish after the sweep kernel (large grids)
+    int xcd_remap;             // k_sweep64: contiguous logical block ranges per XCD
 };
 
 // order-preserving encoding of doubles for integer atomicMax
@@ -857,18 +858,27 @@ __device__ __forceinline__ int interval_frac64(const double2* __restrict__ tab, 
 //     is only needed where x_next lands inside the box, but a wave pays for it as soon as ONE of its lanes does; for an
 //     action the in-box nodes form a rectangle of the velocity plane, which a compact patch meets far less often than
 //     a 64-node line does (two-link 101^4 x 121: 7 % of the cells are in the box, ~40 % of the (line, action) pairs hit it).
-template <int DYN, typename PI_T, bool OFF32, bool PATCH>
+//   * SPARSE (4-D, A <= 128): which cells land in the box does not change from sweep to sweep, so it is decided once at
+//     set-up (k_valid_mask: the same float64 expressions) and kept as a 128-bit mask per node.  A lane then walks the
+//     set bits of ITS mask -- the action constants come from an LDS copy of the table instead of a scalar load -- and
+//     the cells outside the box, whose Q is INF + alpha*0 = INF exactly, enter the argmin as one candidate (INF, first
+//     clear bit).  A wave runs as many trips as its busiest lane has cells in the box instead of A (two-link 101^4 x
+//     121: 7 % of the cells are in the box).
+template <int DYN, typename PI_T, bool OFF32, bool PATCH, bool SPARSE = false>
 __global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restrict__ Jin, double* __restrict__ Jout,
                                                  PI_T* __restrict__ pi, double alpha, SweepCtl sc,
-                                                 const Act64* __restrict__ act64, const double2* __restrict__ levr) {
+                                                 const Act64* __restrict__ act64, const double2* __restrict__ levr,
+                                                 const uint4* __restrict__ vmask) {
     using D = Dyn<DYN>;
     constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M;
     static_assert(!PATCH || DOF == 2, "patches tile the velocity plane of 4-D grids");
+    static_assert(!SPARSE || DOF == 2, "validity masks are kept for 4-D grids");
     typedef typename JOff<OFF32>::T off_t;
     typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
     if (sc.ctrl->done) return;
     extern __shared__ __attribute__((aligned(16))) double2 lr_lds[];
     const double2* tab[N];
+    const double2* act_lds = nullptr;  // SPARSE: {u0, u1}, {gu, aok} per action behind the level tables
     {
         int at = 0;
 #pragma unroll
@@ -877,15 +887,29 @@ __global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restric
             tab[d] = lr_lds + at;
             at += P.dim[d];
         }
+        if constexpr (SPARSE) {
+            const double2* src = (const double2*)act64;
+            for (int i = threadIdx.x; i < 2 * P.A; i += blockDim.x) lr_lds[at + i] = src[i];
+            act_lds = lr_lds + at;
+        }
         __syncthreads();
     }
-    long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // Workgroups go round-robin over the 8 XCDs, each with its own L2.  The gathers of a node land on the position rows
+    // next to its own, anywhere in their velocity planes: neighbours in (i0, i1) share those planes, so every XCD gets
+    // a CONTIGUOUS range of logical blocks (physical block b = 8 j + x  ->  logical x * chunk + j) and a plane is fetched
+    // into one L2 instead of eight.  (Placement only; sc.xcd_remap = 0 keeps the identity.)
+    unsigned lb = blockIdx.x;
+    if (sc.xcd_remap) {
+        const unsigned nb = gridDim.x, xq = nb >> 3, xr = nb & 7u, xx = lb & 7u, jj = lb >> 3;
+        lb = (xx < xr ? xx * (xq + 1u) : xr * (xq + 1u) + (xx - xr) * xq) + jj;
+    }
+    long long o = (long long)lb * blockDim.x + threadIdx.x;
     const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
     bool live = o < owned;
     int idx[N];
     if constexpr (PATCH) {
         const int np2 = (P.dim[2] + 7) >> 3, np3 = (P.dim[3] + 7) >> 3;
-        const long long wid = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave-uniform
+        const long long wid = (long long)lb * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave-uniform
         const long long pl = wid / (np2 * np3);  // position node (owned rows x dim[1])
         const int rem = (int)(wid - pl * (np2 * np3)), p2 = rem / np3, p3 = rem - p2 * np3, lane = threadIdx.x & 63;
         const long long row = pl / P.dim[1];
@@ -990,6 +1014,89 @@ __global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restric
                     }
                 }
             }
+            if constexpr (SPARSE) {
+                const uint4 mk = vmask[o];
+                const unsigned w[4] = {mk.x, mk.y, mk.z, mk.w};
+                int first_out = -1;  // lowest action whose cell leaves the box (lowest clear bit below A)
+#pragma unroll
+                for (int k = 3; k >= 0; --k) {
+                    const unsigned z = ~w[k];
+                    const int i = 32 * k + __ffs((int)z) - 1;
+                    if (z && i < P.A) first_out = i;
+                }
+                bool have = false;
+                // every lane walks its own set bits: the lanes of a wave are at different actions, so the action constants
+                // come from LDS and the gathers of a wave do not coalesce.  (Measured and dropped: the wave walking the
+                // UNION of its lanes' masks with scalar constants and coalesced gathers -- the lanes of a wave have nearly
+                // disjoint in-box actions on the two-link arm, the union is most of A: 23.2 against 19.2 ms on 101^4.)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    unsigned m = w[k];
+                    while (m != 0u) {  // (divergent: a wave leaves when its busiest lane is done)
+                        // two cells per trip, staged (both x_next, the four intervals, the 16 gathers, the two sums): the
+                        // gathers are scattered, their latency is what the loop waits for
+                        int av[2];
+                        av[0] = 32 * k + __ffs((int)m) - 1;
+                        m &= m - 1u;
+                        const bool two = m != 0u;
+                        av[1] = two ? 32 * k + __ffs((int)m) - 1 : av[0];
+                        m &= m - 1u;  // (0 & anything = 0)
+                        double2 ag[2];
+                        double yv[2][DOF];
+                        off_t b[2];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const double2 au = act_lds[2 * av[t]];
+                            ag[t] = act_lds[2 * av[t] + 1];
+                            double u[2] = {au.x, au.y}, acc[DOF];
+                            dyn.accel(u, acc);
+                            b[t] = base;
+#pragma unroll
+                            for (int i = 0; i < DOF; ++i) {
+                                const int d = DOF + i;
+                                const double xn = acc[i] * P.dt + x[d];  // in the box: that is what the mask bit says
+                                const int c = interval_frac64(tab[d], P.dim[d], P.glo[d], P.inv_step[d], xn, yv[t][i]);
+                                b[t] += (off_t)c * vs[i];
+                            }
+                        }
+                        d2u r[2][8];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int pr = 0; pr < 8; ++pr) {
+                                const int c0 = pr >> 2, c1 = (pr >> 1) & 1, c2 = pr & 1;
+                                const off_t off = b[t] + (c0 ? s0 : (off_t)0) + (c1 ? s1 : (off_t)0) + (c2 ? vs[0] : (off_t)0);
+                                r[t][pr] = *(const d2u*)j_at<OFF32>(Jin, off);
+                            }
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            double Jn = 0.0;
+                            const double b2[2] = {1.0 - yv[t][0], yv[t][0]}, b3[2] = {1.0 - yv[t][1], yv[t][1]};
+#pragma unroll
+                            for (int pr = 0; pr < 8; ++pr) {
+                                const int c0 = pr >> 2, c1 = (pr >> 1) & 1, c2 = pr & 1;
+                                const double wgt = wp[c0 * 2 + c1] * b2[c2];
+                                Jn = Jn + r[t][pr].x * (wgt * b3[0]);
+                                Jn = Jn + r[t][pr].y * (wgt * b3[1]);
+                            }
+                            const double g = on_target ? 0.0 : (gx + ag[t].x);
+                            const double G = (ag[t].y != 0.0) ? g * P.dt : P.INF;
+                            const double q = G + alpha * Jn;
+                            if ((t == 0 || two) && (!have || q < best)) {
+                                best = q;
+                                arg = av[t];
+                                have = true;
+                            }
+                        }
+                    }
+                }
+                // the cells outside the box: Q = INF + alpha * 0 = INF, first at action first_out
+                if (first_out >= 0 && (!have || P.INF < best || (P.INF == best && first_out < arg))) {
+                    best = P.INF;
+                    arg = first_out;
+                }
+                a_first = P.A;
+            }
             for (int a = a_first; a < P.A; ++a) {
                 const Act64 ac = act64[a];  // wave-uniform: one scalar load
                 double u[2] = {ac.u0, ac.u1}, acc[DOF], xnv[DOF];
@@ -1047,6 +1154,64 @@ __global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restric
     }
     block_stats(st_j, st_dmax, st_ndmin, sc.slot);
     sweep_finish(sc);
+}
+
+// Validity masks of the SPARSE float64 sweep: bit a of a node's 128-bit word is set when the position row and the cell of
+// action a land inside the box -- the float64 expressions of k_sweep64, evaluated once.  count[0] += cells in the box.
+template <int DYN>
+__global__ __launch_bounds__(256) void k_valid_mask(DevP P, const Act64* __restrict__ act64, uint4* __restrict__ vmask,
+                                                    unsigned long long* __restrict__ count) {
+    using D = Dyn<DYN>;
+    constexpr int DOF = D::DOF, N = 2 * DOF;
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    int nin = 0;
+    if (o < owned) {
+        int idx[N];
+        decode_node<N>(P, o, idx);
+        double x[N];
+#pragma unroll
+        for (int d = 0; d < N; ++d) x[d] = P.lev[d][idx[d]];
+        bool pos_in = true;
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) {
+            const double xn = x[DOF + i] * P.dt + x[i];
+            pos_in = pos_in && !(xn < P.glo[i]) && !(xn > P.ghi[i]);
+        }
+        if (pos_in) {
+            double tr[8];
+            D::trig_from_tables(P, idx, tr);
+            D dyn;
+            dyn.init(P.c, x, tr);
+            for (int a = 0; a < P.A; ++a) {
+                const Act64 ac = act64[a];
+                double u[2] = {ac.u0, ac.u1}, acc[DOF];
+                dyn.accel(u, acc);
+                bool inb = true;
+#pragma unroll
+                for (int i = 0; i < DOF; ++i) {
+                    const int d = DOF + i;
+                    const double xn = acc[i] * P.dt + x[d];
+                    inb = inb && !(xn < P.glo[d]) && !(xn > P.ghi[d]);
+                }
+                if (inb) {
+                    ++nin;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if ((a >> 5) == k) w[k] |= 1u << (a & 31);
+                }
+            }
+        }
+        vmask[o] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    // block total -> one atomic
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    if (nin) atomicAdd(&s_n, nin);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) atomicAdd(count, (unsigned long long)s_n);
 }
 
 // =================================================================================================
@@ -2404,6 +2569,9 @@ struct pvi_problem {
     const double2* levr = nullptr;
     bool force_exact = false; // pvi_self_check: route the next launch to the plain-gather kernel k_sweep
     bool use64 = false;
+    const uint4* vmask = nullptr;  // SPARSE float64 sweep: 128 validity bits per owned node (k_valid_mask)
+    int sparse64 = 0;         // 1: every lane walks the set bits of its validity mask instead of all A actions
+    double infrac64 = -1.0;   // share of the (node, action) cells that land in the box (4-D float64 handles)
     int patch64 = -1;         // 4-D wave mapping of k_sweep64: 1 = 8 x 8 velocity patches, 0 = consecutive nodes (timed at set-up)
     size_t levr_bytes = 0;
     SplineP SP;               // bicubic-spline interpolation mode (sweep_spline.inc)
@@ -3171,18 +3339,65 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
     HCHK(hipStreamSynchronize(h->stream));
 #undef HCHK
     if ((rc = lean_setup(h))) return bail(rc);
+    if (h->use64 && d->n == 4 && A <= 128 && h->levr_bytes + (size_t)A * sizeof(Act64) <= 48 * 1024 &&
+        !(getenv("PVI_SPARSE") && !atoi(getenv("PVI_SPARSE")))) {
+        // SPARSE float64 sweep: validity of every (node, action) cell, once (it does not change between sweeps); kept
+        // where fewer than half of the cells land in the box (PVI_SPARSE=1 keeps it regardless, =0 never builds it)
+        rc = [&]() -> int {
+            uint4* vm = nullptr;
+            unsigned long long* cnt = nullptr;
+            int r;
+            if ((r = dev_alloc(h, (size_t)h->owned, &vm))) return r;
+            if ((r = dev_alloc(h, 1, &cnt))) return r;
+            HIPCHK(hipMemsetAsync(cnt, 0, sizeof(*cnt), h->stream));
+            const unsigned gm = grid_for(h->owned);
+#define VM(DYN) hipLaunchKernelGGL((k_valid_mask<DYN>), gm, 256, 0, h->stream, h->P, h->act64, vm, cnt)
+            switch (d->dynamics_id) {
+                case PVI_DYN_CARTPOLE: VM(PVI_DYN_CARTPOLE); break;
+                case PVI_DYN_TWOLINK: VM(PVI_DYN_TWOLINK); break;
+                case PVI_DYN_NODE_2x1: VM(PVI_DYN_NODE_2x1); break;
+                default: VM(PVI_DYN_NODE_2x2); break;
+            }
+#undef VM
+            HIPCHK(hipGetLastError());
+            unsigned long long inside = 0;
+            HIPCHK(hipMemcpyAsync(&inside, cnt, sizeof(inside), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            dev_release(h, cnt);
+            h->infrac64 = (double)inside / ((double)h->owned * (double)A);
+            const bool forced = getenv("PVI_SPARSE") && atoi(getenv("PVI_SPARSE"));
+            if (h->infrac64 < 0.5 || forced) {
+                h->vmask = vm;
+                h->sparse64 = 1;
+            } else {
+                dev_release(h, vm);
+            }
+            return PVI_OK;
+        }();
+        if (rc) return bail(rc);
+    }
     if (h->use64 && d->n == 4) {
         // Wave mapping of the float64 sweep on 4-D grids, timed like the float32 tile shapes: patches win where few
         // cells land in the box (two-link 101^4 x 121: 33.0 -> 22.5 ms), lines where most do and the velocity plane does
         // not divide by 8 (cart-pole 51^4: 0.77 against 0.88 ms).  One warm-up and one timed sweep per mapping; the
         // results do not depend on it.  PVI_PATCH=0 / 1 pins it.
-        if (const char* e = getenv("PVI_PATCH")) {
-            h->patch64 = atoi(e) ? 1 : 0;
+        // The SPARSE walk (validity masks) is timed the same way where the masks were built: it wins where the loop is
+        // bound by instruction issue (two-link 41^4: 0.89 -> 0.48 ms) and loses where the gathers of the in-box cells
+        // wait for HBM anyway (two-link 101^4: 22.7 -> 24.4 ms).  PVI_SPARSE=1 pins it on.
+        const bool sparse_forced = getenv("PVI_SPARSE") && atoi(getenv("PVI_SPARSE"));
+        if (getenv("PVI_PATCH") && (sparse_forced || !h->sparse64)) {
+            h->patch64 = atoi(getenv("PVI_PATCH")) ? 1 : 0;
         } else {
             float best_ms = 1e30f;
-            int best = 1;
-            for (int pm = 0; pm < 2; ++pm) {
+            int best = 1, best_sp = h->sparse64;
+            const bool have_mask = h->sparse64 != 0;
+            for (int cand = 0; cand < 4; ++cand) {
+                const int pm = cand & 1, sp = cand >> 1;
+                if (sp && !have_mask) continue;
+                if (sparse_forced && sp != best_sp) continue;
+                if (getenv("PVI_PATCH") && pm != (atoi(getenv("PVI_PATCH")) ? 1 : 0)) continue;
                 h->patch64 = pm;
+                h->sparse64 = sp;
                 float ms = 0.f;
                 rc = [&]() -> int {
                     for (int rep = 0; rep < 2; ++rep) {
@@ -3201,7 +3416,13 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
                 if (ms < best_ms) {
                     best_ms = ms;
                     best = pm;
+                    best_sp = sp;
                 }
+            }
+            h->sparse64 = best_sp;
+            if (have_mask && !h->sparse64) {  // the dense walk stays: the masks are not needed
+                dev_release(h, (void*)h->vmask);
+                h->vmask = nullptr;
             }
             h->patch64 = best;
             rc = [&]() -> int {  // the timed sweeps wrote into the second J buffer, pi and the control block
@@ -3240,8 +3461,9 @@ extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
                        : (h->fast_ok && !is_node_dyn(h->d.dynamics_id)) ? "fast"
                        : (h->d.dynamics_id == PVI_DYN_TABLE ? (h->packed ? "table-packed" : "table") : "exact-f32");
     if (h->d.dtype == PVI_F64 && h->use64 && h->d.dynamics_id != PVI_DYN_TABLE) {
-        snprintf(buf, (size_t)n, "path=exact-f64v2 mapping=%s off32=%d note=", h->P.n == 4 ? (h->patch64 ? "patch8x8" : "line64") : "line64",
-                 (int)((unsigned long long)h->stored * 8ull < (1ull << 32)));
+        snprintf(buf, (size_t)n, "path=exact-f64v2 mapping=%s off32=%d sparse=%d inbox=%.4f note=",
+                 h->P.n == 4 ? (h->patch64 ? "patch8x8" : "line64") : "line64",
+                 (int)((unsigned long long)h->stored * 8ull < (1ull << 32)), h->sparse64, h->infrac64);
         return PVI_OK;
     }
     snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d wgs=%u wpc=%d nbuf=%d npt=%d reach=%d opmag=%d note=%s",
@@ -3566,13 +3788,26 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
                 gp = (unsigned)((waves + 3) / 4);
                 sc.nblocks = gp;
             }
-#define S64P(DYN, PT)                                                                                                 \
+            const int sparse = h->sparse64;
+            sc.xcd_remap = (gp >= 64u && !(getenv("PVI_XCD64") && !atoi(getenv("PVI_XCD64")))) ? 1 : 0;
+            const size_t lds64 = h->levr_bytes + (sparse == 1 ? (size_t)h->P.A * sizeof(Act64) : 0);
+#define S64Q(DYN, PT, SP)                                                                                             \
     if (off32)                                                                                                        \
-        hipLaunchKernelGGL((k_sweep64<DYN, PI_T, true, PT>), gp, 256, h->levr_bytes, st, h->P, Jin, Jout, pi, alpha,  \
-                           sc, h->act64, h->levr);                                                                    \
+        hipLaunchKernelGGL((k_sweep64<DYN, PI_T, true, PT, SP>), gp, 256, lds64, st, h->P, Jin, Jout, pi, alpha, sc,  \
+                           h->act64, h->levr, h->vmask);                                                              \
     else                                                                                                              \
-        hipLaunchKernelGGL((k_sweep64<DYN, PI_T, false, PT>), gp, 256, h->levr_bytes, st, h->P, Jin, Jout, pi, alpha, \
-                           sc, h->act64, h->levr);
+        hipLaunchKernelGGL((k_sweep64<DYN, PI_T, false, PT, SP>), gp, 256, lds64, st, h->P, Jin, Jout, pi, alpha, sc, \
+                           h->act64, h->levr, h->vmask);
+#define S64P(DYN, PT)                              \
+    if constexpr (Dyn<DYN>::DOF == 2) {            \
+        if (sparse) {                              \
+            S64Q(DYN, PT, true)                    \
+        } else {                                   \
+            S64Q(DYN, PT, false)                   \
+        }                                          \
+    } else {                                       \
+        S64Q(DYN, PT, false)                       \
+    }
 #define S64(DYN)                                   \
     if constexpr (Dyn<DYN>::DOF == 2) {            \
         if (patch) {                               \
@@ -3593,6 +3828,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             }
 #undef S64
 #undef S64P
+#undef S64Q
             HIPCHK(hipGetLastError());
             return PVI_OK;
         }
@@ -3683,6 +3919,7 @@ static int launch_sweep(pvi_problem* h, int src, double alpha, hipStream_t st, i
     sc.k = k;
     sc.nblocks = 0;
     sc.split_finish = 0;
+    sc.xcd_remap = 0;
     if (h->d.dtype == PVI_F64)
         return h->pi_size == 1 ? launch_sweep_t<double, unsigned char>(h, src, alpha, st, sc)
                                : launch_sweep_t<double, unsigned short>(h, src, alpha, st, sc);

@@ -433,15 +433,23 @@ def test_f64_second_form_is_bit_identical(name, monkeypatch):
         alpha = float(g["alpha"]) if "alpha" in g.files else 1.0
         nsw = 6
     outs = {}
-    for tag, env in (("v1", {"PVI_NO_SWEEP64": "1"}), ("v2", {"PVI_PATCH": "1"}), ("v2line", {"PVI_PATCH": "0"}), ("v2auto", {})):
-        monkeypatch.delenv("PVI_NO_SWEEP64", raising=False)
-        monkeypatch.delenv("PVI_PATCH", raising=False)
+    # (4-D grids: "sparse" walks a per-node validity mask built at set-up instead of all A actions -- forced on and off
+    #  here, chosen by the share of cells in the box otherwise)
+    for tag, env in (("v1", {"PVI_NO_SWEEP64": "1"}), ("v2", {"PVI_PATCH": "1", "PVI_SPARSE": "0"}),
+                     ("v2line", {"PVI_PATCH": "0", "PVI_SPARSE": "0"}), ("v2sparse", {"PVI_PATCH": "1", "PVI_SPARSE": "1"}),
+                     ("v2sparseline", {"PVI_PATCH": "0", "PVI_SPARSE": "1"}), ("v2auto", {})):
+        for k in ("PVI_NO_SWEEP64", "PVI_PATCH", "PVI_SPARSE"):
+            monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         h = native_problem(p)
         assert h.describe().split()[0] == ("path=exact-f64" if tag == "v1" else "path=exact-f64v2")
         if p.n == 4 and tag in ("v2", "v2line"):
             assert ("mapping=patch8x8" if tag == "v2" else "mapping=line64") in h.describe()
+        if tag.startswith(("v2sparse", "v2union")):
+            A = int(np.prod([len(u) for u in p.u_levels]))
+            want = env["PVI_SPARSE"] if (p.n == 4 and A <= 128) else "0"
+            assert ("sparse=" + want) in h.describe(), h.describe()
         h.terminal_cost()
         stats, n = h.sweep(nsw, alpha, -1.0)
         outs[tag] = (h.get_J(), h.get_pi(), stats.copy())
@@ -455,9 +463,9 @@ def test_f64_second_form_is_bit_identical(name, monkeypatch):
         hs.sweep_stats()
         outs[tag + "_slab"] = (hs.get_J(), hs.get_pi())
         hs.close()
-    monkeypatch.delenv("PVI_NO_SWEEP64", raising=False)
-    monkeypatch.delenv("PVI_PATCH", raising=False)
-    for b in ("v2", "v2line", "v2auto"):
+    for k in ("PVI_NO_SWEEP64", "PVI_PATCH", "PVI_SPARSE"):
+        monkeypatch.delenv(k, raising=False)
+    for b in ("v2", "v2line", "v2sparse", "v2sparseline", "v2auto"):
         for a, c in (("v1", b), ("v1_slab", b + "_slab")):
             assert np.array_equal(outs[a][0], outs[c][0]) and np.array_equal(outs[a][1], outs[c][1]), (name, c)
         assert np.array_equal(outs["v1"][2], outs[b][2])
@@ -492,6 +500,47 @@ def test_full_size_c2_against_c_oracle():
         assert relerr(Jg, J) <= tol
         assert (pig != pi).mean() < (1e-9 if dtype == "float64" else 5e-3)
         assert abs(stats[-1, 0] - J.max()) <= 1e-5 * J.max()
+        h.close()
+
+
+def test_full_size_north_star_grid_against_c_oracle():
+    """The north-star grid of BASELINE.json (C2': 201 x 201 nodes x 201 actions, swing-up demo bounds and weights): the
+    float32 path there is the ACTION-SPLIT lean kernel (several lanes per node, cross-lane argmin with the first-minimum
+    rule), float64 the second-form exact kernel.  Whole grid, 1, 3 and 200 sweeps against the oracle's C twin."""
+    from oracle import c_oracle as CO
+    from pyro_amd import configs
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg = configs.build("c2p")
+    s, g, cf = cfg["sys"], cfg["grid_sys"], cfg["cf"]
+    dyn_id, params = s.device_dynamics()
+    p = O.Problem(g.x_level, g.u_level, g.dt, dyn_id, np.array(params), cf.Q, cf.R, cf.S, cf.xbar, cf.ubar,
+                  float(cf.INF), float(cf.EPS), x_lb=s.x_lb, x_ub=s.x_ub, u_lb=s.u_lb, u_ub=s.u_ub)
+    c = CO.CProblem(p)
+    ref, J = {}, c.terminal_cost()
+    for k in range(1, 201):
+        J, pi = c.sweep(J)
+        if k in (1, 3, 200):
+            ref[k] = (J.copy(), pi.copy())
+    for dtype, tol in (("float32", REL_F32), ("float64", 1e-12)):
+        h = native_problem(p, dtype=dtype)
+        desc = h.describe()
+        if dtype == "float32":
+            assert desc.startswith("path=lean ") and "lsplit=0" not in desc, desc      # more than one lane per node
+        else:
+            assert desc.startswith("path=exact-f64v2"), desc
+        h.terminal_cost()
+        done = 0
+        for k in (1, 3, 200):
+            h.sweep(k - done, 1.0, -1.0)
+            done = k
+            Jg, pig = h.get_J(), h.get_pi()
+            assert relerr(Jg, ref[k][0]) <= tol, (dtype, k)
+            if dtype == "float64":
+                assert np.array_equal(pig, ref[k][1]), k
+            else:   # float32 rounding flips near-ties: float64 Q-regret of the GPU's action on the GPU's own previous J
+                nodes = np.arange(pig.size, dtype=np.int64)
+                q, qmin = c.q_at(h.get_J(prev=True), nodes, pig.astype(np.int64))
+                assert (q - qmin).max() <= 1e-5 * max(1.0, np.abs(ref[k][0]).max()), (k, (q - qmin).max())
         h.close()
 
 
