@@ -100,15 +100,16 @@ def _timed(drv, dist, torch, steps, warmup):
     """W warm-up sweeps, then batches of exactly K sweeps, each bracketed by barrier + synchronize on both sides and
     reduced with max over the ranks, until the region reaches MIN_REGION_S (every rank takes the same decisions: they
     are made on the all-reduced times)."""
+    sync = torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None)   # (CPU: the gloo test of this harness)
     if warmup:
         drv.run(warmup)
-    torch.cuda.synchronize()
+    sync()
     batches, elapsed, st = 0, 0.0, None
     while batches == 0 or elapsed < MIN_REGION_S:
         _barrier(dist, torch)
         t0 = time.perf_counter()
         st = drv.run(steps)                    # fixed sweep count: statistics (one all-reduce) for the last sweep only
-        torch.cuda.synchronize()               # (pvi_shard_sweep has synchronised its own streams already)
+        sync()                                 # (pvi_shard_sweep has synchronised its own streams already)
         _barrier(dist, torch)
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

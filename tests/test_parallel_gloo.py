@@ -129,3 +129,62 @@ def test_partition_and_halo():
     cfg = _build("cartpole:151,5,5,5:3:float32")
     # C4 halo = ceil(2*pi*0.05 / (4*pi/150)) + 1 = ceil(3.75) + 1 = 5
     assert parallel.halo_rows(cfg["grid_sys"]) == 5
+
+
+def _harness_worker(rank, world, port, out):
+    """bench.py --gpus N harness on CPU: the timed region is max-over-ranks, every rank runs the same number of batches,
+    a failure on ONE rank is seen by all."""
+    import time
+    import torch
+    import torch.distributed as dist
+    from pyro_amd import parallel_bench as PB
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        class Drv:
+            calls = 0
+
+            def run(self, n):
+                Drv.calls += 1
+                time.sleep(0.004 * n * (1 + 2 * rank))          # rank 1 is three times slower
+                return [1.0, 2.0, 3.0, 4.0]
+        drv = Drv()
+        elapsed, batches, st = PB._timed(drv, dist, torch, steps=5, warmup=1)
+        ok_all = PB._agree(dist, torch, True)
+        ok_one = PB._agree(dist, torch, rank != 1)               # rank 1 reports a failure
+        res = [None] * world
+        dist.all_gather_object(res, (elapsed, batches, Drv.calls, ok_all, ok_one))
+        if rank == 0:
+            np.save(out, np.array(res, dtype=float))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_harness_times_the_slowest_rank(tmp_path):
+    import torch.multiprocessing as mp
+    from pyro_amd import parallel_bench as PB
+    out = str(tmp_path / "h.npy")
+    mp.spawn(_harness_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = np.load(out)
+    assert r[0, 0] == r[1, 0] and r[0, 1] == r[1, 1] and r[0, 2] == r[1, 2]     # same region, batches and calls on both ranks
+    assert r[0, 0] >= PB.MIN_REGION_S                                           # batches repeat until the region is long enough
+    assert r[0, 0] >= r[0, 1] * 5 * 0.004 * 3 * 0.9                             # ... and it is the SLOW rank's time
+    assert r[:, 3].all() and not r[:, 4].any()                                  # one failing rank flips the decision everywhere
+
+
+def test_weak_scaling_family_is_c3_per_rank():
+    """bench.py --gpus N: 100 N + 1 rows on a rail N times as long -- C3's spacing, N = 1 is C3, 100-101 rows per rank."""
+    from pyro_amd import parallel
+    c3 = _build("c3")["grid_sys"]
+    from pyro_amd import configs
+    for world in (1, 2, 8):
+        with contextlib.redirect_stdout(io.StringIO()):
+            g = configs.build("c3w", world=world)["grid_sys"]
+        assert list(g.x_grid_dim) == [100 * world + 1, 101, 101, 101] and list(g.u_grid_dim) == [21]
+        np.testing.assert_allclose(g.x_step_size, c3.x_step_size, rtol=1e-14)
+        for ax in (1, 2, 3):
+            assert np.array_equal(g.x_level[ax], c3.x_level[ax])
+        rows = [b - a for a, b in parallel.partition_rows(g.x_grid_dim[0], world)]
+        assert set(rows) <= {100, 101} and parallel.halo_rows(g) == parallel.halo_rows(c3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        g1 = configs.build("c3w", world=1)["grid_sys"]
+    assert all(np.array_equal(a, b) for a, b in zip(g1.x_level, c3.x_level))
