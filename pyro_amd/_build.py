@@ -16,7 +16,10 @@ def sources():
     return sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".inc", ".h"))) + HDR
 OUT = os.path.join(PKG, "libpyrovi.so")
 # -ffp-contract=off: the f64 kernels mirror the reference's NumPy arithmetic (no implicit FMA)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# -fno-slp-vectorize: the pairing pass packs independent scalar float32 steps of the action loops into v_pk_* pairs that
+#   need their halves transposed first (15 register moves per four cells of the 4-D loop); where packed math pays, the
+#   kernels spell it out on 2-vectors themselves
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
 
 
 def hipcc():
@@ -52,7 +55,7 @@ def build_sanitized(force=False, verbose=True):
     under python there.)"""
     if not force and os.path.exists(OUT_SAN) and all(os.path.getmtime(p) <= os.path.getmtime(OUT_SAN) for p in sources()):
         return OUT_SAN
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
            "-fsanitize=undefined,bounds", "-fno-sanitize=vptr,function", "-fno-sanitize-recover=undefined",
            "-fno-gpu-sanitize", "-shared-libsan", "-o", OUT_SAN] + SRC
     if verbose:

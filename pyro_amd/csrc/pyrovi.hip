@@ -2760,6 +2760,9 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
                !(getenv("PVI_DMA16") && !atoi(getenv("PVI_DMA16")))) ? 1 : 0;
     if (L.dma16) {
         rs = (summary[1] + 3) & ~3;
+        // pitch 64 has its own kernel (the next velocity row is an immediate offset of the LDS read): rows a little
+        // shorter are padded to it when the window still fits
+        if (rs > 48 && rs < 64 && (long long)summary[0] * 64 + 128 <= lds_budget_floats && !getenv("PVI_NO_RS64")) rs = 64;
         L.rs_magic = magic32((unsigned)rs);
     }
     // (2-D windows are staged as pairs -- 8 bytes per column, sweep_lean.inc lds_corners -- 4-D windows as single floats)
@@ -3688,9 +3691,10 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             const float al = (float)alpha;
             sc.nblocks = h->lean_grid.x;
             sc.split_finish = (sc.nblocks >= 16384u && !getenv("PVI_NO_SPLIT_FINISH")) ? 1 : 0;
-#define LEAN3(DYN, U, NP)                                                                                           \
+#define LEAN3(DYN, U, NP) LEAN4(DYN, U, NP, 0)
+#define LEAN4(DYN, U, NP, RSK)                                                                                      \
     {                                                                                                               \
-        auto kfn = k_sweep_lean<DYN, PI_T, U, NP>;                                                                  \
+        auto kfn = k_sweep_lean<DYN, PI_T, U, NP, RSK>;                                                                  \
         if (!h->lean_lds_attr && h->lean_lds > 48 * 1024) {                                                         \
             HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PVI_LDS_MAX)); \
             h->lean_lds_attr = true;                                                                                \
@@ -3699,10 +3703,13 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
                            sc);                                                                                     \
         if (sc.split_finish) hipLaunchKernelGGL(k_sweep_finish, 1, STAT_SHARDS, 0, st, sc);                         \
     }
-#define LEAN(DYN)              \
-    if (h->LP.lsplit == 0)     \
-        LEAN3(DYN, true, 1)    \
-    else                       \
+#define LEAN(DYN)                                                  \
+    if (h->LP.lsplit == 0) {                                       \
+        if (Dyn<DYN>::DOF == 2 && h->LP.RS == 64 && !h->LP.dbg)    \
+            LEAN4(DYN, true, 1, 64)                                \
+        else                                                       \
+            LEAN3(DYN, true, 1)                                    \
+    } else                                                         \
         LEAN3(DYN, false, 1)
             switch (h->d.dynamics_id) {
                 case PVI_DYN_PENDULUM:
@@ -3721,6 +3728,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             }
 #undef LEAN
 #undef LEAN3
+#undef LEAN4
             HIPCHK(hipGetLastError());
             return PVI_OK;
         }
