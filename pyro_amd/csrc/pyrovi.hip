@@ -2753,6 +2753,8 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
         if (atoi(e) == 1 && DOF == 2) rs = summary[1] + 1 + (((L.TV1 - summary[1] - 1) % 32 + 32) % 32);
         if (atoi(e) == 2) rs = 32 * ((summary[1] + 31) / 32) + 1;
     }
+    // 2-D pair windows are a few KB: pitches 64 and 128 have their own kernels (row + 1 is an immediate offset of the read)
+    if (DOF == 1 && !getenv("PVI_NO_RS64")) rs = rs <= 64 ? 64 : (rs <= 128 ? 128 : rs);
     if (const char* e = getenv("PVI_RS")) rs = std::max(rs, atoi(e));  // experiments: explicit row pitch
     // 16-byte window DMA (4-D; J buffers with slack behind them): rows are packed with a pitch that is a multiple of
     // 4 floats, one instruction then moves 256 consecutive window floats (about four rows).  PVI_DMA16=0: 4-byte DMA.
@@ -3705,15 +3707,21 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     }
 #define LEAN(DYN)                                                  \
     if (h->LP.lsplit == 0) {                                       \
-        if (Dyn<DYN>::DOF == 2 && h->LP.RS == 64 && !h->LP.dbg)    \
+        if (h->LP.RS == 64 && !h->LP.dbg)                          \
             LEAN4(DYN, true, 1, 64)                                \
+        else if (Dyn<DYN>::DOF == 1 && h->LP.RS == 128 && !h->LP.dbg) \
+            LEAN4(DYN, true, 1, 128)                               \
         else                                                       \
             LEAN3(DYN, true, 1)                                    \
     } else                                                         \
         LEAN3(DYN, false, 1)
             switch (h->d.dynamics_id) {
                 case PVI_DYN_PENDULUM:
-                    if (h->LP.npt == 2)
+                    if (h->LP.npt == 2 && h->LP.RS == 64 && !h->LP.dbg)
+                        LEAN4(PVI_DYN_PENDULUM, true, 2, 64)
+                    else if (h->LP.npt == 2 && h->LP.RS == 128 && !h->LP.dbg)
+                        LEAN4(PVI_DYN_PENDULUM, true, 2, 128)
+                    else if (h->LP.npt == 2)
                         LEAN3(PVI_DYN_PENDULUM, true, 2)
                     else if (h->LP.npt == 4)
                         LEAN3(PVI_DYN_PENDULUM, true, 4)
