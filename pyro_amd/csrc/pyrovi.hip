@@ -59,6 +59,7 @@ struct DevP {
     double obs_half[2];
     double obs[PVI_MAX_OBS][4];
     const double* aux;          // [A] per-action constants of the dynamics (PVI_DYN_KINCAR)
+    int all_aok;                // every action passes isavalidinput (the rule for box-bounded systems)
 };
 
 struct Ctrl {
@@ -808,6 +809,9 @@ __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ 
 //     every action of a node -- are formed once per node;
 //   * 32-bit offsets into J while the stored slab is below 2 GiB (scalar base + 32-bit lane offset addressing).
 // =================================================================================================
+#ifndef PVI_T64
+#define PVI_T64 4  // cells per trip of the 2-D float64 loop
+#endif
 struct Act64 {
     double u0, u1, gu, aok;
 };
@@ -841,10 +845,14 @@ __device__ __forceinline__ int interval_frac64(const double2* __restrict__ tab, 
     // the reads of several cells can be in flight together), the search loop only for lanes that still have to move
     double2 e0 = tab[i];
     double l1 = tab[i + 1].x;
-    while ((i > 0 && x < e0.x) || (i < N - 2 && x >= l1)) {
-        i += (i > 0 && x < e0.x) ? -1 : 1;
-        e0 = tab[i];
-        l1 = tab[i + 1].x;
+    // (the branch is on a wave vote: written as a plain per-lane loop, the compiler rotates it so that EVERY cell walks
+    //  through the loop's exec-mask bookkeeping and waits for its LDS reads one at a time)
+    if (__builtin_amdgcn_ballot_w64((i > 0 && x < e0.x) || (i < N - 2 && x >= l1)) != 0ull) {
+        while ((i > 0 && x < e0.x) || (i < N - 2 && x >= l1)) {
+            i += (i > 0 && x < e0.x) ? -1 : 1;
+            e0 = tab[i];
+            l1 = tab[i + 1].x;
+        }
     }
     const double t = x - e0.x, d = l1 - e0.x, r = e0.y;
     const double q = t * r;
@@ -880,17 +888,25 @@ __global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restric
     const double2* tab[N];
     const double2* act_lds = nullptr;  // SPARSE: {u0, u1}, {gu, aok} per action behind the level tables
     {
-        int at = 0;
+        // only the velocity axes' tables are read per action: they go to LDS; the position axes' (a few reads per node)
+        // stay in global memory -- a 1001 x 1001 grid otherwise copies 32 KB into every workgroup and holds five
+        // workgroups per CU
+        int at = 0, al = 0;
 #pragma unroll
         for (int d = 0; d < N; ++d) {
-            for (int i = threadIdx.x; i < P.dim[d]; i += blockDim.x) lr_lds[at + i] = levr[at + i];
-            tab[d] = lr_lds + at;
+            if (d < DOF) {
+                tab[d] = levr + at;
+            } else {
+                for (int i = threadIdx.x; i < P.dim[d]; i += blockDim.x) lr_lds[al + i] = levr[at + i];
+                tab[d] = lr_lds + al;
+                al += P.dim[d];
+            }
             at += P.dim[d];
         }
         if constexpr (SPARSE) {
             const double2* src = (const double2*)act64;
-            for (int i = threadIdx.x; i < 2 * P.A; i += blockDim.x) lr_lds[at + i] = src[i];
-            act_lds = lr_lds + at;
+            for (int i = threadIdx.x; i < 2 * P.A; i += blockDim.x) lr_lds[al + i] = src[i];
+            act_lds = lr_lds + al;
         }
         __syncthreads();
     }
@@ -980,6 +996,82 @@ __global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restric
                 // that the LDS and memory latencies of the second cell overlap those of the first
                 const off_t s0 = (off_t)P.strd[0];
                 const double a0 = 1.0 - y[0];
+                // Every action valid (the rule): ONE float64 select per cell.  interval_frac64 clamps its interval, so a
+                // cell outside the box may run through the interpolation on whatever it finds -- its Q is replaced by
+                // INF (= INF + alpha * 0, what the general trip below forms) by the select that in-box cells need anyway.
+                // Waves with a lane on the target (g = 0 there: one node of the grid, usually) take the general trip.
+                if (P.all_aok && !__any(on_target)) {
+                    // four cells per trip, staged: four x_next, four table reads behind ONE wave vote, eight gathers in
+                    // flight, four sums -- the loop waits for its LDS and L2 round trips, not for the float64 pipe
+                    constexpr int T = PVI_T64;
+                    for (; a_first + T - 1 < P.A; a_first += T) {
+                        double xn[T], gu[T];
+                        bool in[T], any = false;
+#pragma unroll
+                        for (int t = 0; t < T; ++t) {
+                            const Act64 ac = act64[a_first + t];
+                            double u[2] = {ac.u0, ac.u1}, acc[1];
+                            dyn.accel(u, acc);
+                            gu[t] = ac.gu;
+                            xn[t] = acc[0] * P.dt + x[1];
+                            in[t] = !(xn[t] < P.glo[1]) && !(xn[t] > P.ghi[1]);
+                            any = any || in[t];
+                        }
+                        double q[T];
+#pragma unroll
+                        for (int t = 0; t < T; ++t) q[t] = P.INF;
+                        if (any) {
+                            int ci4[T];
+                            double2 e0[T];
+                            double l1[T];
+                            bool mv = false;
+#pragma unroll
+                            for (int t = 0; t < T; ++t) {
+                                const double t0 = floor((xn[t] - P.glo[1]) * P.inv_step[1]);
+                                ci4[t] = (t0 < 0.0) ? 0 : (t0 > (double)(P.dim[1] - 2) ? P.dim[1] - 2 : (int)t0);
+                                e0[t] = tab[1][ci4[t]];
+                                l1[t] = tab[1][ci4[t] + 1].x;
+                            }
+#pragma unroll
+                            for (int t = 0; t < T; ++t)
+                                mv = mv || (ci4[t] > 0 && xn[t] < e0[t].x) || (ci4[t] < P.dim[1] - 2 && xn[t] >= l1[t]);
+                            if (__builtin_amdgcn_ballot_w64(mv) != 0ull) {  // rounding put some x across a level (rare)
+#pragma unroll
+                                for (int t = 0; t < T; ++t)
+                                    while ((ci4[t] > 0 && xn[t] < e0[t].x) || (ci4[t] < P.dim[1] - 2 && xn[t] >= l1[t])) {
+                                        ci4[t] += (ci4[t] > 0 && xn[t] < e0[t].x) ? -1 : 1;
+                                        e0[t] = tab[1][ci4[t]];
+                                        l1[t] = tab[1][ci4[t] + 1].x;
+                                    }
+                            }
+                            d2u r0[T], r1[T];
+#pragma unroll
+                            for (int t = 0; t < T; ++t) {
+                                const off_t bt = base + (off_t)ci4[t];
+                                r0[t] = *(const d2u*)j_at<OFF32>(Jin, bt);
+                                r1[t] = *(const d2u*)j_at<OFF32>(Jin, bt + s0);
+                            }
+#pragma unroll
+                            for (int t = 0; t < T; ++t) {
+                                const double tt = xn[t] - e0[t].x, dd = l1[t] - e0[t].x, rr = e0[t].y;
+                                const double qq = tt * rr;
+                                const double ee = __builtin_fma(-qq, dd, tt);
+                                const double yt = __builtin_fma(ee, rr, qq);
+                                const double c1 = 1.0 - yt;
+                                const double Jt = r0[t].x * a0 * c1 + r0[t].y * a0 * yt + r1[t].x * y[0] * c1 + r1[t].y * y[0] * yt;
+                                const double gt = gx + gu[t];
+                                const double vt = gt * P.dt + alpha * Jt;
+                                q[t] = in[t] ? vt : P.INF;
+                            }
+                        }
+#pragma unroll
+                        for (int t = 0; t < T; ++t)
+                            if ((t == 0 && a_first == 0) || q[t] < best) {
+                                best = q[t];
+                                arg = a_first + t;
+                            }
+                    }
+                }
                 for (; a_first + 1 < P.A; a_first += 2) {
                     const Act64 ac0 = act64[a_first], ac1 = act64[a_first + 1];
                     double u0[2] = {ac0.u0, ac0.u1}, u1[2] = {ac1.u0, ac1.u1}, acc0[1], acc1[1];
@@ -3192,6 +3284,8 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
     if ((rc = dev_upload(h, utab.data(), utab.size(), &P.utab))) return bail(rc);
     if ((rc = dev_upload(h, gu.data(), gu.size(), &P.gu))) return bail(rc);
     if ((rc = dev_upload(h, aok.data(), aok.size(), &P.aok))) return bail(rc);
+    P.all_aok = 1;
+    for (long long a = 0; a < A; ++a) P.all_aok = P.all_aok && aok[a];
     {
         std::vector<int> aok32(aok.begin(), aok.end());
         if ((rc = dev_upload(h, aok32.data(), aok32.size(), &h->aok32))) return bail(rc);
@@ -3241,7 +3335,9 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
                     const double dd = k + 1 < d->x_dim[i] ? d->x_level[i][k + 1] - l0 : 1.0;
                     lr[at] = make_double2(l0, 1.0 / dd);  // IEEE division: the correctly rounded reciprocal
                 }
-            h->levr_bytes = nlev * sizeof(double2);
+            size_t nvel = 0;  // the velocity axes' tables are the ones kept in LDS
+            for (int i = d->n / 2; i < d->n; ++i) nvel += (size_t)d->x_dim[i];
+            h->levr_bytes = nvel * sizeof(double2);
             if (h->levr_bytes <= 48 * 1024) {
                 if ((rc = dev_upload(h, a64.data(), a64.size(), &h->act64))) return bail(rc);
                 if ((rc = dev_upload(h, lr.data(), lr.size(), &h->levr))) return bail(rc);
