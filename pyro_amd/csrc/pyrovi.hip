@@ -319,15 +319,21 @@ __device__ inline int find_interval_lv(const double* lev, int N, double lo, doub
                                        double& l1) {
     double t = floor((x - lo) * inv_step);
     int i = (t < 0.0) ? 0 : (t > (double)(N - 2) ? N - 2 : (int)t);
-    for (;;) {
-        l0 = lev[i];
-        l1 = lev[i + 1];
-        if (i > 0 && x < l0)
-            --i;
-        else if (i < N - 2 && x >= l1)
-            ++i;
-        else
-            break;
+    l0 = lev[i];
+    l1 = lev[i + 1];
+    // the estimate is the interval unless rounding put x across a level: the search is entered on a wave vote, so that
+    // the common case stays straight-line code (as a plain per-lane loop every cell pays the loop's bookkeeping)
+    if (__builtin_amdgcn_ballot_w64((i > 0 && x < l0) || (i < N - 2 && x >= l1)) != 0ull) {
+        for (;;) {
+            if (i > 0 && x < l0)
+                --i;
+            else if (i < N - 2 && x >= l1)
+                ++i;
+            else
+                break;
+            l0 = lev[i];
+            l1 = lev[i + 1];
+        }
     }
     return i;
 }
