@@ -891,31 +891,6 @@ __global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restric
     typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
     if (sc.ctrl->done) return;
     extern __shared__ __attribute__((aligned(16))) double2 lr_lds[];
-    const double2* tab[N];
-    const double2* act_lds = nullptr;  // SPARSE: {u0, u1}, {gu, aok} per action behind the level tables
-    {
-        // only the velocity axes' tables are read per action: they go to LDS; the position axes' (a few reads per node)
-        // stay in global memory -- a 1001 x 1001 grid otherwise copies 32 KB into every workgroup and holds five
-        // workgroups per CU
-        int at = 0, al = 0;
-#pragma unroll
-        for (int d = 0; d < N; ++d) {
-            if (d < DOF) {
-                tab[d] = levr + at;
-            } else {
-                for (int i = threadIdx.x; i < P.dim[d]; i += blockDim.x) lr_lds[al + i] = levr[at + i];
-                tab[d] = lr_lds + al;
-                al += P.dim[d];
-            }
-            at += P.dim[d];
-        }
-        if constexpr (SPARSE) {
-            const double2* src = (const double2*)act64;
-            for (int i = threadIdx.x; i < 2 * P.A; i += blockDim.x) lr_lds[al + i] = src[i];
-            act_lds = lr_lds + al;
-        }
-        __syncthreads();
-    }
     // Workgroups go round-robin over the 8 XCDs, each with its own L2.  The gathers of a node land on the position rows
     // next to its own, anywhere in their velocity planes: neighbours in (i0, i1) share those planes, so every XCD gets
     // a CONTIGUOUS range of logical blocks (physical block b = 8 j + x  ->  logical x * chunk + j) and a plane is fetched
@@ -944,13 +919,50 @@ __global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restric
     } else if (live) {
         decode_node<N>(P, o, idx);
     }
+    // the node's own coordinates, from the global tables: issued BEFORE the table copy below so that the two memory round
+    // trips overlap (the copy loop waits for its loads before it can write LDS)
+    double xown[N];
+    {
+        int at = 0;
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+            xown[d] = live ? levr[at + idx[d]].x : 0.0;
+            at += P.dim[d];
+        }
+    }
+    // (the node's own levels were requested above: their round trip and the copy's are one)
+    const double2* tab[N];
+    const double2* act_lds = nullptr;  // SPARSE: {u0, u1}, {gu, aok} per action behind the level tables
+    {
+        // only the velocity axes' tables are read per action: they go to LDS; the position axes' (a few reads per node)
+        // stay in global memory -- a 1001 x 1001 grid otherwise copies 32 KB into every workgroup and holds five
+        // workgroups per CU
+        int at = 0, al = 0;
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+            if (d < DOF) {
+                tab[d] = levr + at;
+            } else {
+                for (int i = threadIdx.x; i < P.dim[d]; i += blockDim.x) lr_lds[al + i] = levr[at + i];
+                tab[d] = lr_lds + al;
+                al += P.dim[d];
+            }
+            at += P.dim[d];
+        }
+        if constexpr (SPARSE) {
+            const double2* src = (const double2*)act64;
+            for (int i = threadIdx.x; i < 2 * P.A; i += blockDim.x) lr_lds[al + i] = src[i];
+            act_lds = lr_lds + al;
+        }
+        __syncthreads();
+    }
     double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
     if (live) {
         double x[N], dx[N];
         long long self = (long long)(idx[0] - P.store_begin) * P.strd[0];
 #pragma unroll
         for (int d = 0; d < N; ++d) {
-            x[d] = tab[d][idx[d]].x;
+            x[d] = xown[d];
             dx[d] = x[d] - P.xbar[d];
             if (d > 0) self += idx[d] * P.strd[d];
         }
@@ -960,13 +972,32 @@ __global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restric
         bool pos_in = true, halo_bad = false;
         int ci[N];
         double y[N];
+        // (estimate, both end levels in ONE round trip to the global table, a wave vote on whether anybody has to step --
+        //  find_interval's dependent loads were two to three round trips at the head of every workgroup)
+        {
+            double xn[DOF], l0[DOF], l1[DOF];
+            bool mv = false;
 #pragma unroll
-        for (int i = 0; i < DOF; ++i) {
-            const double xn = x[DOF + i] * P.dt + x[i];
-            pos_in = pos_in && !(xn < P.glo[i]) && !(xn > P.ghi[i]);
-            ci[i] = find_interval(P.lev[i], P.dim[i], P.glo[i], P.inv_step[i], xn);
-            const double l0 = tab[i][ci[i]].x;
-            y[i] = (xn - l0) / (tab[i][ci[i] + 1].x - l0);
+            for (int i = 0; i < DOF; ++i) {
+                xn[i] = x[DOF + i] * P.dt + x[i];
+                pos_in = pos_in && !(xn[i] < P.glo[i]) && !(xn[i] > P.ghi[i]);
+                const double t0 = floor((xn[i] - P.glo[i]) * P.inv_step[i]);
+                ci[i] = (t0 < 0.0) ? 0 : (t0 > (double)(P.dim[i] - 2) ? P.dim[i] - 2 : (int)t0);
+                l0[i] = tab[i][ci[i]].x;
+                l1[i] = tab[i][ci[i] + 1].x;
+            }
+#pragma unroll
+            for (int i = 0; i < DOF; ++i) mv = mv || (ci[i] > 0 && xn[i] < l0[i]) || (ci[i] < P.dim[i] - 2 && xn[i] >= l1[i]);
+            if (__builtin_amdgcn_ballot_w64(mv) != 0ull) {
+#pragma unroll
+                for (int i = 0; i < DOF; ++i) {
+                    ci[i] = find_interval(P.lev[i], P.dim[i], P.glo[i], P.inv_step[i], xn[i]);
+                    l0[i] = tab[i][ci[i]].x;
+                    l1[i] = tab[i][ci[i] + 1].x;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < DOF; ++i) y[i] = (xn[i] - l0[i]) / (l1[i] - l0[i]);
         }
         double best = P.INF;  // position row outside the box: every action costs INF + alpha*0, the first one wins
         int arg = 0;
