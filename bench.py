@@ -160,6 +160,24 @@ def issue_roofline(ctr, kern_ms, cells):
             "counters_source": ctr.get("source")}
 
 
+def lds_roofline(ctr, kern_ms, cells, n, w, lean):
+    """The second on-chip ceiling of the float32 sweeps: LDS bandwidth.  Every cell gathers 2^n values of w bytes from the
+    LDS window (N*A*2^n*w bytes per sweep, C3 140 GB -- not HBM traffic); the narrow-read class they use
+    (ds_read2_b32, ds_read_b32) moves 128 B per clock per CU (MI355X_MICROARCH.md, LDS), 256 CUs at 2.4 GHz = 78.6 TB/s.
+    `lds_busy_frac` = LDS-array cycles per CU (SQ_LDS_IDX_ACTIVE, committed PMC pass) / kernel cycles measured in this run;
+    `bank_conflict_share` of those cycles are conflict cycles."""
+    if not lean or not ctr.get("lds_idx_active_cycles"):
+        return None
+    alg = cells * (1 << n) * w
+    peak = 256 * 128 * CLOCK_HZ / 1e12
+    ach = alg / (kern_ms * 1e-3) / 1e12
+    return {"bound": "lds", "achieved": ach, "peak": peak, "unit": "TB/s", "frac": ach / peak,
+            "algorithmic_bytes_per_launch": alg,
+            "lds_busy_frac": ctr["lds_idx_active_cycles"] / 256.0 / (kern_ms * 1e-3 * CLOCK_HZ),
+            "bank_conflict_share": ctr["lds_bank_conflict_cycles"] / ctr["lds_idx_active_cycles"],
+            "counters_source": ctr.get("source")}
+
+
 def load_counters(workload):
     """Per-launch hardware counters of the sweep kernel from the committed rocprofv3 PMC passes
     (profiles/counters.json, produced by tools/tools_counters.sh + tools/make_counters_json.py).  They are NOT measured
@@ -226,6 +244,7 @@ def measure(name, steps, warmup, keep_handle=False):
                      "note": "nominal: the fused sweep is instruction-issue bound (A actions per node on %d B of "
                              "compulsory traffic), see roofline_issue" % (2 * w + pbytes)},
         "roofline_issue": None if not ctr.get("valu_insts_per_launch") else issue_roofline(ctr, kern_ms, N * A),
+        "roofline_lds": lds_roofline(ctr, kern_ms, N * A, g.sys.n, w, w == 4 and "k_sweep_lean" in str(ctr.get("kernel", ""))),
         "flops_frac_vector_peak": {"dtype": dt_name, "peak_tflops": VALU_PEAK_TFLOPS[dt_name],
                                    "algorithmic_flops_per_cell": flops_cell,
                                    "frac": cells_per_s_kernel * flops_cell / (VALU_PEAK_TFLOPS[dt_name] * 1e12)},
