@@ -671,13 +671,19 @@ __global__ void k_terminal_cost(DevP P, REAL* __restrict__ J) {
 // the fused sweep, tier A (in-kernel dynamics), one thread per node, actions looped in registers.
 // v0 gather path: J_k read straight through L1/L2.
 // =================================================================================================
-template <int DYN, typename REAL, typename PI_T, bool LEVLDS>
+// SPARSE (4-D, state box = grid box, A <= 128): the actions whose cell lands in the box come from the 128-bit mask that
+// k_valid_mask wrote at set-up (further down: the same float64 expressions), every lane walks the set bits of ITS mask with
+// the cell arithmetic of the dense loop, and the cells outside -- Q = INF + alpha * 0 = INF -- enter the argmin as one
+// candidate (INF, first clear bit).  This is the float32-storage path of systems whose float32 displacement cancels
+// (the two-link arm): 88 % of its cells are outside the box.
+template <int DYN, typename REAL, typename PI_T, bool LEVLDS, bool SPARSE = false>
 __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ Jin, REAL* __restrict__ Jout,
                                                PI_T* __restrict__ pi, double alpha, SweepCtl sc,
                                                const double* __restrict__ utab, const double* __restrict__ gutab,
-                                               const int* __restrict__ aoktab) {
+                                               const int* __restrict__ aoktab, const uint4* __restrict__ vmask = nullptr) {
     using D = Dyn<DYN>;
     constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M;
+    static_assert(!SPARSE || DOF == 2, "validity masks are kept for 4-D grids");
     if (sc.ctrl->done) return;
     // grid levels: LDS copies when they fit (they are read several times per cell), else global memory
     extern __shared__ __attribute__((aligned(16))) double lev_lds[];
@@ -747,7 +753,7 @@ __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ 
         REAL best = (REAL)0;
         int arg = 0;
         const REAL alpha_r = (REAL)alpha;
-        for (int a = 0; a < P.A; ++a) {
+        auto cell = [&](int a) -> REAL {
             double u[M], acc[DOF];
 #pragma unroll
             for (int k = 0; k < M; ++k) u[k] = utab[a * M + k];
@@ -782,9 +788,45 @@ __global__ __launch_bounds__(256) void k_sweep(DevP P, const REAL* __restrict__ 
                 q = G + alpha_r * Jn;  // two roundings, as numpy (:567)
             else
                 q = fmaf(alpha_r, Jn, G);
-            if (a == 0 || q < best) {
-                best = q;
-                arg = a;
+            return q;
+        };
+        if constexpr (SPARSE) {
+            const uint4 mk = pos_in ? vmask[o] : make_uint4(0u, 0u, 0u, 0u);
+            const unsigned w[4] = {mk.x, mk.y, mk.z, mk.w};
+            int first_out = -1;
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {
+                const unsigned z = ~w[k];
+                const int i = 32 * k + __ffs((int)z) - 1;
+                if (z && i < P.A) first_out = i;
+            }
+            bool have = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned m = w[k];
+                while (m != 0u) {
+                    const int a = 32 * k + __ffs((int)m) - 1;
+                    m &= m - 1u;
+                    const REAL q = cell(a);
+                    if (!have || q < best) {
+                        best = q;
+                        arg = a;
+                        have = true;
+                    }
+                }
+            }
+            const REAL inf_r = (REAL)P.INF;
+            if (first_out >= 0 && (!have || inf_r < best || (inf_r == best && first_out < arg))) {
+                best = inf_r;
+                arg = first_out;
+            }
+        } else {
+            for (int a = 0; a < P.A; ++a) {
+                const REAL q = cell(a);
+                if (a == 0 || q < best) {
+                    best = q;
+                    arg = a;
+                }
             }
         }
         Jout[self] = best;
@@ -3477,7 +3519,18 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
     HCHK(hipStreamSynchronize(h->stream));
 #undef HCHK
     if ((rc = lean_setup(h))) return bail(rc);
-    if (h->use64 && d->n == 4 && A <= 128 && h->levr_bytes + (size_t)A * sizeof(Act64) <= 48 * 1024 &&
+    // the float32-storage exact path (float64 dynamics: systems whose float32 displacement cancels) walks the same masks
+    bool grid_is_box = true;
+    for (int i = 0; i < d->n; ++i) grid_is_box = grid_is_box && d->x_lb[i] == P.glo[i] && d->x_ub[i] == P.ghi[i];
+    const bool exact32 = d->dtype == PVI_F32 && d->dynamics_id != PVI_DYN_TABLE && !is_dyn3(d->dynamics_id) &&
+                         !is_node_dyn(d->dynamics_id) && !h->lean_ok && !h->fast_ok && !h->tile_ok && grid_is_box;
+    if (exact32 && d->n == 4 && A <= 128 && !h->act64) {
+        std::vector<Act64> a64((size_t)A);
+        for (long long a = 0; a < A; ++a)
+            a64[a] = Act64{utab[a * d->m], d->m > 1 ? utab[a * d->m + 1] : 0.0, gu[a], aok[a] ? 1.0 : 0.0};
+        if ((rc = dev_upload(h, a64.data(), a64.size(), &h->act64))) return bail(rc);
+    }
+    if (((h->use64 && h->levr_bytes + (size_t)A * sizeof(Act64) <= 48 * 1024) || exact32) && d->n == 4 && A <= 128 &&
         !(getenv("PVI_SPARSE") && !atoi(getenv("PVI_SPARSE")))) {
         // SPARSE float64 sweep: validity of every (node, action) cell, once (it does not change between sweeps); kept
         // where fewer than half of the cells land in the box (PVI_SPARSE=1 keeps it regardless, =0 never builds it)
@@ -3604,11 +3657,12 @@ extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
                  (int)((unsigned long long)h->stored * 8ull < (1ull << 32)), h->sparse64, h->infrac64);
         return PVI_OK;
     }
-    snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d wgs=%u wpc=%d nbuf=%d npt=%d reach=%d opmag=%d note=%s",
+    snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d wgs=%u wpc=%d nbuf=%d npt=%d reach=%d opmag=%d sparse=%d note=%s",
              path, h->LP.TV0, h->LP.TV1, h->lean_grid.x, h->lean_grid.y, h->lean_grid.z, h->lean_block, h->lean_pw1,
              h->lean_lds, h->lean_ok ? h->LP.lsplit : h->F.lsplit, h->LP.tb_tile, h->lean_ok ? h->LP.dma16 : 0,
              (h->lean_ok && h->lean_persist) ? h->lean_pgrid : 0u, (h->lean_ok && h->lean_persist) ? h->lean_wpc : 0,
-             (h->lean_ok && h->lean_persist) ? h->LP.nbuf : 0, h->lean_ok ? h->LP.npt : 1, h->lean_reach, h->lean_opmag, h->lean_why);
+             (h->lean_ok && h->lean_persist) ? h->LP.nbuf : 0, h->lean_ok ? h->LP.npt : 1, h->lean_reach, h->lean_opmag,
+             (h->d.dtype == PVI_F32 && h->sparse64 && h->vmask) ? 1 : 0, h->lean_why);
     return PVI_OK;
 }
 
@@ -3918,13 +3972,21 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     for (int d = 0; d < h->P.n; ++d) nlev_all += h->P.dim[d];
     const bool lev_in_lds = nlev_all * 8 <= 32 * 1024;
     const size_t lev_bytes = lev_in_lds ? (size_t)nlev_all * 8 : 0;
+    const bool sparse_x = sizeof(REAL) == 4 && h->sparse64 && h->vmask && h->P.n == 4 && lev_in_lds && !h->force_exact;
 #define EXACT(DYN)                                                                                                     \
+    if constexpr (Dyn<DYN>::DOF == 2 && sizeof(REAL) == 4) {                                                           \
+        if (sparse_x) {                                                                                                \
+            hipLaunchKernelGGL((k_sweep<DYN, REAL, PI_T, true, true>), g, 256, lev_bytes, st, h->P, Jin, Jout, pi,     \
+                               alpha, sc, h->P.utab, h->P.gu, h->aok32, h->vmask);                                     \
+            break;                                                                                                     \
+        }                                                                                                              \
+    }                                                                                                                  \
     if (lev_in_lds)                                                                                                    \
         hipLaunchKernelGGL((k_sweep<DYN, REAL, PI_T, true>), g, 256, lev_bytes, st, h->P, Jin, Jout, pi, alpha, sc,    \
-                           h->P.utab, h->P.gu, h->aok32);                                                              \
+                           h->P.utab, h->P.gu, h->aok32, (const uint4*)nullptr);                                       \
     else                                                                                                               \
         hipLaunchKernelGGL((k_sweep<DYN, REAL, PI_T, false>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha, sc, h->P.utab,   \
-                           h->P.gu, h->aok32);
+                           h->P.gu, h->aok32, (const uint4*)nullptr);
     if constexpr (sizeof(REAL) == 8) {
         if (h->use64 && !h->force_exact) {
             const bool off32 = (unsigned long long)h->stored * 8ull < (1ull << 32);

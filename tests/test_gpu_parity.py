@@ -418,6 +418,39 @@ def test_f32_kernel_variants_agree(name, monkeypatch):
     assert path_of(outs["exact32"][2]) == "path=exact-f32"
 
 
+def test_exact_f32_sparse_walk_is_bit_identical(monkeypatch):
+    """float32 storage with float64 dynamics (systems whose float32 displacement cancels: the two-link arm): the walk over
+    the per-node validity masks against the dense action loop of the same kernel -- J, pi and statistics bit for bit,
+    whole grid and a slab with halos."""
+    for name in ("twolink_11p4x3x3", "doublependulum_13x11x13x11x3x3"):
+        g = load(name)
+        p = oracle_problem(g, *CASES[name])
+        alpha = float(g["alpha"]) if "alpha" in g.files else 1.0
+        outs = {}
+        for tag, env in (("dense", {"PVI_SPARSE": "0"}), ("sparse", {"PVI_SPARSE": "1"})):
+            monkeypatch.setenv("PVI_NO_FAST", "1")           # the exact float32 path whatever the displacement magnitude
+            monkeypatch.setenv("PVI_SPARSE", env["PVI_SPARSE"])
+            h = native_problem(p, dtype="float32")
+            desc = h.describe()
+            assert desc.startswith("path=exact-f32") and ("sparse=1" if tag == "sparse" else "sparse=0") in desc, desc
+            h.terminal_cost()
+            stats, n = h.sweep(6, alpha, -1.0)
+            outs[tag] = [h.get_J(), h.get_pi(), stats.copy()]
+            h.close()
+            N0 = p.dims[0]
+            r0, r1 = N0 // 3, max(N0 // 3 + 2, (2 * N0) // 3)
+            hs = native_problem(p, dtype="float32", rows=(r0, r1), halo=(r0, N0 - r1))
+            hs.terminal_cost()
+            hs.sweep_async(alpha)
+            hs.sweep_stats()
+            outs[tag] += [hs.get_J(), hs.get_pi()]
+            hs.close()
+        for a, b in zip(outs["dense"], outs["sparse"]):
+            assert np.array_equal(a, b), name
+    monkeypatch.delenv("PVI_NO_FAST", raising=False)
+    monkeypatch.delenv("PVI_SPARSE", raising=False)
+
+
 @pytest.mark.parametrize("name", list(CASES) + ["edge:" + k for k in ("A300_u16_policy", "minimal_2x2_A1", "cartpole_ragged_fancy_cost", "doublependulum_72_actions", "everything_out_of_bounds", "tiny_box")])
 def test_f64_second_form_is_bit_identical(name, monkeypatch):
     """k_sweep64 (tabulated-reciprocal fractions, hoisted position weights, one validity compare per bound, skipped
