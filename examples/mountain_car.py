@@ -1,7 +1,12 @@
 """pyro's examples/demos_by_system/mountain_car/mountain_car_with_valueiteration_quadratic.py with pyro_amd imports.
 MountainCar has position-dependent inertia / Coriolis / actuator / gravity terms and no closed-form kernel: it runs
 through the generic mechanical tier (per-node tables, O(N) evaluations of the model terms)."""
+import os
+import sys
+
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # run from a checkout
 
 from pyro_amd.analysis import costfunction
 from pyro_amd.dynamic import mountaincar

@@ -4,8 +4,12 @@ switched to pyro_amd (BASELINE configs[0] at 101x101x11; pass a larger grid to t
 
     python examples/pendulum_optimal_swingup.py [nx nv nu [dtype]]
 """
+import os
 import sys
+
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # run from a checkout
 
 from pyro_amd.analysis import costfunction
 from pyro_amd.dynamic import pendulum

@@ -440,3 +440,15 @@ def test_rccl_entry_points_the_library_binds_exist():
     if m:
         from pyro_amd import _native
         assert int(m.group(1)) == _native.COMM_ID_BYTES == 128
+
+
+def test_examples_run_from_a_checkout():
+    """`python examples/<script>.py` from anywhere: the scripts put the checkout on sys.path themselves."""
+    import ast
+    for name in ("pendulum_optimal_swingup.py", "mountain_car.py", "cartpole_sharded.py"):
+        src = open(os.path.join(ROOT, "examples", name)).read()
+        tree = ast.parse(src)
+        first_pkg_import = min(n.lineno for n in ast.walk(tree) if isinstance(n, ast.ImportFrom) and (n.module or "").startswith("pyro_amd"))
+        path_insert = [n.lineno for n in ast.walk(tree) if isinstance(n, ast.Call) and getattr(n.func, "attr", "") == "insert" and
+                       "sys.path" in ast.unparse(n.func)]
+        assert path_insert and min(path_insert) < first_pkg_import, name
