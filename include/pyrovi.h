@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PVI_ABI_VERSION 2
+#define PVI_ABI_VERSION 3
 #define PVI_MAX_N 4 /* state dimensions supported by the reference grid: 2, 3, 4 (discretizer.py:183-245) */
 #define PVI_MAX_M 2 /* input dimensions: 1, 2 (discretizer.py:271-306) */
 #define PVI_MAX_TRIG 4
@@ -263,8 +263,14 @@ typedef struct pvi_shard_s* pvi_shard;
 /* ncclGetUniqueId: call on ONE rank and hand the 128 bytes to the others by any means (MPI, a file, a TCP store) */
 int pvi_comm_unique_id(uint8_t* id128);
 /* `whole` describes the WHOLE grid (row_begin / row_end / halo_* / ext_* are ignored; device = this rank's GPU).
-   halo_rows = ceil(max |x_next_0 - x_0| / dx_0) + 1 (mechanical systems: max |dq_0| dt / dx_0).  id128 may be NULL when
-   world == 1 (no communicator).  overlap != 0: boundary-first schedule on two streams. */
+   halo_rows = ceil(max |x_next_0 - x_0| / dx_0) + 1 (mechanical systems: max |dq_0| dt / dx_0) and must be ONE number for
+   the whole grid: the counts of the send / recv pairs and the send/recv-or-broadcast decision depend on it.
+     halo_rows >= 1 : the width, the same on every rank -- checked across the ranks, PVI_EINVAL if they disagree;
+     halo_rows <  0 : -halo_rows is a bound THIS rank derived from its own rows (e.g. from its part of an x_next
+                      table); the library takes the largest over the ranks.
+   id128 may be NULL when world == 1 (no communicator).  overlap != 0: boundary-first schedule on two streams.
+   Collective: every rank of the communicator must call it (the ranks agree on the halo and on success; if one rank
+   cannot build its slab, all return an error). */
 int pvi_shard_create(const pvi_desc* whole, int32_t rank, int32_t world, int32_t halo_rows, const uint8_t* id128,
                      int32_t overlap, pvi_shard* out);
 /* Bring-your-own transport (MPI without RCCL, or a host-staged test harness): the same slab schedule with the two
@@ -294,8 +300,29 @@ int pvi_shard_sweep(pvi_shard s, int32_t max_sweeps, double alpha, double tol, d
 int pvi_shard_set_tables(pvi_shard s, const double* x_next_rows, const double* G_rows, const uint8_t* ok_rows);
 int pvi_shard_set_J(pvi_shard s, const double* J_owned_rows);
 int pvi_shard_get_J(pvi_shard s, double* J_owned_rows);   /* this rank's rows, float64 */
+int pvi_shard_get_J_prev(pvi_shard s, double* J_owned_rows); /* ... of the previous sweep (dp.J_next) */
+int pvi_shard_halo(pvi_shard s, int32_t* halo_rows);      /* the width the ranks agreed on (rows stored beyond the owned ones) */
 int pvi_shard_get_pi(pvi_shard s, int64_t* pi_owned_rows);
+/* ---- ABI 3: the sharded solve behind the reference's attributes ---- */
+/* dp.J (which = 0) / dp.J_next (which = 1: the cost-to-go of the previous sweep) and dp.pi of the WHOLE grid on every
+   rank (dynamicprogramming.py:181, :569-570).  Collective over the RCCL communicator (every rank calls; one ncclBroadcast
+   per owner in one group).  With a caller-supplied transport: PVI_ESTATE for world > 1 -- gather the rows of
+   pvi_shard_get_J / pvi_shard_get_pi with that transport. */
+int pvi_shard_gather_J(pvi_shard s, int32_t which, double* J_whole);
+int pvi_shard_gather_pi(pvi_shard s, int64_t* pi_whole);
+/* finalize_backward_step reports every sweep (dynamicprogramming.py:240-261): on != 0 makes a fixed-count
+   pvi_shard_sweep take and all-reduce the statistics after EVERY sweep (a host synchronisation each; off by default).
+   pvi_shard_sweep_history returns the rows (max J, max d, min d, delta) of the last call's sweeps that took
+   statistics, oldest first: all of them with a stop tolerance or the switch on, else the last sweep only. */
+int pvi_shard_stats_every_sweep(pvi_shard s, int32_t on);
+int pvi_shard_sweep_history(pvi_shard s, double* stats, int32_t max_rows, int32_t* rows);
+/* "rank=r/w rows=[..) stored=[..) halo=h exchange=send/recv|broadcast[+overlap] pieces=k comm=rccl|caller|none
+   rccl_ranks=N | <pvi_describe of the interior handle>"; rccl_ranks = ncclCommCount of the communicator in use */
 int pvi_shard_describe(pvi_shard s, char* buf, int32_t n);
+/* GPU times of the last pvi_shard_sweep call on this rank (HIP events on its compute and comm streams), per-sweep
+   averages over its last <= 32 sweeps, milliseconds: out6 = {boundary kernels, interior kernel, halo exchange,
+   exchange time NOT hidden behind the interior kernel, boundary + interior + exposed exchange, sweeps averaged over} */
+int pvi_shard_timing(pvi_shard s, double out6[6]);
 
 /* ---- batched dynamics ------------------------------------------------------------------------ */
 /* dX[b] = f(X[b], U[b]) for B states (mechanical.py:238-263); host pointers, float64 */

@@ -22,7 +22,7 @@ INTERP_LINEAR, INTERP_BICUBIC_SPLINE = 0, 1
 PVI_EHALO = -5
 FLAG_EXT_J_SLACK = 1
 FLAG_HARD_INF = 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 PVI_MAX_OBS = 8
 
 _dp = C.POINTER(C.c_double)
@@ -96,8 +96,15 @@ SYMBOLS = {
     "pvi_shard_set_tables": (C.c_int, [_h, _dp, _dp, C.POINTER(C.c_uint8)]),
     "pvi_shard_set_J": (C.c_int, [_h, _dp]),
     "pvi_shard_get_J": (C.c_int, [_h, _dp]),
+    "pvi_shard_get_J_prev": (C.c_int, [_h, _dp]),
+    "pvi_shard_halo": (C.c_int, [_h, C.POINTER(C.c_int32)]),
     "pvi_shard_get_pi": (C.c_int, [_h, C.POINTER(C.c_int64)]),
     "pvi_shard_describe": (C.c_int, [_h, C.c_char_p, C.c_int32]),
+    "pvi_shard_timing": (C.c_int, [_h, _dp]),
+    "pvi_shard_gather_J": (C.c_int, [_h, C.c_int32, _dp]),
+    "pvi_shard_gather_pi": (C.c_int, [_h, C.POINTER(C.c_int64)]),
+    "pvi_shard_stats_every_sweep": (C.c_int, [_h, C.c_int32]),
+    "pvi_shard_sweep_history": (C.c_int, [_h, _dp, C.c_int32, C.POINTER(C.c_int32)]),
 }
 COMM_ID_BYTES = 128
 
@@ -440,6 +447,9 @@ class ShardedProblem:
         r0, r1 = C.c_int32(), C.c_int32()
         check(lib().pvi_shard_rows(self._h, C.byref(r0), C.byref(r1)))
         self.rows = (r0.value, r1.value)
+        h = C.c_int32()
+        check(lib().pvi_shard_halo(self._h, C.byref(h)))
+        self.halo = h.value                 # the width the ranks agreed on
 
     def close(self):
         if getattr(self, "_h", None):
@@ -462,9 +472,9 @@ class ShardedProblem:
         check(lib().pvi_shard_sweep(self._h, int(max_sweeps), float(alpha), float(tol), _ptr(st), C.byref(done)))
         return st, done.value
 
-    def get_J(self):
+    def get_J(self, prev=False):
         out = np.empty((self.rows[1] - self.rows[0]) * self.plane)
-        check(lib().pvi_shard_get_J(self._h, _ptr(out)))
+        check((lib().pvi_shard_get_J_prev if prev else lib().pvi_shard_get_J)(self._h, _ptr(out)))
         return out
 
     def set_tables(self, x_next, G, ok=None):
@@ -477,6 +487,8 @@ class ShardedProblem:
         okp = None
         if ok is not None:
             ok = np.ascontiguousarray(ok, dtype=np.uint8)
+            if ok.shape != G.shape:
+                raise ValueError("ok mask shape does not match this rank's rows")
             okp = ok.ctypes.data_as(C.POINTER(C.c_uint8))
         check(lib().pvi_shard_set_tables(self._h, _ptr(x_next), _ptr(G), okp))
 
@@ -495,3 +507,30 @@ class ShardedProblem:
         buf = C.create_string_buffer(1024)
         check(lib().pvi_shard_describe(self._h, buf, 1024))
         return buf.value.decode()
+
+    def gather_J(self, prev=False):
+        """J (or J_next) of the whole grid on every rank: collective over the RCCL communicator."""
+        out = np.empty(self._desc_owner.dims[0] * self.plane)
+        check(lib().pvi_shard_gather_J(self._h, int(bool(prev)), _ptr(out)))
+        return out
+
+    def gather_pi(self):
+        out = np.empty(self._desc_owner.dims[0] * self.plane, dtype=np.int64)
+        check(lib().pvi_shard_gather_pi(self._h, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
+
+    def stats_every_sweep(self, on):
+        check(lib().pvi_shard_stats_every_sweep(self._h, int(bool(on))))
+
+    def sweep_history(self, max_rows=1024):
+        st = np.zeros((max(int(max_rows), 1), 4))
+        n = C.c_int32(0)
+        check(lib().pvi_shard_sweep_history(self._h, _ptr(st), int(max_rows), C.byref(n)))
+        return st[:n.value]
+
+    def timing(self):
+        """Per-sweep GPU milliseconds of the last sweep() call on this rank (pvi_shard_timing)."""
+        t = np.zeros(6)
+        check(lib().pvi_shard_timing(self._h, _ptr(t)))
+        return dict(boundary_ms=t[0], interior_ms=t[1], exchange_ms=t[2], exposed_exchange_ms=t[3], sweep_ms=t[4],
+                    sweeps_timed=int(t[5]))

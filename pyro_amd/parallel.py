@@ -8,7 +8,11 @@ The reference has no counterpart (single thread); the partition follows SURVEY.m
     rank r owns rows [r0, r1), stores [r0-h, r1+h) clipped to the grid;
     h = ceil(max|x_next_0 - x_0| / dx_0) + 1; for mechanical systems x_next_0 - x_0 = dq_0*dt exactly.
 
-Two drivers:
+The reference's own surface over a sharded grid (compute_steps, solve_bellman_equation, J, pi, clean_infeasible_set,
+get_lookup_table_controller, save_latest, ...) is pyro_amd.planning.dynamicprogramming.DynamicProgramming* with the
+`comm=` keyword: RcclComm / TransportComm / TorchDistComm below say how the ranks talk.
+
+Two drivers underneath:
   RcclValueIteration    -- the product path: slab, halo exchange (ncclSend / ncclRecv), statistics all-reduce and the
                            boundary-first overlap all live INSIDE libpyrovi (pvi_shard_*, include/pyrovi.h); the host
                            only hands every rank the communicator id.  No torch anywhere.
@@ -33,23 +37,24 @@ def partition_rows(n_rows, world):
     return out
 
 
-def halo_rows(grid_sys, rows=None):
-    """Rows of axis 0 a gather can reach beyond a node's own row (+1 for the upper corner).  Mechanical systems:
-    x_next_0 - x_0 = dq_0 dt exactly, so the bound is analytic.  Any other system: the largest |x_next_0 - x_0| over
-    the cells whose x_next stays in the grid box, taken from the x_next table of `rows` (default: the whole grid) --
-    for the table tier that table exists anyway; a rank that looks at its own rows only gets a LOCAL bound, and the
-    library reports PVI_EHALO if a gather ever leaves the stored rows."""
+def halo_rows(grid_sys, rows=None, xn=None):
+    """Rows of axis 0 a gather can reach beyond a node's own row (+1 for the upper corner).
+
+    Mechanical systems: x_next_0 - x_0 = dq_0 dt exactly, so the bound is analytic and GLOBAL.  Any other system: the
+    largest |x_next_0 - x_0| over the cells whose x_next stays in the grid box, taken from an x_next table -- `xn` if the
+    caller has one for `rows` already, else the table of `rows` (default: the whole grid).  With `rows` given the result
+    is a LOCAL bound of that slab: every rank must end up with the same width (the send / recv counts of the exchange
+    depend on it), so reduce local bounds with max over the ranks -- pvi_shard_create does when it is handed a negative
+    width (ShardedProblem(halo_rows=-bound)); the library reports PVI_EHALO if a gather ever leaves the stored rows."""
     s = grid_sys.sys
     dof = getattr(s, "dof", None)
     if dof is not None:
         vmax = max(abs(float(s.x_lb[dof])), abs(float(s.x_ub[dof])))
         return int(math.ceil(vmax * grid_sys.dt / float(grid_sys.x_step_size[0]))) + 1
     plane = int(np.prod(grid_sys.x_grid_dim[1:]))
-    if rows is None:
-        xn, lo = grid_sys.x_next_table, 0
-    else:
-        lo = rows[0] * plane
-        xn = grid_sys._xnext_rows(lo, rows[1] * plane)[0]
+    lo = 0 if rows is None else rows[0] * plane
+    if xn is None:
+        xn = grid_sys.x_next_table if rows is None else _xnext_of_rows(grid_sys, rows)
     x0 = np.repeat(grid_sys.x_level[0], plane)[lo:lo + xn.shape[0]]
     inside = np.ones(xn.shape[:2], dtype=bool)
     for d in range(s.n):
@@ -57,6 +62,20 @@ def halo_rows(grid_sys, rows=None):
     reach = np.abs(xn[:, :, 0] - x0[:, None])[inside]
     r = float(reach.max()) if reach.size else 0.0
     return int(math.ceil(r / float(grid_sys.x_step_size[0]))) + 1
+
+
+def _xnext_of_rows(grid_sys, rows):
+    """x_next of the nodes of axis-0 rows [rows[0], rows[1]): from the GPU for systems with in-kernel dynamics (only those
+    rows are built), from the reference's loop over sys.f otherwise."""
+    from pyro_amd.planning.discretizer import device_dynamics_of
+    plane = int(np.prod(grid_sys.x_grid_dim[1:]))
+    if device_dynamics_of(grid_sys.sys) is not None:
+        p = grid_sys._device_problem()
+        try:
+            return p.build_tables(rows[0], rows[1] - rows[0], x_next_isok=False, action_isok=False, G=False)[0]
+        finally:
+            p.close()
+    return grid_sys._xnext_rows(rows[0] * plane, rows[1] * plane)[0]
 
 
 class HipSlab:
@@ -146,8 +165,14 @@ class HipSlab:
         o = (row0 - self.store_rows[0]) * self.plane
         return self.J[self.cur][o:o + nrows * self.plane]
 
-    def owned_J(self):
-        return self.rows_view(self.rows[0], self.rows[1] - self.rows[0]).double().cpu().numpy()
+    def owned_J(self, prev=False):
+        o = (self.rows[0] - self.store_rows[0]) * self.plane
+        return self.J[self.cur ^ (1 if prev else 0)][o:o + (self.rows[1] - self.rows[0]) * self.plane].double().cpu().numpy()
+
+    def set_owned_J(self, J):
+        t = self.torch.as_tensor(np.ascontiguousarray(J), dtype=self.J[0].dtype).to(self.dev)
+        self.rows_view(self.rows[0], self.rows[1] - self.rows[0]).copy_(t)
+        self.torch.cuda.synchronize(self.dev)
 
     def owned_pi(self):
         pi = self.pi.cpu().numpy()
@@ -170,13 +195,22 @@ class ShardedValueIteration:
         self.grid_sys = grid_sys
         n0 = int(grid_sys.x_grid_dim[0])
         self.parts = partition_rows(n0, self.world)
-        self.halo = halo_rows(grid_sys) if halo is None else halo
         self.rows = self.parts[self.rank]
+        if halo is None:
+            # mechanical systems: analytic.  Anything else: this rank's bound, then the largest over the ranks -- the
+            # exchange needs ONE width (neighbours post matching send / recv counts)
+            halo = halo_rows(grid_sys, None if getattr(grid_sys.sys, "dof", None) is not None else self.rows)
+            if self.world > 1 and getattr(grid_sys.sys, "dof", None) is None:
+                t = torch.tensor([halo], dtype=torch.int64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                halo = int(t.item())
+        self.halo = int(halo)
         if self.rows[1] - self.rows[0] < 1:
             raise ValueError("more ranks than rows of axis 0")
         # the +-1 neighbour exchange needs every neighbour slab to be at least `halo` thick
         self.p2p = all(b - a >= self.halo for a, b in self.parts) or self.world == 1
-        cost = cost_function.device_cost() if hasattr(cost_function, "device_cost") else cost_function
+        from pyro_amd.planning.discretizer import device_cost_of
+        cost = device_cost_of(cost_function, grid_sys.sys) if hasattr(cost_function, "device_cost") else cost_function
         store_halo = self.halo if self.p2p else n0          # fall-back: every rank stores the whole grid
         # boundary-first schedule (halo exchange overlapped with the interior kernel): product slabs, p2p exchange
         self.overlap = bool(overlap) and slab_factory is None and self.p2p and self.world > 1
@@ -278,9 +312,15 @@ class ShardedValueIteration:
                 break
         return out
 
-    def gather(self):
-        """J and pi of the whole grid on every rank (host arrays)."""
-        J, pi = self.slab.owned_J(), self.slab.owned_pi()
+    def set_J(self, J_whole):
+        """Replace the current cost-to-go by a whole-grid host array (every rank passes the same array)."""
+        plane = int(np.prod(self.grid_sys.x_grid_dim[1:]))
+        self.slab.set_owned_J(np.asarray(J_whole, dtype=float).ravel()[self.rows[0] * plane:self.rows[1] * plane])
+        self.exchange()
+
+    def gather(self, prev=False):
+        """J (prev: the cost-to-go of the previous sweep) and pi of the whole grid on every rank (host arrays)."""
+        J, pi = (self.slab.owned_J(True) if prev else self.slab.owned_J()), self.slab.owned_pi()
         if self.world == 1:
             return J, pi
         objs = [None] * self.world
@@ -292,33 +332,44 @@ class RcclValueIteration:
     """Value iteration on this rank's slab with everything between the sweeps done by RCCL inside libpyrovi.
 
     `comm_id`: the 128 bytes of `_native.comm_unique_id()` created on ONE rank and distributed by the caller (the bench
-    uses torch.distributed's store for that; MPI or a file do as well).  world == 1 needs none."""
+    uses torch.distributed's store for that; MPI or a file do as well).  world == 1 needs none.
+    Construction is collective (pvi_shard_create: the ranks agree on the halo width and on success)."""
 
     def __init__(self, grid_sys, cost_function, rank, world, comm_id=None, dtype="float32", device=0, halo=None,
-                 overlap=True, transport=None):
-        from pyro_amd.planning.discretizer import device_dynamics_of
+                 overlap=True, transport=None, hard_inf=False):
+        from pyro_amd import _native
+        from pyro_amd.planning.discretizer import device_cost_of, device_dynamics_of
         self.rank, self.world = int(rank), int(world)
         self.grid_sys = grid_sys
-        cost = cost_function.device_cost() if hasattr(cost_function, "device_cost") else cost_function
-        fused = device_dynamics_of(grid_sys.sys) is not None and isinstance(cost, dict)
-        if fused:
-            cost.pop("validity_of", None)
-            self.halo = halo_rows(grid_sys) if halo is None else int(halo)
-            self.shard = grid_sys._shard_problem(self.rank, self.world, self.halo, comm_id=comm_id, overlap=overlap,
-                                                 cost=cost, dtype=dtype, device=device, transport=transport)
+        s = grid_sys.sys
+        # the same tier decision as DynamicProgramming._make_engine: a cost that tests validity against another system
+        # (or a wrapped test) is arbitrary Python -> look-up tables
+        cost = device_cost_of(cost_function, s)
+        self.tier = "fused" if (device_dynamics_of(s) is not None and cost is not None) else "table"
+        n0 = int(grid_sys.x_grid_dim[0])
+        r0, r1 = partition_rows(n0, self.world)[self.rank]
+        plane = int(np.prod(grid_sys.x_grid_dim[1:]))
+        if self.tier == "fused":
+            if halo is None:
+                # mechanical: analytic and global.  Explicit systems: the bound of THIS rank's rows (built on the GPU for
+                # those rows only), negative = "take the largest over the ranks" (pvi_shard_create)
+                mech = getattr(s, "dof", None) is not None
+                halo = halo_rows(grid_sys) if mech else -halo_rows(grid_sys, (r0, r1))
+            self.shard = grid_sys._shard_problem(self.rank, self.world, int(halo), comm_id=comm_id, overlap=overlap,
+                                                 cost=cost, dtype=dtype, device=device, transport=transport,
+                                                 flags=_native.FLAG_HARD_INF if hard_inf else 0)
+            self.halo = self.shard.halo
             self.rows = self.shard.rows
             self.shard.terminal_cost()
             return
         # table tier (arbitrary Python sys.f / cf.g): every rank builds the reference's look-up tables for ITS rows only
         # (the O(N*A) host loops of discretizer.py:342-376 and dynamicprogramming.py:517-553, split over the ranks) and
         # the sweeps run sharded like the fused ones
-        n0 = int(grid_sys.x_grid_dim[0])
-        r0, r1 = partition_rows(n0, self.world)[self.rank]
-        plane = int(np.prod(grid_sys.x_grid_dim[1:]))
         lo, hi = r0 * plane, r1 * plane
         xn, xok = grid_sys._xnext_rows(lo, hi)
-        self.halo = (halo_rows(grid_sys, (r0, r1)) if halo is None else int(halo))
-        X, U, s = grid_sys.state_from_node_id, grid_sys.input_from_action_id, grid_sys.sys
+        if halo is None:
+            halo = -halo_rows(grid_sys, (r0, r1), xn=xn)       # local bound; the library takes the largest
+        X, U = grid_sys.state_from_node_id, grid_sys.input_from_action_id
         aok = np.array([[s.isavalidinput(X[i], U[a]) for a in range(grid_sys.actions_n)] for i in range(lo, hi)], dtype=bool)
         ok = aok & xok
         G = np.full(ok.shape, float(cost_function.INF))
@@ -326,13 +377,14 @@ class RcclValueIteration:
             G[i, a] = cost_function.g(X[lo + i], U[a], 0) * grid_sys.dt
         kw = dict(x_levels=grid_sys.x_level, u_levels=grid_sys.u_level, x_lb=s.x_lb, x_ub=s.x_ub, u_lb=s.u_lb, u_ub=s.u_ub,
                   dt=grid_sys.dt, dtype=dtype, dynamics_id=0, table_inf=float(cost_function.INF), device=device)
-        from pyro_amd import _native
-        self.shard = _native.ShardedProblem(self.rank, self.world, self.halo, comm_id=comm_id, overlap=overlap,
+        self.shard = _native.ShardedProblem(self.rank, self.world, int(halo), comm_id=comm_id, overlap=overlap,
                                             transport=transport, **kw)
+        self.halo = self.shard.halo
         self.rows = self.shard.rows
         assert self.rows == (r0, r1)
-        self.shard.set_tables(xn, G, None)
-        self.shard.set_J(np.array([cost_function.h(X[i], 0) for i in range(lo, hi)], dtype=float))
+        self.shard.set_tables(xn, G, ok if hard_inf else None)
+        self.J0_rows = np.array([cost_function.h(X[i], 0) for i in range(lo, hi)], dtype=float)
+        self.shard.set_J(self.J0_rows)
 
     def run(self, max_sweeps, alpha=1.0, tol=-1.0):
         """compute_steps (tol < 0) / solve_bellman_equation (tol >= 0): -> ((max J, max d, min d, delta), sweeps done)."""
@@ -347,3 +399,182 @@ class RcclValueIteration:
 
     def close(self):
         self.shard.close()
+
+
+# =====================================================================================================================
+# How the ranks talk: the `comm=` argument of DynamicProgramming* (pyro_amd/planning/dynamicprogramming.py)
+# =====================================================================================================================
+class RcclComm:
+    """In-library RCCL (pvi_shard_*): halo exchange, statistics all-reduce and the J / pi gathers all run inside
+    libpyrovi; the caller only distributes the communicator id (`_native.comm_unique_id()` from ONE rank)."""
+
+    def __init__(self, rank, world, comm_id=None, overlap=True):
+        self.rank, self.world, self.comm_id, self.overlap = int(rank), int(world), comm_id, bool(overlap)
+
+    def engine(self, dp):
+        return _LibraryEngine(dp, self, transport=None, allgather=None)
+
+
+class TransportComm:
+    """The library's slab schedule with the inter-rank steps supplied by the caller (MPI without RCCL, a host-staged
+    harness): sendrecv / max3 as in include/pyrovi.h pvi_transport, allgather(host array) -> list of every rank's array
+    (for dp.J / dp.pi)."""
+
+    def __init__(self, rank, world, sendrecv, max3, allgather, overlap=True):
+        self.rank, self.world, self.overlap = int(rank), int(world), bool(overlap)
+        self.sendrecv, self.max3, self.allgather = sendrecv, max3, allgather
+
+    def engine(self, dp):
+        return _LibraryEngine(dp, self, transport=(self.sendrecv, self.max3), allgather=self.allgather)
+
+
+def staged_transport(dist, rank, world, overlap=True):
+    """TransportComm over a torch.distributed process group WITHOUT device transport (gloo): halo rows are staged
+    through host buffers -- what an MPI build without GPU-aware buffers does.  Used where RCCL cannot run (several ranks
+    sharing one GPU in the tests)."""
+    import ctypes as C
+    import torch
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    D2H, H2D = 2, 1
+
+    def sendrecv(send_lo, recv_lo, lo_s, lo_r, send_hi, recv_hi, hi_s, hi_r, stream):
+        if hip.hipStreamSynchronize(stream) != 0:
+            return 1
+        ops, landing = [], []
+        for sp, nb, peer in ((send_lo, lo_s, rank - 1), (send_hi, hi_s, rank + 1)):
+            if sp:
+                buf = torch.empty(nb, dtype=torch.uint8)
+                if hip.hipMemcpy(buf.data_ptr(), sp, nb, D2H) != 0:
+                    return 2
+                ops.append(dist.P2POp(dist.isend, buf, peer))
+        for rp, nb, peer in ((recv_lo, lo_r, rank - 1), (recv_hi, hi_r, rank + 1)):
+            if rp:
+                buf = torch.empty(nb, dtype=torch.uint8)
+                ops.append(dist.P2POp(dist.irecv, buf, peer))
+                landing.append((rp, buf, nb))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for rp, buf, nb in landing:
+            if hip.hipMemcpy(rp, buf.data_ptr(), nb, H2D) != 0:
+                return 3
+        return 0
+
+    def max3(v):
+        t = torch.tensor([v[0], v[1], v[2]], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        for i in range(3):
+            v[i] = float(t[i])
+        return 0
+
+    def allgather(arr):
+        out = [None] * world
+        dist.all_gather_object(out, arr)
+        return out
+
+    return TransportComm(rank, world, sendrecv, max3, allgather, overlap=overlap)
+
+
+class TorchDistComm:
+    """The Python-driven schedule (ShardedValueIteration) over an initialised torch.distributed process group: nccl on
+    GPUs, gloo on CPU.  `slab_factory` replaces the compute back end (the CPU tests inject an oracle-backed slab; the
+    product never does)."""
+
+    def __init__(self, dist, slab_factory=None, overlap=True):
+        self.dist, self.slab_factory, self.overlap = dist, slab_factory, bool(overlap)
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def engine(self, dp):
+        return _TorchEngine(dp, self)
+
+
+class _LibraryEngine:
+    """What DynamicProgramming drives (the subset of _native.Problem it uses) on a pvi_shard."""
+
+    sharded = True
+
+    def __init__(self, dp, comm, transport, allgather):
+        self.vi = RcclValueIteration(dp.grid_sys, dp.cf, comm.rank, comm.world, comm_id=getattr(comm, "comm_id", None),
+                                     dtype=dp.dtype, device=dp.device, overlap=comm.overlap, transport=transport,
+                                     hard_inf=dp.HARD_INF)
+        self.shard, self.tier, self.rows = self.vi.shard, self.vi.tier, self.vi.rows
+        self.world, self._allgather = comm.world, allgather
+        self.plane = self.shard.plane
+        self.dynamics_id = self.shard._desc_owner.dynamics_id
+
+    def terminal_cost(self):
+        if self.tier == "fused":
+            self.shard.terminal_cost()
+        else:                               # table tier: J0 = cf.h(x) of this rank's rows, evaluated in the constructor
+            self.shard.set_J(self.vi.J0_rows)
+
+    def set_J(self, J_whole):
+        J = np.asarray(J_whole, dtype=float).ravel()
+        self.shard.set_J(J[self.rows[0] * self.plane:self.rows[1] * self.plane])
+
+    def _whole(self, lib_gather, own):
+        if self._allgather is None or self.world == 1:
+            return lib_gather()
+        return np.concatenate(self._allgather(own()))
+
+    def get_J(self, prev=False):
+        return self._whole(lambda: self.shard.gather_J(prev), lambda: self.shard.get_J(prev=prev))
+
+    def get_pi(self):
+        return self._whole(self.shard.gather_pi, self.shard.get_pi)
+
+    def sweep(self, max_sweeps, alpha, tol, every=False):
+        """-> (statistics rows of the sweeps that took them, sweeps done)"""
+        self.shard.stats_every_sweep(every)
+        _, n = self.shard.sweep(max_sweeps, alpha, tol)
+        return self.shard.sweep_history(max(n, 1)), n
+
+    def describe(self):
+        return self.shard.describe()
+
+    def close(self):
+        self.shard.close()
+
+
+class _TorchEngine:
+    sharded = True
+
+    def __init__(self, dp, comm):
+        self.vi = ShardedValueIteration(dp.grid_sys, dp.cf, comm.dist, dtype=dp.dtype, device=dp.device,
+                                        slab_factory=comm.slab_factory, overlap=comm.overlap)
+        self.tier, self.rows, self.world = "fused", self.vi.rows, comm.world
+        self.dynamics_id = None
+
+    def terminal_cost(self):
+        self.vi.slab.terminal_cost()
+        self.vi.exchange()
+
+    def set_J(self, J_whole):
+        self.vi.set_J(J_whole)
+
+    def get_J(self, prev=False):
+        return self.vi.gather(prev)[0]
+
+    def get_pi(self):
+        return self.vi.gather()[1]
+
+    def sweep(self, max_sweeps, alpha, tol, every=False):
+        rows = []
+        n = 0
+        for i in range(max_sweeps):
+            last = i == max_sweeps - 1
+            st = self.vi.sweep(alpha, want_stats=(tol >= 0 or last or every))
+            n += 1
+            if st is not None:
+                rows.append(st)
+                if tol >= 0 and st[3] <= tol:
+                    break
+        return np.array(rows, dtype=float).reshape(-1, 4), n
+
+    def describe(self):
+        return "torch.distributed schedule, %s" % (self.vi.slab.describe() if hasattr(self.vi.slab, "describe") else "")
+
+    def close(self):
+        if hasattr(self.vi.slab, "close"):
+            self.vi.slab.close()

@@ -61,20 +61,33 @@ class _Driver:
         self.fallback_reason = None
         self.vi = None
         if not via_torch:
-            err = None
+            # Everything that can fail on ONE rank without a peer -- the library, RCCL's dlopen, the device -- is tried
+            # and agreed on BEFORE the first RCCL collective (ncclCommInitRank inside pvi_shard_create): a rank that
+            # cannot get there must not leave the others waiting in it.  pvi_shard_create itself then agrees on the halo
+            # and on every rank having built its slab, so its failures are seen by all ranks too.
+            err, my_id = None, None
             try:
-                ids = [_native.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(ids, src=0)
-                self.vi = parallel.RcclValueIteration(g, cfg["cf"], rank, world, comm_id=ids[0], dtype=cfg["dtype"], device=local)
-                self.vi.run(1, 1.0, -1.0)                 # one whole sweep: exchange + all-reduce have run
-            except Exception as e:                        # noqa: BLE001 -- any failure selects the other transport
+                my_id = _native.comm_unique_id()          # loads librccl and talks to the device on EVERY rank
+                if _native.device_count() <= local:
+                    raise RuntimeError("no HIP device %d" % local)
+            except Exception as e:                        # noqa: BLE001
                 err = "%s: %s" % (type(e).__name__, e)
+            if _agree(dist, torch, err is None):
+                try:
+                    ids = [my_id if rank == 0 else None]
+                    dist.broadcast_object_list(ids, src=0)
+                    self.vi = parallel.RcclValueIteration(g, cfg["cf"], rank, world, comm_id=ids[0], dtype=cfg["dtype"], device=local)
+                    self.vi.run(1, 1.0, -1.0)             # one whole sweep: exchange + all-reduce have run
+                except Exception as e:                    # noqa: BLE001 -- a failure here is collective (see above)
+                    err = "%s: %s" % (type(e).__name__, e)
             if _agree(dist, torch, err is None):
                 vi = self.vi
                 self.run = lambda n: list(vi.run(n, 1.0, -1.0)[0])
                 desc = vi.describe()
                 self.halo, self.p2p, self.overlap, self.describe = vi.halo, "send/recv" in desc, "+overlap" in desc, vi.describe
                 self.collectives = "RCCL inside libpyrovi (pvi_shard_*)"
+                self.timing = vi.shard.timing
+                self.rccl_ranks = int(desc.split("rccl_ranks=")[1].split()[0]) if "rccl_ranks=" in desc else None
                 return
             errs = [None] * world
             dist.all_gather_object(errs, err)
@@ -87,6 +100,7 @@ class _Driver:
         self.run = lambda n: vi.run(n, 1.0, -1.0)
         self.halo, self.p2p, self.overlap, self.describe = vi.halo, vi.p2p, vi.overlap, vi.slab.describe
         self.collectives = "torch.distributed (nccl)"
+        self.timing, self.rccl_ranks = None, None
 
     def close(self):
         with contextlib.suppress(Exception):
@@ -118,7 +132,21 @@ def _timed(drv, dist, torch, steps, warmup):
     return elapsed, batches, st
 
 
-def _fragment(cfg, drv, world, steps, warmup, elapsed, batches, st, setup_s):
+def _rank_timing(drv, dist, world):
+    """Every rank's per-sweep GPU times of the last timed batch (pvi_shard_timing: HIP events on the rank's compute and
+    comm streams), gathered so that rank 0 can print them: kernel time split into boundary and interior pieces, the
+    exchange, and the part of the exchange the interior kernel did not hide."""
+    mine = drv.timing() if drv.timing else None
+    out = [None] * world
+    dist.all_gather_object(out, mine)
+    if any(t is None for t in out):
+        return None
+    keys = ("boundary_ms", "interior_ms", "exchange_ms", "exposed_exchange_ms", "sweep_ms")
+    return {"source": "HIP events per rank (pvi_shard_timing), mean over the last %d sweeps of the last batch" % out[0]["sweeps_timed"],
+            **{"kernel_" + k if k in ("boundary_ms", "interior_ms") else k: [round(float(t[k]), 4) for t in out] for k in keys}}
+
+
+def _fragment(cfg, drv, world, steps, warmup, elapsed, batches, st, setup_s, per_rank=None):
     g = cfg["grid_sys"]
     N, A = g.nodes_n, g.actions_n
     w = 4 if cfg["dtype"] == "float32" else 8
@@ -139,7 +167,13 @@ def _fragment(cfg, drv, world, steps, warmup, elapsed, batches, st, setup_s):
                      "note": "whole-step rate of all ranks incl. halo exchange and all-reduce against N x 8 TB/s; "
                              "per-kernel figures and counters are in the N=1 line"},
         "last_stats": [float(v) for v in st], "kernel_path": drv.describe(),
+        "rccl_ranks": drv.rccl_ranks, "per_rank": per_rank,
     }
+    if per_rank:
+        k = [b + i for b, i in zip(per_rank["kernel_boundary_ms"], per_rank["kernel_interior_ms"])]
+        out["kernel_ms_max_rank"] = max(k)
+        out["exposed_exchange_ms_max_rank"] = max(per_rank["exposed_exchange_ms"])
+        out["overlap_efficiency"] = 1.0 - max(per_rank["exposed_exchange_ms"]) / max(max(per_rank["exchange_ms"]), 1e-9)
     if drv.fallback_reason:
         out["in_library_rccl_error"] = drv.fallback_reason
     return out
@@ -182,7 +216,8 @@ def run(args):
         torch.cuda.synchronize()
         setup_s = time.perf_counter() - t0
         elapsed, batches, st = _timed(drv, dist, torch, steps, warmup)
-        frag = _fragment(cfg, drv, world, steps, warmup, elapsed, batches, st, setup_s)
+        per_rank = _rank_timing(drv, dist, world)
+        frag = _fragment(cfg, drv, world, steps, warmup, elapsed, batches, st, setup_s, per_rank)
         drv.close()
         return frag, ref
 
@@ -201,17 +236,23 @@ def run(args):
             out["value_1gpu_same_workload"] = ref
             out["strong_scaling_speedup"] = out["value"] / ref if ref else None
     if args.workload is None and not args.no_secondary:
-        # BASELINE configs[3] over the same ranks: strong scaling
+        # BASELINE configs[3] over the same ranks: strong scaling.  A secondary line must not take the headline down,
+        # and the ranks must leave it TOGETHER: whatever one rank caught, all of them agree on before going on.
+        frag, ref, err = None, None, None
         try:
             frag, ref = one("c4", max(5, steps // 2), 2, 3)
-            if rank == 0:
+        except Exception as e:                            # noqa: BLE001
+            err = "%s: %s" % (type(e).__name__, e)
+        errs = [None] * world
+        dist.all_gather_object(errs, err)
+        if rank == 0:
+            if any(errs):
+                out["secondary"] = {"c4": {"error": "; ".join("rank %d: %s" % (r, e) for r, e in enumerate(errs) if e)}}
+            else:
                 frag["scaling"] = "strong"
                 frag["value_1gpu_same_workload"] = ref
                 frag["strong_scaling_speedup"] = frag["value"] / ref if ref else None
                 out["secondary"] = {"c4": frag}
-        except Exception as e:                            # noqa: BLE001 -- a secondary line must not take the headline down
-            if rank == 0:
-                out["secondary"] = {"c4": {"error": "%s: %s" % (type(e).__name__, e)}}
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     _barrier(dist, torch)

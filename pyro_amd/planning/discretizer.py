@@ -334,6 +334,19 @@ def host_parallel_rows(obj, method, n_rows, n_calls, min_calls=200000):
         _FORK_TARGET.pop("obj", None)
 
 
+def device_cost_of(cost_function, sys):
+    """The in-kernel description of `cost_function` on `sys` (dict for _native.Problem), or None when the cost has to go
+    through the look-up tables.  A domain-check / reachability cost tests states against a SYSTEM's validity: in-kernel
+    that is the validity of the grid's own system (box + its obstacle list), so the cost must be bound to exactly that
+    system's stock isavalidstate -- one bound to another system, or to a wrapped test, is arbitrary Python."""
+    cost = cost_function.device_cost() if hasattr(cost_function, "device_cost") else None
+    if cost is not None and cost.get("kind") in ("quadratic_domain", "reachability"):
+        test = cost_function.isavalidstate if cost["kind"] == "quadratic_domain" else cost_function.isavalidestate
+        if cost.pop("validity_of", None) is not sys or getattr(test, "__func__", None) is not getattr(sys.isavalidstate, "__func__", 0):
+            return None
+    return cost
+
+
 def device_dynamics_of(sys):
     """(dynamics_id, params) when `sys` can be evaluated in-kernel: it must say so itself
     (device_dynamics()) AND keep the plain box validity tests the kernels implement."""
@@ -358,6 +371,8 @@ def device_dynamics_of(sys):
             return None
         if type(sys).device_obstacles is not owner.device_obstacles:
             return None
+        if len(np.asarray(sys.device_obstacles()["boxes"], dtype=float).reshape(-1, 4)) > _native.PVI_MAX_OBS:
+            return None             # more boxes than the descriptor holds: the look-up tables take any number
     return fn()
 
 

@@ -11,8 +11,14 @@ Two device tiers behind one API:
   table  : any other sys / cf -> x_next_table and G are built on the host exactly like the
            reference (Python loops over sys.f / cf.g), uploaded once; sweeps run on the GPU.
 
-Extra keyword arguments (not in the reference): dtype ('float64' default, 'float32'), device.
+Extra keyword arguments (not in the reference): dtype ('float64' default, 'float32'), device, comm.
 J, pi, J_next are NumPy views of device state, fetched on access.
+
+Multi-GPU: `comm=` (pyro_amd.parallel.RcclComm(rank, world, comm_id) | TransportComm | TorchDistComm) shards the grid
+by axis-0 slabs over the ranks of the communicator, one process per GPU; every method keeps its meaning and every rank
+calls it (they are collective): compute_steps / solve_bellman_equation stop at the same sweep everywhere, J / pi / J_next
+are the WHOLE grid on every rank (gathered on access), clean_infeasible_set / get_lookup_table_controller / save_latest
+work on those.
 """
 import time
 
@@ -20,7 +26,7 @@ import numpy as np
 
 from pyro_amd import _native
 from pyro_amd.control import controller
-from pyro_amd.planning.discretizer import device_dynamics_of
+from pyro_amd.planning.discretizer import device_cost_of, device_dynamics_of
 
 
 class LookUpTableController(controller.StaticController):
@@ -60,31 +66,55 @@ class DynamicProgramming:
     BATCH = 256                     # sweeps enqueued per host round trip when no history is kept
     INTERPOLATION = "linear"        # interpolant of J_k between the nodes (discretizer.py:570-587)
 
-    def __init__(self, grid_sys, cost_function, final_time=0, dtype="float64", device=0):
+    def __init__(self, grid_sys, cost_function, final_time=0, dtype="float64", device=0, comm=None):
         self.grid_sys, self.sys = grid_sys, grid_sys.sys
         self.cf, self.tf = cost_function, final_time
         self.alpha = 1.0
-        self.interpol_method = "linear"
         self.save_time_history = True
         self.verbose = True
         self.t, self.k = self.tf, 0
         self.start_time = time.time()
-        self.dtype, self.device = np.dtype(dtype), device
+        self.dtype, self.device, self.comm = np.dtype(dtype), device, comm
         self._make_engine()
+        self.interpol_method = self.INTERPOLATION
         self.evaluate_terminal_cost()
         self.t_list, self.J_list, self.pi_list = [], [], []
         if self._history_ok():
             self.t_list, self.J_list, self.pi_list = [self.tf], [self.J], [self.pi]
 
     # ------------------------------------------------------------------ device engine
+    # interpolants of J_k the sweeps implement (discretizer.py:570-587 hands dp.interpol_method to RegularGridInterpolator
+    # every sweep; 'bicubic' is this build's name for the RectBivariateSpline subclass, dynamicprogramming.py:578-614)
+    _INTERPOLATIONS = ("linear", "bicubic")
+
+    @property
+    def interpol_method(self):
+        return self.__dict__.get("_interpol_method", "linear")
+
+    @interpol_method.setter
+    def interpol_method(self, value):
+        """The reference passes dp.interpol_method to the interpolant of every sweep; here the interpolation is compiled
+        into the kernel the engine was built with, so a value that engine does not implement ('nearest', 'cubic', ...,
+        or switching kind after construction) raises instead of silently computing with another interpolant."""
+        if value not in self._INTERPOLATIONS:
+            raise NotImplementedError("interpol_method %r: the GPU sweeps implement %s" % (value, ", ".join(self._INTERPOLATIONS)))
+        if "_p" in self.__dict__ and value != self.INTERPOLATION:
+            raise NotImplementedError("interpol_method %r on a %s engine: use %s" % (
+                value, self.INTERPOLATION, "DynamicProgramming2DRectBivariateSpline" if value == "bicubic"
+                else "DynamicProgrammingWithLookUpTable"))
+        self.__dict__["_interpol_method"] = value
+
     def _make_engine(self):
+        self._host = {}             # cached downloads: 'J', 'pi', 'J_next'
+        self._dirty = False         # host J newer than the device copy
+        if self.comm is not None:
+            if self.INTERPOLATION != "linear":
+                raise NotImplementedError("the spline fit couples every row of the grid: single-GPU only")
+            self._p = self.comm.engine(self)
+            self.tier = self._p.tier
+            return
         dd = device_dynamics_of(self.sys)
-        cost = self.cf.device_cost() if hasattr(self.cf, "device_cost") else None
-        if cost is not None and cost.get("kind") in ("quadratic_domain", "reachability"):
-            # the in-kernel domain check tests the node against the SYSTEM's validity: it must be this system's own
-            test = self.cf.isavalidstate if cost["kind"] == "quadratic_domain" else self.cf.isavalidestate
-            if cost.pop("validity_of", None) is not self.sys or getattr(test, "__func__", None) is not getattr(self.sys.isavalidstate, "__func__", 0):
-                cost = None
+        cost = device_cost_of(self.cf, self.sys)
         self.tier = "fused" if (dd is not None and cost is not None) else "table"
         if self.INTERPOLATION != "linear" and dd is not None and dd[0] != _native.DYN_PENDULUM:
             self.tier = "table"         # the spline sweep has in-kernel dynamics for the pendulum family only
@@ -104,8 +134,10 @@ class DynamicProgramming:
             self._p.set_tables(g.x_next_table, self._host_cost_table(), ok)
         if self.tier == "fused" and self.INTERPOLATION != "linear":
             self._p.set_interpolation(self.INTERPOLATION)
-        self._host = {}             # cached downloads: 'J', 'pi', 'J_next'
-        self._dirty = False         # host J newer than the device copy
+
+    @property
+    def sharded(self):
+        return bool(getattr(self._p, "sharded", False))
 
     def _cost_rows(self, lo, hi):
         g = self.grid_sys
@@ -171,8 +203,8 @@ class DynamicProgramming:
     # ------------------------------------------------------------------ reference API
     def evaluate_terminal_cost(self):
         """J = cf.h(x, tf), pi = 0 (dynamicprogramming.py:159-171)."""
-        if self.tier == "fused":
-            self._p.terminal_cost()
+        if self.tier == "fused" or self.sharded:
+            self._p.terminal_cost()         # (sharded table tier: every rank evaluates cf.h on its own rows)
             self._invalidate()
         else:
             X = self.grid_sys.state_from_node_id
@@ -196,12 +228,20 @@ class DynamicProgramming:
         delta, done = None, 0
         while done < max_sweeps:
             nb = 1 if self._history_ok() else min(self.BATCH, max_sweeps - done)
-            stats, n = self._p.sweep(nb, self.alpha, tol)
+            if self.sharded:
+                # statistics cost a host synchronisation + an all-reduce per sweep on a sharded grid: every sweep when
+                # they are printed or tested (verbose, tol), else only the last of the batch
+                stats, n = self._p.sweep(nb, self.alpha, tol, every=self.verbose)
+                quiet = n - len(stats)
+                self.k += quiet
+                self.t -= self.grid_sys.dt * quiet
+            else:
+                stats, n = self._p.sweep(nb, self.alpha, tol)
             self._invalidate()
-            for i in range(n):
+            for st in stats:
                 self.k += 1
                 self.t -= self.grid_sys.dt
-                delta = self._report(stats[i])
+                delta = self._report(st)
             done += n
             if self.save_time_history and n:
                 self.J_list.append(self.J)
@@ -224,7 +264,7 @@ class DynamicProgramming:
 
     def compute_backward_step(self):
         self._flush()
-        self._last_stats, n = self._p.sweep(1, self.alpha, -1.0)
+        self._last_stats, n = self._p.sweep(1, self.alpha, -1.0)[:2]
         self._invalidate()
         self.k += 1
         self.t -= self.grid_sys.dt
@@ -293,7 +333,7 @@ class DynamicProgramming:
         (controller.py:328-355, simulation.py:298-324).  Returns t [n], X [B,n,sys.n], U [B,n,sys.m]."""
         dt = (tf + 0.0) / (n - 1)
         t = np.linspace(0, tf, n)
-        closed_form = self.tier == "fused" and self._p.dynamics_id in _native.CLOSED_FORM_IDS
+        closed_form = self.tier == "fused" and not self.sharded and self._p.dynamics_id in _native.CLOSED_FORM_IDS
         if closed_form:
             self._p.set_pi(self.pi)             # the host policy may have been edited (clean_infeasible_set)
             X, U = self._p.rollout(X0, n, dt)
@@ -417,7 +457,11 @@ class DynamicProgrammingWithLookUpTable(DynamicProgramming):
     def compute_cost_lookuptable(self):
         t0 = time.time()
         print("Computing g(x,u,t) look-up table..  ", end="")
-        if self.tier == "fused":
+        if self.tier == "fused" and self.sharded:
+            p = self.grid_sys._device_problem(cost=device_cost_of(self.cf, self.sys), device=self.device)
+            self.__dict__["_G"] = p.build_tables(x_next=False, x_next_isok=False, action_isok=False)[3]
+            p.close()
+        elif self.tier == "fused":
             self.__dict__["_G"] = self._p.build_tables(x_next=False, x_next_isok=False, action_isok=False)[3]
         else:
             self.__dict__["_G"] = self._host_cost_table()
@@ -431,11 +475,10 @@ class DynamicProgramming2DRectBivariateSpline(DynamicProgrammingWithLookUpTable)
 
     INTERPOLATION = "bicubic"
 
-    def __init__(self, grid_sys, cost_function, final_time=0, dtype="float64", device=0):
+    def __init__(self, grid_sys, cost_function, final_time=0, dtype="float64", device=0, comm=None):
         if grid_sys.sys.n != 2:
             raise NotImplementedError                   # discretizer.py:599-610
-        super().__init__(grid_sys, cost_function, final_time, dtype=dtype, device=device)
-        self.interpol_method = "bicubic"
+        super().__init__(grid_sys, cost_function, final_time, dtype=dtype, device=device, comm=comm)
 
     @property
     def J_interpol(self):

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libpyrovi.so does not export %s" % name
     assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
-    assert L.pvi_abi_version() == 2
+    assert L.pvi_abi_version() == _native.ABI_VERSION == 3
 
 
 def test_sanitized_library_is_rebuilt_with_the_product_library():

@@ -1590,6 +1590,29 @@ def test_rccl_shard_world1_equals_plain_handle(tmp_path, case, overlap):
 
 
 @pytest.mark.gpu
+def test_class_surface_over_a_one_rank_rccl_communicator():
+    """comm=RcclComm(0, 1, id): a real RCCL communicator of one rank behind the class surface -- ncclCommCount is
+    reported, J / pi come through pvi_shard_gather_*, the timing of the last call is filled in, results equal the plain
+    class."""
+    from pyro_amd import _native, configs, parallel
+    from pyro_amd.planning import dynamicprogramming
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg = configs.build("cartpole:21,21,21,21:7:float32")
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(
+            cfg["grid_sys"], cfg["cf"], dtype="float32", comm=parallel.RcclComm(0, 1, _native.comm_unique_id()))
+        one = dynamicprogramming.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype="float32")
+        for d in (dp, one):
+            d.save_time_history = False
+            d.compute_steps(7)
+    desc = dp._p.describe()
+    assert "comm=rccl" in desc and "rccl_ranks=1" in desc
+    assert np.array_equal(dp.J, one.J) and np.array_equal(dp.pi, one.pi) and np.array_equal(dp.J_next, one.J_next)
+    t = dp._p.shard.timing()
+    assert t["sweeps_timed"] == 7 and t["interior_ms"] > 0 and t["exposed_exchange_ms"] >= 0
+    dp._p.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case,world,overlap", [("cartpole:21,21,21,21:7:float32", 2, True),
                                                 ("cartpole:21,21,21,21:7:float32", 3, True),
                                                 ("pendulum:101,101:11:float32", 2, False)])
@@ -1627,39 +1650,8 @@ sys.path.insert(0, %(root)r)
 from pyro_amd import configs, parallel
 rank, world, case, port, out, overlap = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6])
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world)
-hip = C.CDLL("libamdhip64.so")
-hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-hip.hipStreamSynchronize.argtypes = [C.c_void_p]
-D2H, H2D = 2, 1
-
-
-def sendrecv(send_lo, recv_lo, lo_s, lo_r, send_hi, recv_hi, hi_s, hi_r, stream):
-    # host-staged halo exchange over gloo: what an MPI transport without GPU-aware buffers would do
-    assert hip.hipStreamSynchronize(stream) == 0
-    ops, landing = [], []
-    for sp, nb, peer in ((send_lo, lo_s, rank - 1), (send_hi, hi_s, rank + 1)):
-        if sp:
-            buf = torch.empty(nb, dtype=torch.uint8)
-            assert hip.hipMemcpy(buf.data_ptr(), sp, nb, D2H) == 0
-            ops.append(dist.P2POp(dist.isend, buf, peer))
-    for rp, nb, peer in ((recv_lo, lo_r, rank - 1), (recv_hi, hi_r, rank + 1)):
-        if rp:
-            buf = torch.empty(nb, dtype=torch.uint8)
-            ops.append(dist.P2POp(dist.irecv, buf, peer))
-            landing.append((rp, buf, nb))
-    for w in dist.batch_isend_irecv(ops):
-        w.wait()
-    for rp, buf, nb in landing:
-        assert hip.hipMemcpy(rp, buf.data_ptr(), nb, H2D) == 0
-    return 0
-
-
-def max3(v):
-    t = torch.tensor([v[0], v[1], v[2]], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    for i in range(3):
-        v[i] = float(t[i])
-    return 0
+tc = parallel.staged_transport(dist, rank, world)       # host-staged halo exchange over gloo
+sendrecv, max3 = tc.sendrecv, tc.max3
 
 
 with contextlib.redirect_stdout(io.StringIO()):
@@ -1668,7 +1660,19 @@ with contextlib.redirect_stdout(io.StringIO()):
         from table_case import table_case
         cfg = table_case()
     else:
-        cfg = configs.build(case)
+        cfg = configs.build(case.split(":", 1)[1] if case.startswith("halo-mismatch:") else case)
+if case.startswith("halo-mismatch:"):
+    # one width for the whole grid: ranks that pass different widths must ALL be refused (no hang, no wrong rows)
+    try:
+        parallel.RcclValueIteration(cfg["grid_sys"], cfg["cf"], rank, world, dtype=cfg["dtype"], halo=2 + rank,
+                                    transport=(sendrecv, max3))
+    except Exception as e:
+        assert "halo_rows differs" in str(e), e
+        np.savez(out, refused=True)
+        dist.destroy_process_group()
+        print("TRANSPORT-RANK-OK", rank)
+        sys.exit(0)
+    raise SystemExit("a per-rank halo width was accepted")
 vi = parallel.RcclValueIteration(cfg["grid_sys"], cfg["cf"], rank, world, dtype=cfg["dtype"], overlap=bool(overlap),
                                  transport=(sendrecv, max3))
 st5, n5 = vi.run(5, 1.0, -1.0)
@@ -1686,7 +1690,8 @@ print("TRANSPORT-RANK-OK", rank)
                                                     ("cartpole:21,21,21,21:7:float32", 2, True, -1.0),
                                                     ("cartpole:21,21,21,21:7:float32", 3, True, 0.5),
                                                     ("pendulum:101,101:11:float64", 2, False, 0.5),
-                                                    ("pendulum:101,101:11:float32", 4, True, -1.0)])
+                                                    ("pendulum:101,101:11:float32", 4, True, -1.0),
+                                                    ("halo-mismatch:pendulum:41,41:5:float32", 2, True, -1.0)])
 def test_c_shard_schedule_with_caller_transport_on_one_gpu(tmp_path, case, world, overlap, tol):
     """The slab schedule of pvi_shard_sweep itself -- partition, boundary / interior handles over shared buffers, the
     two streams and events, which rows go to which neighbour, the stop test on all-reduced statistics -- with 2-4 ranks
@@ -1712,6 +1717,9 @@ def test_c_shard_schedule_with_caller_transport_on_one_gpu(tmp_path, case, world
             raise
         assert p.returncode == 0 and ("TRANSPORT-RANK-OK %d" % r) in o, o[-3000:]
     parts = [np.load(tmp_path / ("t%d.npz" % r)) for r in range(world)]
+    if case.startswith("halo-mismatch:"):
+        assert all(bool(p["refused"]) for p in parts)
+        return
     assert "comm=caller" in str(parts[0]["desc"]) and ("+overlap" in str(parts[0]["desc"])) == bool(overlap)
     if case == "python-system":
         # an arbitrary Python system (table tier): every rank built the look-up tables of its own rows; the sharded
@@ -1735,6 +1743,91 @@ def test_c_shard_schedule_with_caller_transport_on_one_gpu(tmp_path, case, world
     for p in parts:
         assert int(p["n"]) == n and np.allclose(p["st"], st[-1], rtol=1e-12) and np.allclose(p["st5"], st5[-1], rtol=1e-12)
     h.close()
+
+
+_SURFACE_RANK = r"""
+import contextlib, io, os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from pyro_amd import configs, parallel
+from pyro_amd.planning import dynamicprogramming
+rank, world, port, out, dtype = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world)
+with contextlib.redirect_stdout(io.StringIO()) as log:
+    cfg = configs.build("c1")
+    dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype=dtype,
+                                                              comm=parallel.staged_transport(dist, rank, world))
+    dp.save_time_history = False
+    assert dp.sharded and dp.tier == "fused" and "comm=caller" in dp._p.describe()
+    dp.compute_steps(3)
+    dp.solve_bellman_equation(tol=0.1)
+    J, pi, Jn, k = dp.J.copy(), dp.pi.copy(), dp.J_next.copy(), dp.k
+    u = dp.get_lookup_table_controller().c(np.array([-1.0, 0.5]), None)
+    dp.clean_infeasible_set()
+    Jc, pic = dp.J.copy(), dp.pi.copy()
+    dp.verbose = False
+    dp.compute_steps(2)                     # the cleaned J went back to every slab; quiet batch of two
+    J2, k2 = dp.J.copy(), dp.k
+    dp.save_latest(out + "_latest")
+np.savez(out, J=J, pi=pi, Jn=Jn, k=k, u=u, Jc=Jc, pic=pic, J2=J2, k2=k2, lines=log.getvalue().count(" max: "))
+dp._p.close()
+dist.destroy_process_group()
+print("SURFACE-RANK-OK", rank)
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_sharded_class_surface_solves_config1(tmp_path, dtype):
+    """VERDICT r2 row b': DynamicProgrammingWithLookUpTable(grid_sys, cf, comm=...) over two ranks (the library's slab
+    schedule, host-staged transport because both ranks share the one GPU): compute_steps, solve_bellman_equation, J, pi,
+    J_next, clean_infeasible_set, get_lookup_table_controller and save_latest as on one GPU -- config 1 stops after the
+    reference's 618 sweeps with the reference's J* and pi* (float64; float32 within 1e-5 and the same sweep count as the
+    one-GPU float32 solve)."""
+    import subprocess
+    import sys as _sys
+    from pyro_amd import configs
+    from pyro_amd.planning import dynamicprogramming
+    g = load("config1_pendulum_101x101x11")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "surface_rank.py"
+    script.write_text(_SURFACE_RANK % dict(root=root))
+    port = str(29300 + (os.getpid() + (7 if dtype == "float32" else 0)) % 300)
+    procs = [subprocess.Popen([_sys.executable, str(script), str(r), "2", port, str(tmp_path / ("s%d.npz" % r)), dtype],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    for r, p in enumerate(procs):
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0 and ("SURFACE-RANK-OK %d" % r) in o, o[-3000:]
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg = configs.build("c1")
+        one = dynamicprogramming.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype=dtype)
+        one.save_time_history = False
+        one.solve_bellman_equation(tol=0.1)
+        J1, pi1, Jn1, k1 = one.J.copy(), one.pi.copy(), one.J_next.copy(), one.k
+        u1 = one.get_lookup_table_controller().c(np.array([-1.0, 0.5]), None)
+        one.clean_infeasible_set()
+        Jc1, pic1 = one.J.copy(), one.pi.copy()
+        one.compute_steps(2)
+    for r in range(2):
+        p = np.load(tmp_path / ("s%d.npz" % r))
+        # sharded == one GPU, bit for bit, in either dtype
+        assert int(p["k"]) == k1 and int(p["k2"]) == k1 + 2 and int(p["lines"]) == k1
+        assert np.array_equal(p["J"], J1) and np.array_equal(p["pi"], pi1) and np.array_equal(p["Jn"], Jn1)
+        assert np.array_equal(p["Jc"], Jc1) and np.array_equal(p["pic"], pic1) and np.array_equal(p["u"], u1)
+        assert np.array_equal(p["J2"], one.J)
+        assert np.array_equal(np.load(str(tmp_path / ("s%d.npz" % r)) + "_latest_J_inf.npy"), one.J_next)
+        # ... and the reference's result
+        if dtype == "float64":
+            assert int(p["k"]) == int(g["sweeps"]) == 618
+            assert relerr(p["J"], g["J"]) < 1e-12 and np.array_equal(p["pi"], g["pi"].astype(np.int64))
+        else:
+            assert relerr(p["J"], g["J"]) <= REL_F32
 
 
 @pytest.mark.gpu

@@ -53,11 +53,35 @@ class OracleSlab:
     def rows_view(self, row0, nrows):
         return self.t[self.cur][row0 * self.plane:(row0 + nrows) * self.plane]
 
-    def owned_J(self):
-        return self.buf[self.cur][self.ids].copy()
+    def owned_J(self, prev=False):
+        return self.buf[self.cur ^ (1 if prev else 0)][self.ids].copy()
+
+    def set_owned_J(self, J):
+        self.buf[self.cur][:] = np.nan
+        self.buf[self.cur][self.ids] = J
 
     def owned_pi(self):
         return self.pi
+
+
+class COracleSlab(OracleSlab):
+    """The same slab on the oracle's C twin (bit-identical to the NumPy oracle, tests/test_c_oracle.py): for the
+    618-sweep solve."""
+
+    def __init__(self, *a):
+        super().__init__(*a)
+        from oracle import c_oracle as CO
+        self.c = CO.CProblem(self.p)
+
+    def sweep(self, alpha):
+        Jc = self.buf[self.cur]
+        Jn, self.pi = self.c.sweep(np.nan_to_num(Jc, nan=np.nan), alpha, int(self.ids[0]), int(self.ids[-1]) + 1, threads=1)
+        nxt = self.buf[self.cur ^ 1]
+        nxt[:] = np.nan
+        nxt[self.ids] = Jn
+        d = Jn - Jc[self.ids]
+        self._st = np.array([Jn.max(), d.max(), d.min()])
+        self.cur ^= 1
 
 
 def _free_port():
@@ -188,3 +212,156 @@ def test_weak_scaling_family_is_c3_per_rank():
     with contextlib.redirect_stdout(io.StringIO()):
         g1 = configs.build("c3w", world=1)["grid_sys"]
     assert all(np.array_equal(a, b) for a, b in zip(g1.x_level, c3.x_level))
+
+
+# ---- the reference's class surface over a sharded grid (VERDICT r2 row b') ---------------------------------------------
+def _surface_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from pyro_amd import parallel
+    from pyro_amd.planning import dynamicprogramming
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        cfg = _build("c1")
+        with contextlib.redirect_stdout(io.StringIO()) as log:
+            dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(
+                cfg["grid_sys"], cfg["cf"], comm=parallel.TorchDistComm(dist, slab_factory=COracleSlab))
+            dp.save_time_history = False
+            assert dp.sharded and dp.tier == "fused"
+            J0 = dp.J.copy()
+            dp.compute_steps(3)
+            k3, J3 = dp.k, dp.J.copy()
+            dp.solve_bellman_equation(tol=0.1)
+            J, pi, Jn, k = dp.J.copy(), dp.pi.copy(), dp.J_next.copy(), dp.k
+            ctl = dp.get_lookup_table_controller()
+            u = [float(ctl.c(np.array(x), None)[0]) for x in ([-1.0, 0.5], [2.0, -3.0], [7.0, 0.0])]
+            dp.clean_infeasible_set()
+            Jc, pic = dp.J.copy(), dp.pi.copy()
+            dp.save_latest(out + ".r%d" % rank)
+            # a host edit of J goes back to every slab: one more backup from the cleaned cost-to-go
+            dp.compute_steps(1)
+            J_after_clean = dp.J.copy()
+        np.savez(out + ".rank%d.npz" % rank, J0=J0, J3=J3, k3=k3, J=J, pi=pi, Jn=Jn, k=k, u=np.array(u), Jc=Jc, pic=pic,
+                 J_after_clean=J_after_clean, lines=np.array(log.getvalue().count(" max: ")))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_class_surface_on_two_ranks_solves_config1_like_the_reference(tmp_path):
+    """DynamicProgrammingWithLookUpTable(grid_sys, cf, comm=...) on two gloo ranks: compute_steps,
+    solve_bellman_equation, J / pi / J_next, get_lookup_table_controller, clean_infeasible_set and save_latest behave
+    as on one device -- BASELINE config 1 stops after the reference's 618 sweeps with the reference's J* and pi*
+    (dynamicprogramming.py:265-334, 472-485), on every rank."""
+    import torch.multiprocessing as mp
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "config1_pendulum_101x101x11.npz"))
+    out = str(tmp_path / "surf")
+    mp.spawn(_surface_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    cfg = _build("c1")
+    gs, cf, s = cfg["grid_sys"], cfg["cf"], cfg["sys"]
+    dyn_id, params = s.device_dynamics()
+    p = O.Problem(gs.x_level, gs.u_level, gs.dt, dyn_id, np.array(params), cf.Q, cf.R, cf.S, cf.xbar, cf.ubar, cf.INF, cf.EPS)
+    for rank in range(2):
+        r = np.load(out + ".rank%d.npz" % rank)
+        assert int(r["k3"]) == 3 and int(r["k"]) == int(g["sweeps"]) == 618
+        assert np.array_equal(r["J0"], O.terminal_cost(p))
+        assert np.abs(r["J"] - g["J"]).max() <= 1e-12 * np.abs(g["J"]).max()
+        assert np.array_equal(r["pi"], g["pi"].astype(np.int64))
+        assert np.abs(r["Jn"] - g["J_prev"]).max() <= 1e-12 * np.abs(g["J"]).max()
+        assert int(r["lines"]) == 618 + 1                         # finalize_backward_step printed every sweep
+        Jc, pic = O.clean_infeasible_set(p, r["J"], r["pi"], s.ubar)
+        assert np.array_equal(r["Jc"], Jc) and np.array_equal(r["pic"], pic)
+        for x, u in zip(([-1.0, 0.5], [2.0, -3.0], [7.0, 0.0]), r["u"]):
+            assert u == float(np.ravel(O.controller_c(p, r["pi"], np.array(x)))[0])
+        Jn, _ = O.sweep(p, Jc)
+        assert np.array_equal(r["J_after_clean"], Jn)
+        assert np.array_equal(np.load(out + ".r%d_J_inf.npy" % rank), r["Jn"])
+        assert np.array_equal(np.load(out + ".r%d_pi_inf.npy" % rank), r["pic"])
+
+
+def test_interpol_method_is_not_silently_ignored():
+    """The reference hands dp.interpol_method to the interpolant of every sweep (dynamicprogramming.py:186-189,
+    discretizer.py:570-587); a kind the kernels do not implement must raise, not compute bilinear results."""
+    from pyro_amd.planning import dynamicprogramming as DPm
+
+    class Probe(DPm.DynamicProgramming):
+        def _make_engine(self):                     # no device needed for the attribute's contract
+            self._host, self._dirty, self.tier = {}, False, "fused"
+
+            class P:
+                def terminal_cost(self): pass
+                def get_J(self, prev=False): return np.zeros(1)
+                def get_pi(self): return np.zeros(1, dtype=int)
+            self._p = P()
+    cfg = _build("pendulum:5,5:3:float64")
+    dp = Probe(cfg["grid_sys"], cfg["cf"])
+    assert dp.interpol_method == "linear"
+    dp.interpol_method = "linear"
+    for kind in ("nearest", "cubic", "slinear", "quintic", "pchip"):
+        with pytest.raises(NotImplementedError):
+            dp.interpol_method = kind
+    with pytest.raises(NotImplementedError):        # a linear engine cannot turn into the spline class by assignment
+        dp.interpol_method = "bicubic"
+    assert dp.interpol_method == "linear"
+
+
+# ---- one halo width for the whole grid (ADVICE r2, high) --------------------------------------------------------------
+def _contracting_grid():
+    from pyro_amd.dynamic import system
+    from pyro_amd.planning import discretizer
+
+    class Contracting(system.ContinuousDynamicSystem):
+        def __init__(self):
+            super().__init__(2, 1, 2)
+            self.x_ub, self.x_lb = np.array([3.0, 1.0]), np.array([-3.0, -1.0])
+
+        def f(self, x, u, t=0):
+            return np.array([-2.0 * x[0] + x[1], u[0]])
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        return discretizer.GridDynamicSystem(Contracting(), [61, 11], [3], dt=0.5)
+
+
+def test_local_halo_bounds_differ_between_ranks_and_are_reduced():
+    """A system whose axis-0 speed depends on x0 (f = [-2 x0 + x1, u]) gives every slab its own reach: the halo handed to
+    the exchange must be the LARGEST, the same on every rank (mismatched send / recv counts otherwise)."""
+    from pyro_amd import parallel
+    gs = _contracting_grid()
+    parts = parallel.partition_rows(61, 3)
+    local = [parallel.halo_rows(gs, rows) for rows in parts]
+    assert len(set(local)) > 1                                    # the per-rank bounds really differ
+    assert max(local) == parallel.halo_rows(gs)                   # ... and their maximum is the whole-grid bound
+    xn = gs._xnext_rows(parts[1][0] * 11, parts[1][1] * 11)[0]
+    assert parallel.halo_rows(gs, parts[1], xn=xn) == local[1]    # a table the caller already has is not rebuilt
+
+
+def _halo_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from pyro_amd import parallel
+    from pyro_amd.analysis import costfunction
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        gs = _contracting_grid()
+        cf = costfunction.QuadraticCostFunction.from_sys(gs.sys)
+
+        class Stub:                                               # no compute: only the constructor's halo agreement
+            def __init__(self, grid_sys, cost, dtype, rows, halo, device):
+                self.halo = halo
+
+            def terminal_cost(self):
+                pass
+        vi = parallel.ShardedValueIteration(gs, cf, dist, slab_factory=Stub)
+        res = [None] * world
+        dist.all_gather_object(res, (vi.halo, vi.p2p, parallel.halo_rows(gs, vi.rows)))
+        if rank == 0:
+            np.save(out, np.array(res, dtype=float))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_python_driver_agrees_on_one_halo(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "halo.npy")
+    mp.spawn(_halo_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    r = np.load(out)
+    assert len(set(r[:, 0])) == 1 and len(set(r[:, 1])) == 1          # one width, one exchange kind on every rank
+    assert len(set(r[:, 2])) > 1 and r[0, 0] == r[:, 2].max()         # ... although the local bounds differ
