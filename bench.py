@@ -81,17 +81,20 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(cfg, budget_s=20.0):
+def cpu_baseline(cfg, budget_s=20.0, J_start=None, depth=0):
     """Oracle C/OpenMP twin (oracle/vi_oracle.c) on the host cores, bounded sample.  One thread per physical core;
     whole sweeps inside ONE persistent parallel region (vio_sweeps: preallocated ping-pong buffers, no thread start-up
-    between sweeps) while they fit the budget, otherwise a leading slice of the nodes of one sweep.  The single-core
-    rate is measured on a slice beside it, so the line shows how the all-cores number scales.
-    Returns (record, J after `n` sweeps | None, n, slice | None)."""
+    between sweeps) while they fit the budget, otherwise a slice of the nodes of one sweep from the middle of the grid.
+    The single-core rate is measured on a slice beside it, so the line shows how the all-cores number scales.
+    `J_start`: the cost-to-go the sweeps start from -- the GPU's own J after `depth` sweeps, so that the same pass is the
+    accuracy check at depth (a sweep from J0 = h(x) checks nothing where S = 0: J0 is identically zero there).
+    Returns (record, J after `n` sweeps | None, n, slice | None, the twin)."""
     from oracle import c_oracle as CO
     p = oracle_problem(cfg)
     c = CO.CProblem(p)
     cores = max(1, min(CO.physical_cores(), usable_cpus(), CO.max_threads()))
-    J0 = c.terminal_cost()
+    J0 = c.terminal_cost() if J_start is None else np.ascontiguousarray(J_start, dtype=np.float64)
+    start = "J0 = h(x)" if J_start is None else "the GPU's J after %d sweeps" % depth
     A = p.actions_n
     cells_per_sweep = p.nodes_n * A
     # a slice from the middle of the grid (in- and out-of-box cells in their global proportion) for the probes
@@ -122,17 +125,17 @@ def cpu_baseline(cfg, budget_s=20.0):
         v = nsweeps * cells_per_sweep / dt
         rec.update(value=v, sweeps_per_sec=nsweeps / dt, scaling_vs_one_core=v / one, efficiency=v / one / cores,
                    sample="%d whole sweeps of the workload in %.1f s, one persistent OpenMP region of %d threads "
-                          "(oracle/vi_oracle.c vio_sweeps)" % (nsweeps, dt, cores))
-        return rec, J, nsweeps, None
+                          "from %s (oracle/vi_oracle.c vio_sweeps)" % (nsweeps, dt, cores, start))
+        return rec, J, nsweeps, None, c
     nodes = int(min(p.nodes_n - mid, max(4096, rate * budget_s / A)))
     t0 = time.perf_counter()
     Js, _ = c.sweep(J0, 1.0, mid, mid + nodes, threads=cores)
     dt = time.perf_counter() - t0
     v = nodes * A / dt
     rec.update(value=v, sweeps_per_sec=v / cells_per_sweep, scaling_vs_one_core=v / one, efficiency=v / one / cores,
-               sample="nodes [%d, %d) of %d, one sweep from J0, in %.1f s on %d threads (oracle/vi_oracle.c vio_sweep)"
-                      % (mid, mid + nodes, p.nodes_n, dt, cores))
-    return rec, Js, 1, (mid, mid + nodes)
+               sample="nodes [%d, %d) of %d, one sweep from %s, in %.1f s on %d threads (oracle/vi_oracle.c vio_sweep)"
+                      % (mid, mid + nodes, p.nodes_n, start, dt, cores))
+    return rec, Js, 1, (mid, mid + nodes), c
 
 
 N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9          # 256 CUs x 4 SIMDs, 2.4 GHz
@@ -189,6 +192,26 @@ def load_counters(workload):
         return {}
 
 
+def check_counters(ctr, desc):
+    """The committed PMC passes were taken with ONE kernel variant (tile shape, window layout, wave mapping: recorded with
+    them as `kernel_path`); pvi_create picks the variant of THIS run by timing.  If they differ the counters say nothing
+    about this run: they are dropped and the line says why, loudly."""
+    if not ctr:
+        return {}, None
+    keys = ("path", "tile", "win", "tables", "mapping", "sparse", "npt", "lsplit")
+    a = dict(t.split("=", 1) for t in str(ctr.get("kernel_path", "")).split() if "=" in t)
+    b = dict(t.split("=", 1) for t in desc.split() if "=" in t)
+    diff = ["%s: counters %s, this run %s" % (k, a.get(k), b.get(k)) for k in keys if k in a and a.get(k) != b.get(k)]
+    if not a:
+        diff = ["the committed counters do not record the kernel variant they were taken with"]
+    if diff:
+        msg = "PMC counters of %s do not describe this run's kernel (%s): traffic / issue / LDS objects dropped" % (
+            ctr.get("source"), "; ".join(diff))
+        print("bench.py: " + msg, file=sys.stderr)
+        return {}, msg
+    return ctr, None
+
+
 def measure(name, steps, warmup, keep_handle=False):
     """Create the problem through the class surface (timed: set-up), W warm-up sweeps, then batches of K sweeps until
     the timed region reaches MIN_REGION_S.  Returns (line fragment, cfg, handle | None)."""
@@ -225,10 +248,17 @@ def measure(name, steps, warmup, keep_handle=False):
     kern_ms = kern_ms_sum / timed
 
     alg_bytes = N * (2 * w + pbytes)
-    ctr = load_counters(cfg["name"])
+    desc = p.describe()
+    ctr, ctr_err = check_counters(load_counters(cfg["name"]), desc)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     flops_cell = {2: 30, 4: 90}[g.sys.n] if g.sys.m == 1 else 120
-    cells_per_s_kernel = N * A / (kern_ms * 1e-3)
+    # Cells whose x_next leaves the grid box cost exactly INF (Q = INF + alpha*0): the sweeps that walk set-up's validity
+    # masks (sparse=1) never evaluate them.  `value` counts every state-action cell of the grid (BASELINE's metric: each
+    # one IS updated); flop rates must only count the cells that were computed.
+    tok = dict(t.split("=", 1) for t in desc.split() if "=" in t)
+    inbox = float(tok["inbox"]) if tok.get("inbox") not in (None, "-1.0000") else None
+    walked = inbox if (inbox is not None and tok.get("sparse") == "1") else 1.0
+    cells_per_s_kernel = N * A * walked / (kern_ms * 1e-3)
     out = {
         "value": N * A * timed / elapsed, "unit": "cells/s", "steps": steps, "warmup": warmup,
         "batches": batches, "timed_steps": timed, "timed_region_s": elapsed,
@@ -243,13 +273,16 @@ def measure(name, steps, warmup, keep_handle=False):
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                      "note": "nominal: the fused sweep is instruction-issue bound (A actions per node on %d B of "
                              "compulsory traffic), see roofline_issue" % (2 * w + pbytes)},
+        "inbox_fraction": inbox, "cells_evaluated_fraction": walked,
+        "cells_evaluated_per_sec": N * A * walked * timed / elapsed,
+        "counters_error": ctr_err,
         "roofline_issue": None if not ctr.get("valu_insts_per_launch") else issue_roofline(ctr, kern_ms, N * A),
         "roofline_lds": lds_roofline(ctr, kern_ms, N * A, g.sys.n, w, w == 4 and "k_sweep_lean" in str(ctr.get("kernel", ""))),
         "flops_frac_vector_peak": {"dtype": dt_name, "peak_tflops": VALU_PEAK_TFLOPS[dt_name],
-                                   "algorithmic_flops_per_cell": flops_cell,
+                                   "algorithmic_flops_per_cell": flops_cell, "cells": "evaluated cells only",
                                    "frac": cells_per_s_kernel * flops_cell / (VALU_PEAK_TFLOPS[dt_name] * 1e12)},
         "last_stats": [float(v) for v in stats[-1]],
-        "kernel_path": p.describe(),
+        "kernel_path": desc,
     }
     ref = REFERENCE_NUMPY_SWEEPS_PER_SEC.get(cfg["name"])
     if ref:
@@ -263,14 +296,61 @@ def measure(name, steps, warmup, keep_handle=False):
     return out, cfg, p
 
 
-def accuracy_vs_cpu(p, J_cpu, n_cmp, rows):
-    """max |J_gpu - J_cpu| / max |J_cpu| after n_cmp sweeps from J0 (whole grid, or the CPU sample's node range)."""
-    p.terminal_cost()
+def cpu_leg(p, cfg, budget_s, depth):
+    """CPU baseline + accuracy at depth in one pass.  J_K = the GPU's cost-to-go after `depth` sweeps (downloaded; its
+    float32 values are exact in float64).  CPU: n sweeps (whole grid) or one sweep (a slice) of the float64 oracle twin
+    from J_K.  GPU: the same n sweeps from the same J_K.  Reported: max |J_gpu - J_cpu| / max |J_cpu| over the compared
+    nodes, and the float64 Q-regret of the GPU's actions on the GPU's own previous cost-to-go (how much worse than the
+    best action, relative to max |J|: the measure of a policy that is insensitive to ties)."""
+    J_K = p.get_J()
+    cpu, J_cpu, n_cmp, rows, c = cpu_baseline(cfg, budget_s, J_start=J_K, depth=depth)
+    p.set_J(J_K)
     p.sweep(n_cmp, 1.0, -1.0)
-    Jg = p.get_J()
-    if rows is not None:
-        Jg = Jg[rows[0]:rows[1]]
-    return float(np.abs(Jg - J_cpu).max() / max(np.abs(J_cpu).max(), 1e-300))
+    Jg, pig, Jprev = p.get_J(), p.get_pi(), p.get_J(prev=True)
+    lo, hi = (0, Jg.size) if rows is None else rows
+    scale = max(float(np.abs(J_cpu).max()), 1e-300)
+    err = float(np.abs(Jg[lo:hi] - J_cpu).max() / scale)
+    rng = np.random.default_rng(0)
+    nodes = np.sort(rng.choice(np.arange(lo, hi), size=min(hi - lo, 200000), replace=False))
+    q, qmin = c.q_at(Jprev, nodes, pig[nodes])
+    ok = np.isfinite(q) & np.isfinite(qmin)
+    regret = float((q[ok] - qmin[ok]).max() / scale) if ok.any() else 0.0
+    acc = {"jstar_rel_err_vs_cpu": err, "jstar_rel_err_after_sweeps": n_cmp, "jstar_rel_err_from_depth": depth,
+           "jstar_rel_err_nodes": "whole grid" if rows is None else "nodes [%d, %d)" % rows,
+           "pi_q_regret_vs_cpu": regret, "pi_q_regret_nodes": int(nodes.size),
+           "jstar_check": "GPU and float64 CPU twin both advance the GPU's own J after %d sweeps by %d sweep(s)" % (depth, n_cmp)}
+    return cpu, acc
+
+
+def converged_check(cfg, tol=0.1, every=100, max_sweeps=20000):
+    """north_star: "J* match within 1e-5".  The workload solved to `tol` twice on the GPU -- float32 production path and
+    float64 path (oracle-pinned one step at a time by the tests) -- in lockstep batches of `every` sweeps; the drift
+    max |J32 - J64| / max |J64| is recorded after every batch.  Returns the final figure, both sweep counts and the curve."""
+    from pyro_amd.planning import dynamicprogramming
+    g = cfg["grid_sys"]
+    hs = {}
+    t0 = time.perf_counter()
+    for dt in ("float32", "float64"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, cfg["cf"], dtype=dt)
+        hs[dt] = dp._p
+    done = {"float32": 0, "float64": 0}
+    stop = {"float32": False, "float64": False}
+    curve = []
+    while not all(stop.values()) and max(done.values()) < max_sweeps:
+        for dt, h in hs.items():
+            if not stop[dt]:
+                st, n = h.sweep(every, 1.0, tol)
+                done[dt] += n
+                stop[dt] = n < every or (n and st[-1][3] <= tol)
+        a, b = hs["float32"].get_J(), hs["float64"].get_J()
+        curve.append([max(done.values()), float(np.abs(a - b).max() / np.abs(b).max())])
+    out = {"tol": tol, "sweeps_f32": done["float32"], "sweeps_f64": done["float64"], "rel_err": curve[-1][1],
+           "max_J": float(np.abs(b).max()), "drift_curve": curve, "seconds": time.perf_counter() - t0,
+           "paths": {k: h.describe() for k, h in hs.items()}}
+    for h in hs.values():
+        h.close()
+    return out
 
 
 def run_single(args):
@@ -284,25 +364,33 @@ def run_single(args):
     out.update(head)
     out["head"] = git_head()
     out["jstar_rel_err_vs_cpu"], out["jstar_rel_err_after_sweeps"] = None, 0
+    depth = out["warmup"] + out["timed_steps"]
     if not args.no_cpu:
         # (after the timed region: a descheduled launch thread would show up as GPU idle time inside it)
-        cpu, J_cpu, n_cmp, rows = cpu_baseline(cfg, args.cpu_budget)
+        cpu, acc = cpu_leg(p, cfg, args.cpu_budget, depth)
         out["cpu_baseline"] = cpu
         out["speedup_vs_cpu_baseline"] = out["value"] / cpu["value"]
-        out["jstar_rel_err_vs_cpu"] = accuracy_vs_cpu(p, J_cpu, n_cmp, rows)
-        out["jstar_rel_err_after_sweeps"] = n_cmp
-        out["jstar_rel_err_nodes"] = "whole grid" if rows is None else "nodes [%d, %d)" % rows
+        out.update(acc)
     p.close()
+    if args.converged:
+        try:
+            cv = converged_check(cfg)
+            out["jstar_rel_err_converged_f32_vs_f64"] = cv["rel_err"]
+            out["converged"] = cv
+        except Exception as e:                           # (reported, not fatal: the timed line stands on its own)
+            out["jstar_rel_err_converged_f32_vs_f64"] = None
+            out["converged"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if args.with_secondary:
         sec = {}
-        for name, st, wu in (("c2", 2000, 200), ("c2p", 2000, 200), ("c5", 10, 2), ("c4", 5, 2), ("c1", 2000, 200)):
+        for name, st, wu in (("c2", 2000, 200), ("c2p", 2000, 200), ("c5", 10, 2), ("c5d", 5, 2), ("c4", 5, 2),
+                             ("c1", 2000, 200)):
             try:
                 frag, scfg, sp = measure(name, st, wu, keep_handle=(name == "c2p"))
                 if sp is not None:                       # north-star grid: small enough for its own CPU leg
-                    cpu, J_cpu, n_cmp, rows = cpu_baseline(scfg, 5.0)
+                    cpu, acc = cpu_leg(sp, scfg, 5.0, frag["warmup"] + frag["timed_steps"])
                     frag["cpu_baseline"] = cpu
                     frag["speedup_vs_cpu_baseline"] = frag["value"] / cpu["value"]
-                    frag["jstar_rel_err_vs_cpu"] = accuracy_vs_cpu(sp, J_cpu, n_cmp, rows)
+                    frag.update(acc)
                     sp.close()
                 sec[name] = frag
             except Exception as e:                       # a secondary line must not take the headline down
@@ -368,14 +456,20 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-secondary", action="store_true", help="headline workload only")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--converged", action="store_true", default=None,
+                    help="solve the workload to tol 0.1 in float32 and float64 and report the J* difference "
+                         "(default: on for the default run, off with --workload)")
+    ap.add_argument("--no-converged", dest="converged", action="store_false")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or os.environ.get("PVI_FORCE_PARALLEL"):
         from pyro_amd import parallel_bench
         return parallel_bench.run(args)
     args.with_secondary = args.workload is None and not args.no_cpu and not args.no_secondary   # the default driver run
+    if args.converged is None:
+        args.converged = args.with_secondary
     args.workload = args.workload or "c3"
-    big = args.workload in ("c3", "c4", "c5")
+    big = args.workload in ("c3", "c4", "c5", "c5d")
     args.steps = args.steps if args.steps is not None else (20 if big else 2000)
     args.warmup = args.warmup if args.warmup is not None else (2 if big else 200)
     run_single(args)

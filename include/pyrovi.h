@@ -160,6 +160,15 @@ int pvi_abi_version(void);
 const char* pvi_last_error(void);
 int pvi_device_count(int* count);
 
+/* Pin one of the kernel variants pvi_create chooses between by heuristics and timed sweeps (tile shapes, lanes per
+   node, wave mappings, dense / sparse walks, which float32 path ...).  Every variant computes the same recursion: bit for
+   bit within a dtype path, within the float32 tolerance across float32 paths -- this is how the tests compare them and
+   how profiling passes keep set-up's timed candidates out of their averages.  Process-wide, read when a handle is
+   created.  value == NULL removes the key, key == NULL removes all.  Unknown keys: PVI_EINVAL (the list is in
+   pyro_amd/csrc/pyrovi.hip OVERRIDE_KEYS).  The library never reads the environment for any of this: no environment
+   variable changes what it computes (PVI_RCCL_LIB, the file name of the RCCL library, is the one variable it reads). */
+int pvi_override(const char* key, const char* value);
+
 /* ---- problem life cycle ------------------------------------------------------------------- */
 /* GridDynamicSystem.__init__ + DynamicProgramming.__init__ (discretizer.py:27, dynamicprogramming.py:119) */
 int pvi_create(const pvi_desc* desc, pvi_handle* out);

@@ -56,6 +56,7 @@ SYMBOLS = {
     "pvi_abi_version": (C.c_int, []),
     "pvi_last_error": (C.c_char_p, []),
     "pvi_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "pvi_override": (C.c_int, [C.c_char_p, C.c_char_p]),
     "pvi_create": (C.c_int, [C.POINTER(pvi_desc), C.POINTER(_h)]),
     "pvi_destroy": (None, [_h]),
     "pvi_plane_size": (C.c_int64, [_h]),
@@ -146,6 +147,28 @@ def device_count():
     n = C.c_int(0)
     check(lib().pvi_device_count(C.byref(n)))
     return n.value
+
+
+def override(key=None, value=None):
+    """Pin a kernel variant for handles created from now on (pvi_override; tests and profiling).  override(key, None)
+    removes the key, override() removes all."""
+    check(lib().pvi_override(None if key is None else str(key).encode(), None if value is None else str(value).encode()))
+
+
+class overrides:
+    """with _native.overrides(LSPLIT=0, NPT=2): ...   -- the keys are cleared again on exit."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            override(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kv:
+            override(k, None)
 
 
 def _f64(a):

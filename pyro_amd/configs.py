@@ -41,9 +41,9 @@ def _cartpole(xdims, udims, dtype, rail=1):
     return s, g, cf, dtype
 
 
-def _twolink(xdims, udims, dtype):
+def _twolink(xdims, udims, dtype, dt=0.05):
     s = manipulator.TwoLinkManipulator()
-    g = _quiet(discretizer.GridDynamicSystem, s, list(xdims), list(udims))
+    g = _quiet(discretizer.GridDynamicSystem, s, list(xdims), list(udims), dt)
     cf = costfunction.QuadraticCostFunction.from_sys(s)
     cf.INF = 1000
     return s, g, cf, dtype
@@ -58,9 +58,14 @@ CONFIGS = {
     "c3": ("cart-pole 101^4 x 21 actions, f32 (BASELINE configs[2])", lambda: _cartpole((101,) * 4, (21,), "float32")),
     "c4": ("cart-pole 151^4 x 31 actions, f32 (BASELINE configs[3])", lambda: _cartpole((151,) * 4, (31,), "float32")),
     "c5": ("two-link 101^4 x 11x11 torques, f64 (BASELINE configs[4])", lambda: _twolink((101,) * 4, (11, 11), "float64")),
+    # with the default dt = 0.05 only 12 % of C5's cells land inside the grid box, so most of the in-kernel
+    # H(q)^-1 dynamics that configs[4] names is skipped; dt = 0.01 keeps most of them in (the dense variant)
+    "c5d": ("two-link 101^4 x 11x11 torques, dt = 0.01, f64 (BASELINE configs[4], dense variant of SURVEY 8d)",
+            lambda: _twolink((101,) * 4, (11, 11), "float64", dt=0.01)),
     # reduced twins for quick checks
     "c3s": ("cart-pole 41^4 x 21 actions, f32", lambda: _cartpole((41,) * 4, (21,), "float32")),
     "c5s": ("two-link 41^4 x 11x11 torques, f64", lambda: _twolink((41,) * 4, (11, 11), "float64")),
+    "c5ds": ("two-link 41^4 x 11x11 torques, dt = 0.01, f64", lambda: _twolink((41,) * 4, (11, 11), "float64", dt=0.01)),
 }
 
 

@@ -25,6 +25,9 @@
 #include <limits>
 #include <new>
 #include <algorithm>
+#include <mutex>
+#include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/pyrovi.h"
@@ -1836,374 +1839,6 @@ __global__ __launch_bounds__(256) void k_sweep_fast(DevP P, FastP F, const float
 }
 
 
-// =================================================================================================
-// f32 LDS-tiled path ("v2").  Arithmetic identical to k_sweep_fast; what changes is where the 2^n
-// corner values come from.  A workgroup owns blockDim.x >> lsplit consecutive nodes.  Every thread
-// first works out the index box its gathers can touch -- position rows are exact, velocity rows
-// follow from the affine displacement evaluated at the corner actions (float rounding is monotone
-// in u, so the extremes over the action grid sit at its corners) -- the workgroup reduces the boxes
-// to one window, stages that window of J_k from HBM/L2 into LDS with coalesced row reads, and the
-// action loop then gathers from LDS only (ds_read: 2 clk per wave instruction instead of ~16 clk
-// per global gather through the texture addresser).  The loop body is branch free; lanes that came
-// within the guard band of a bound are re-run afterwards with float64 classification (EXACT pass).
-// A window that does not fit the LDS budget falls back to global gathers for that workgroup.
-// =================================================================================================
-struct TileP {
-    float guard;
-    int lsplit;
-    int lds_floats;  // capacity of the dynamic LDS window
-};
-
-template <int DOF, int M>
-struct LaneState {
-    int idxv[DOF], vmax[DOF];  // own velocity indices; dim-2 (largest interval index)
-    float ta[DOF], tB[DOF][M], selff[DOF], nm1f[DOF];
-    float wp[1 << DOF];
-    int bpw[1 << DOF];  // offsets of the position corners in the gather source
-    int vs[DOF];        // strides of the velocity axes in the gather source
-    int vorg;           // sum of window origin * stride over the velocity axes
-    int limit;          // number of elements in the gather source (debug bounds check)
-    bool pos_in, on_target;
-    float gxdt;
-};
-
-template <int DYN, bool UNIFORM, bool EXACT>
-__device__ __forceinline__ void run_actions(const DevP& P, const float4* __restrict__ actp, float guard,
-                                            const float* __restrict__ src,
-                                            const LaneState<Dyn<DYN>::DOF, Dyn<DYN>::M>& L, const int* idx, int part,
-                                            int split, float alpha, float INF_F, float& best, int& arg,
-                                            bool& need_exact, int* dbg = nullptr) {
-    using D = Dyn<DYN>;
-    constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M, NP = 1 << DOF;
-    double x[N];
-    D dyn;
-    if (EXACT) {
-        double tr[8];
-#pragma unroll
-        for (int d = 0; d < N; ++d) x[d] = P.lev[d][idx[d]];
-        D::trig_from_tables(P, idx, tr);
-        dyn.init(P.c, x, tr);
-    }
-    best = INFINITY;
-    arg = 0x7fffffff;
-    for (int a = UNIFORM ? 0 : part; a < P.A; a += UNIFORM ? 1 : split) {
-        const float4 act = actp[a];
-        float rel[DOF], m = INFINITY;
-#pragma unroll
-        for (int i = 0; i < DOF; ++i) {
-            float r = fmaf(L.tB[i][0], act.x, L.ta[i]);
-            if (M == 2) r = fmaf(L.tB[i][M - 1], act.y, r);
-            rel[i] = r;
-            m = fminf(m, fminf(r + L.selff[i], L.nm1f[i] - r));
-        }
-        bool inb;
-        if (!EXACT) {
-            inb = L.pos_in && (m >= 0.f);
-            need_exact = need_exact || (L.pos_in && fabsf(m) < guard);
-        } else {
-            double u[M], acc[DOF];
-#pragma unroll
-            for (int k = 0; k < M; ++k) u[k] = P.utab[a * M + k];
-            dyn.accel(u, acc);
-            inb = L.pos_in;
-#pragma unroll
-            for (int i = 0; i < DOF; ++i) {
-                const double xn = acc[i] * P.dt + x[DOF + i];
-                inb = inb && !(xn < P.glo[DOF + i]) && !(xn > P.ghi[DOF + i]);
-            }
-        }
-        int off = -L.vorg;
-        float yv[DOF];
-#pragma unroll
-        for (int i = 0; i < DOF; ++i) {
-            const int ii = min(max(L.idxv[i] + (int)floorf(rel[i]), 0), L.vmax[i]);
-            yv[i] = fminf(fmaxf(rel[i] - (float)(ii - L.idxv[i]), 0.f), 1.f);
-            off += ii * L.vs[i];
-        }
-        float sv[NP];
-#pragma unroll
-        for (int v = 0; v < NP; ++v) {
-            int vo = off;
-#pragma unroll
-            for (int i = 0; i < DOF; ++i) vo += ((v >> (DOF - 1 - i)) & 1) ? L.vs[i] : 0;
-#ifdef PVI_CHECK_BOUNDS
-            int gi[NP];
-#pragma unroll
-            for (int c = 0; c < NP; ++c) {
-                gi[c] = L.bpw[c] + vo;
-                if (gi[c] < 0 || gi[c] >= L.limit) {
-                    atomicOr(dbg, 2);
-                    dbg[1] = gi[c]; dbg[2] = L.limit; dbg[3] = a; dbg[4] = L.bpw[c]; dbg[5] = vo; dbg[6] = L.vorg;
-                    dbg[7] = L.idxv[0]; dbg[8] = (int)floorf(rel[0]); dbg[9] = L.vs[0]; dbg[10] = EXACT; dbg[11] = L.pos_in;
-                    gi[c] = 0;
-                }
-            }
-            float acc = L.wp[0] * src[gi[0]];
-#pragma unroll
-            for (int c = 1; c < NP; ++c) acc = fmaf(L.wp[c], src[gi[c]], acc);
-#else
-            float acc = L.wp[0] * src[L.bpw[0] + vo];
-#pragma unroll
-            for (int c = 1; c < NP; ++c) acc = fmaf(L.wp[c], src[L.bpw[c] + vo], acc);
-#endif
-            sv[v] = acc;
-        }
-#pragma unroll
-        for (int i = DOF - 1; i >= 0; --i) {
-#pragma unroll
-            for (int k = 0; k < (1 << i); ++k) sv[k] = fmaf(yv[i], sv[2 * k + 1] - sv[2 * k], sv[2 * k]);
-        }
-        const float Jn = inb ? sv[0] : 0.f;
-        const float G = (inb && act.w != 0.f) ? (L.on_target ? 0.f : L.gxdt + act.z) : INF_F;
-        const float q = fmaf(alpha, Jn, G);
-        if (q < best) {  // strict: first (smallest a) minimum within this lane
-            best = q;
-            arg = a;
-        }
-    }
-}
-
-template <int DYN, typename PI_T, bool UNIFORM>
-__global__ __launch_bounds__(1024) void k_sweep_tile(DevP P, TileP F, const float4* __restrict__ actp,
-                                                     const float* __restrict__ Jin, float* __restrict__ Jout,
-                                                     PI_T* __restrict__ pi, float alpha, SweepCtl sc) {
-    using D = Dyn<DYN>;
-    constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M, NP = 1 << DOF;
-    extern __shared__ __attribute__((aligned(16))) float tile[];
-    __shared__ int s_box[2 * N][16];
-    __shared__ int s_win[2 * N];
-    if (sc.ctrl->done) return;
-    const int split = UNIFORM ? 1 : (1 << F.lsplit);
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long o = UNIFORM ? t : (t >> F.lsplit);
-    const int part = UNIFORM ? 0 : (int)(t & (split - 1));
-    const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
-    const bool live = o < owned;
-    const float INF_F = (float)P.INF;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
-
-    LaneState<DOF, M> L;
-    int idx[N], ci[DOF];
-    long long self = 0;
-    int lo[N], hi[N];  // this thread's gather box (inclusive); axis 0 in stored-row coordinates
-#pragma unroll
-    for (int d = 0; d < N; ++d) {
-        lo[d] = 0x7fffffff;
-        hi[d] = -0x7fffffff;
-        idx[d] = 0;
-    }
-#pragma unroll
-    for (int i = 0; i < DOF; ++i) ci[i] = 0;
-    L.pos_in = false;
-    L.on_target = false;
-    L.gxdt = 0.f;
-    if (live) {
-        decode_node<N>(P, o, idx);
-        double x[N], dx[N];
-        self = (long long)(idx[0] - P.store_begin) * P.strd[0];
-#pragma unroll
-        for (int d = 0; d < N; ++d) {
-            x[d] = P.lev[d][idx[d]];
-            dx[d] = x[d] - P.xbar[d];
-            if (d > 0) self += idx[d] * P.strd[d];
-        }
-        const double gx = quad_form<N>(P.Q, dx);
-        L.on_target = P.ontarget && (l2norm<N>(dx) < P.EPS);
-        L.gxdt = (float)(gx * P.dt);
-        bool pin = true;
-        float yp[DOF];
-#pragma unroll
-        for (int i = 0; i < DOF; ++i) {
-            const double xn = x[DOF + i] * P.dt + x[i];
-            pin = pin && !(xn < P.glo[i]) && !(xn > P.ghi[i]);
-            ci[i] = find_interval(P.lev[i], P.dim[i], P.glo[i], P.inv_step[i], xn);
-            yp[i] = (float)((xn - P.lev[i][ci[i]]) / (P.lev[i][ci[i] + 1] - P.lev[i][ci[i]]));
-        }
-        L.pos_in = pin;
-        if (pin) {
-            int r0 = ci[0];
-            if (r0 < P.store_begin || r0 + 1 >= P.store_end) {
-                atomicOr(&sc.ctrl->halo_err, 1);
-                r0 = min(max(r0, P.store_begin), P.store_end - 2);
-            }
-            ci[0] = r0 - P.store_begin;
-        }
-#pragma unroll
-        for (int c = 0; c < NP; ++c) {
-            float w = 1.f;
-#pragma unroll
-            for (int i = 0; i < DOF; ++i) w *= ((c >> (DOF - 1 - i)) & 1) ? yp[i] : (1.f - yp[i]);
-            L.wp[c] = w;
-        }
-        double tr[8], a64[DOF], B64[DOF][M];
-        D::trig_from_tables(P, idx, tr);
-        D dyn;
-        dyn.init(P.c, x, tr);
-        dyn.affine(a64, B64);
-#pragma unroll
-        for (int i = 0; i < DOF; ++i) {
-            const double sc = P.dt * P.inv_step[DOF + i];
-            L.ta[i] = (float)(a64[i] * sc);
-#pragma unroll
-            for (int k = 0; k < M; ++k) L.tB[i][k] = (float)(B64[i][k] * sc);
-            L.idxv[i] = idx[DOF + i];
-            L.vmax[i] = P.dim[DOF + i] - 2;
-            L.selff[i] = (float)idx[DOF + i];
-            L.nm1f[i] = (float)(P.dim[DOF + i] - 1 - idx[DOF + i]);
-        }
-        if (pin) {
-#pragma unroll
-            for (int i = 0; i < DOF; ++i) {
-                lo[i] = ci[i];
-                hi[i] = ci[i] + 1;
-            }
-#pragma unroll
-            for (int cr = 0; cr < (1 << M); ++cr) {
-                int a;
-                if (M == 1)
-                    a = cr ? P.A - 1 : 0;
-                else
-                    a = ((cr & 2) ? (P.udim[0] - 1) * P.udim[1] : 0) + ((cr & 1) ? P.udim[1] - 1 : 0);
-                const float4 ac = actp[a];
-#pragma unroll
-                for (int i = 0; i < DOF; ++i) {
-                    float r = fmaf(L.tB[i][0], ac.x, L.ta[i]);
-                    if (M == 2) r = fmaf(L.tB[i][M - 1], ac.y, r);
-                    const int ii = min(max(L.idxv[i] + (int)floorf(r), 0), L.vmax[i]);
-                    lo[DOF + i] = min(lo[DOF + i], ii);
-                    hi[DOF + i] = max(hi[DOF + i], ii + 1);
-                }
-            }
-        }
-    }
-
-    // ---- workgroup window --------------------------------------------------------------------
-#pragma unroll
-    for (int d = 0; d < N; ++d) {
-        const int l = wave_min_i(lo[d]), h = wave_max_i(hi[d]);
-        if (lane == 0) {
-            s_box[d][wave] = l;
-            s_box[N + d][wave] = h;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 2 * N) {
-        int v = s_box[threadIdx.x][0];
-        for (int w = 1; w < nwaves; ++w)
-            v = (threadIdx.x < N) ? min(v, s_box[threadIdx.x][w]) : max(v, s_box[threadIdx.x][w]);
-        s_win[threadIdx.x] = v;
-    }
-    __syncthreads();
-    int wlo[N], wdim[N];
-    long long W = 1;
-    bool any = true;
-#pragma unroll
-    for (int d = 0; d < N; ++d) {
-        wlo[d] = s_win[d];
-        any = any && s_win[N + d] >= wlo[d];  // sentinels (no in-bounds lane) must not be subtracted
-        wdim[d] = any ? s_win[N + d] - wlo[d] + 1 : 0;
-        W *= wdim[d];
-    }
-    const bool use_lds = any && W <= F.lds_floats;
-    if (use_lds) {
-        // rows of the last axis, one row per wave at a time, lanes along the row (coalesced)
-        const int rowlen = wdim[N - 1];
-        const int rows = (int)(W / rowlen);
-        for (int r = wave; r < rows; r += nwaves) {
-            int rem = r;
-            long long g = wlo[N - 1];
-#pragma unroll
-            for (int d = N - 2; d >= 0; --d) {
-                const int q = rem / wdim[d];
-                g += (long long)(wlo[d] + (rem - q * wdim[d])) * P.strd[d];
-                rem = q;
-            }
-            const float* __restrict__ grow = Jin + g;
-            float* trow = tile + r * rowlen;
-            for (int c = lane; c < rowlen; c += 64) trow[c] = grow[c];
-        }
-    }
-    __syncthreads();
-
-    // ---- per-lane gather geometry: window (LDS) or stored buffer (global fallback) --------
-    {
-        int st[N];
-        if (use_lds) {
-            int acc = 1;
-#pragma unroll
-            for (int d = N - 1; d >= 0; --d) {
-                st[d] = acc;
-                acc *= wdim[d];
-            }
-        } else {
-#pragma unroll
-            for (int d = 0; d < N; ++d) st[d] = (int)P.strd[d];
-        }
-#pragma unroll
-        for (int c = 0; c < NP; ++c) {
-            int b = 0;
-#pragma unroll
-            for (int i = 0; i < DOF; ++i)
-                b += (ci[i] + ((c >> (DOF - 1 - i)) & 1) - (use_lds ? wlo[i] : 0)) * st[i];
-            L.bpw[c] = L.pos_in ? b : 0;
-        }
-        L.vorg = 0;
-#pragma unroll
-        for (int i = 0; i < DOF; ++i) {
-            L.vs[i] = st[DOF + i];
-            L.vorg += (use_lds ? wlo[DOF + i] : 0) * st[DOF + i];
-        }
-        L.limit = use_lds ? (int)W : (int)((long long)(P.store_end - P.store_begin) * P.plane);
-        if (!L.pos_in) {  // nothing of this lane is in the window: keep its (discarded) reads in range
-            L.vorg = 0;
-#pragma unroll
-            for (int i = 0; i < DOF; ++i) L.vs[i] = 0;
-        }
-    }
-
-    float best = INFINITY;
-    int arg = 0x7fffffff;
-    bool need_exact = false;
-    if (live) {
-        if (use_lds)
-            run_actions<DYN, UNIFORM, false>(P, actp, F.guard, tile, L, idx, part, split, alpha, INF_F, best, arg,
-                                             need_exact, sc.ctrl->dbg);
-        else
-            run_actions<DYN, UNIFORM, false>(P, actp, F.guard, Jin, L, idx, part, split, alpha, INF_F, best, arg,
-                                             need_exact, sc.ctrl->dbg);
-        if (need_exact) {
-            bool dummy = false;
-            if (use_lds)
-                run_actions<DYN, false, true>(P, actp, F.guard, tile, L, idx, part, split, alpha, INF_F, best, arg,
-                                              dummy, sc.ctrl->dbg);
-            else
-                run_actions<DYN, false, true>(P, actp, F.guard, Jin, L, idx, part, split, alpha, INF_F, best, arg,
-                                              dummy, sc.ctrl->dbg);
-        }
-    }
-    if (!UNIFORM) {
-        for (int off = split >> 1; off > 0; off >>= 1) {
-            const float q2 = __shfl_xor(best, off, 64);
-            const int a2 = __shfl_xor(arg, off, 64);
-            if (q2 < best || (q2 == best && a2 < arg)) {
-                best = q2;
-                arg = a2;
-            }
-        }
-    }
-    double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
-    if (live && part == 0) {
-        Jout[self] = best;
-        pi[o] = (PI_T)arg;
-        const double jn = (double)best, d = jn - (double)Jin[self];
-        st_j = jn;
-        st_dmax = d;
-        st_ndmin = -d;
-    }
-    block_stats(st_j, st_dmax, st_ndmin, sc.slot);
-    sweep_finish(sc);
-}
-
 #include "sweep_lean.inc"
 
 // =================================================================================================
@@ -2689,6 +2324,45 @@ static inline unsigned grid_for(long long n, int block = 256) { return (unsigned
 
 static const int MAX_BATCH = 1024;  // sweeps per device-side batch (stats slots)
 
+// ---- variant overrides (pvi_override) ---------------------------------------------------------------------------------
+// pvi_create picks between kernel variants that compute the same recursion (tile shapes, lanes per node, nodes per
+// thread, wave mappings, dense / sparse walks, which float32 path) by heuristics and timed sweeps.  Tests and profiling
+// passes need to pin a variant; they do so through pvi_override(key, value) -- an explicit call, process-wide, read
+// when a handle is created.  The ENVIRONMENT is never consulted: no environment variable changes what the library
+// computes.  Only the keys below exist; every one selects among product variants whose results agree (bit for bit
+// within a dtype path, within the float32 tolerance across float32 paths).
+static const char* const OVERRIDE_KEYS[] = {
+    "LSPLIT",      // log2 lanes per node of the float32 sweeps (small grids)
+    "NPT",         // 2-D lean sweep: nodes per thread, 1 or 2
+    "TV0", "TV1", "TV_EXACT",  // lean sweep tile shape (rows x columns; TV_EXACT: do not even out the column split)
+    "TUNE",        // 0: no timed candidate sweeps at create (first candidate that fits)
+    "LDS_KB",      // LDS budget of the lean window
+    "DMA16",       // 0: 4-byte window DMA
+    "NO_RS64", "NO_TBTILE", "NO_XCD", "XCD64", "NO_SPLIT_FINISH",   // layout / launch details of the lean and float64 sweeps
+    "NO_LEAN",     // float32: skip the LDS-window kernel (plain-gather k_sweep_fast)
+    "NO_FAST",     // float32: float64 dynamics with float32 storage (k_sweep<float>)
+    "NO_SWEEP64",  // float64: the operation-for-operation kernel k_sweep instead of k_sweep64
+    "SPARSE", "PATCH",         // 4-D float64 / exact-float32 sweeps: walk over validity masks, 8x8 patch mapping
+    "NO_PACK",     // table tier: sweep the raw tables instead of the packed records
+    "SPLINE_CHUNK",            // spline mode: rows per chunk of the substitution passes
+    "WIN",         // 4-D lean sweep window layout: 0 single floats + ds_read2_b32, 1 position-paired + ds_read_b64
+    "TABLES",      // lean sweep per-node coefficient tables: 0 per-node arrays, 1 factorised where the dynamics allow
+};
+static std::vector<std::pair<std::string, std::string>> g_overrides;
+static std::mutex g_override_mu;
+
+// value of an override or NULL (the returned pointer stays valid until the key is set again)
+static const char* ovr(const char* key) {
+    std::lock_guard<std::mutex> lk(g_override_mu);
+    for (auto& kv : g_overrides)
+        if (kv.first == key) return kv.second.c_str();
+    return nullptr;
+}
+static inline bool ovr_is(const char* key, int v) {
+    const char* e = ovr(key);
+    return e && atoi(e) == v;
+}
+
 struct pvi_problem {
     pvi_desc d;
     DevP P;
@@ -2715,26 +2389,15 @@ struct pvi_problem {
     long long stage_n = 0;
     FastP F;                  // f32 fast path tables
     bool fast_ok = false;
-    TileP T;                  // f32 LDS-tiled path
-    bool tile_ok = false;
-    int tile_block = 256;
     LeanP LP;                 // f32 lean path (sweep_lean.inc)
     bool lean_ok = false;
     int lean_pw1 = 2, lean_block = 256;
     dim3 lean_grid;
-    bool lean_persist = false;   // persistent form of the lean kernel (k_sweep_leanp)
-    unsigned lean_pgrid = 0;     // its grid: workgroups the chip holds at once
-    int lean_wpc = 0;            // workgroups per CU behind lean_pgrid
     size_t lean_lds = 0;
     bool lean_lds_attr = false;
     char lean_why[160] = "";
     int lean_reach = 0;       // largest |velocity displacement| of an in-box cell, grid cells
     int lean_opmag = 0;       // largest |ta| + sum |tB u| (cells): operand magnitude of the float32 displacement
-    MarchP MP;                // 4-D march variant of the lean path
-    bool march_ok = false;
-    size_t march_lds = 0;
-    bool march_lds_attr = false;
-    int march_block = 256;
     const int* aok32 = nullptr;  // isavalidinput per action as int32 (scalar loads in the exact kernel)
     const Act64* act64 = nullptr;   // float64 second form (k_sweep64): per-action records, {level, reciprocal} tables
     const double2* levr = nullptr;
@@ -2793,54 +2456,6 @@ static void dev_release(pvi_problem* h, void* p) {
 
 static int launch_sweep(pvi_problem* h, int src, double alpha, hipStream_t st, int k, double tol);
 
-// the persistent lean kernel of this handle's dynamics / policy type
-static const void* leanp_kernel(const pvi_problem* h) {
-#define LP_K(DYN) (h->pi_size == 1 ? (const void*)k_sweep_leanp<DYN, unsigned char> : (const void*)k_sweep_leanp<DYN, unsigned short>)
-    switch (h->d.dynamics_id) {
-        case PVI_DYN_PENDULUM: return LP_K(PVI_DYN_PENDULUM);
-        case PVI_DYN_CARTPOLE: return LP_K(PVI_DYN_CARTPOLE);
-        case PVI_DYN_NODE_1x1: return LP_K(PVI_DYN_NODE_1x1);
-        case PVI_DYN_NODE_2x1: return LP_K(PVI_DYN_NODE_2x1);
-        case PVI_DYN_NODE_2x2: return LP_K(PVI_DYN_NODE_2x2);
-        default: return LP_K(PVI_DYN_TWOLINK);
-    }
-#undef LP_K
-}
-
-// Persistent launch geometry for the tile shape just set up: window buffers per workgroup and a grid of as many
-// workgroups as are resident at once (a surplus workgroup would only run after another exits: a second, short round).
-static int lean_persist_setup(pvi_problem* h) {
-    LeanP& L = h->LP;
-    h->lean_persist = false;
-    L.nbuf = 1;
-    // opt-in (PVI_PERSIST=1): measured 42.9 us against 39-42 us on C2 and 5.94 ms against 5.13 ms on C3 -- the hardware's
-    // dynamic dealing of one tile per workgroup balances uneven tiles (exact-pass nodes, validity-checked boundary tiles)
-    // better than static tile lists, and its staggered workgroups overlap each other's prologues about as well
-    if (L.lsplit != 0 || L.npt != 1 || !(getenv("PVI_PERSIST") && atoi(getenv("PVI_PERSIST")))) return PVI_OK;
-    const void* fn = leanp_kernel(h);
-    // two window buffers when that does not cost residency: small (2-D) windows
-    size_t lds = h->lean_lds;
-    int nbuf = (2 * lds <= 16 * 1024) ? 2 : 1;
-    if (const char* e = getenv("PVI_NBUF")) nbuf = atoi(e) == 2 ? 2 : 1;
-    lds *= nbuf;
-    if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PVI_LDS_MAX));
-    int per_cu = 0, cus = 0;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, h->lean_block, lds));
-    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
-    if (per_cu < 1 || cus < 1) return PVI_OK;
-    if (const char* e = getenv("PVI_WPC")) per_cu = std::max(1, atoi(e));  // experiments: workgroups per CU
-    unsigned grid = (unsigned)per_cu * (unsigned)cus;
-    // every workgroup needs a tile, on every XCD: ceil(grid / 8) <= floor(tiles / 8)
-    const unsigned cap = (L.nblocks / 8u) * 8u;
-    if (cap == 0) return PVI_OK;
-    grid = std::min(grid, cap);
-    L.nbuf = nbuf;
-    h->lean_persist = true;
-    h->lean_pgrid = grid;
-    h->lean_wpc = per_cu;
-    return PVI_OK;
-}
-
 static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats) {
     const DevP& P = h->P;
     LeanP& L = h->LP;
@@ -2851,7 +2466,7 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
     L.V0 = DOF == 2 ? P.dim[2] : (P.row_end - P.row_begin);
     L.V1 = P.dim[P.n - 1];
     L.ntx = (L.V1 + tv1_t - 1) / tv1_t;
-    L.TV1 = getenv("PVI_TV_EXACT") ? tv1_t : (L.V1 + L.ntx - 1) / L.ntx;
+    L.TV1 = ovr("TV_EXACT") ? tv1_t : (L.V1 + L.ntx - 1) / L.ntx;
     const int tv0 = std::max(1, std::min(L.V0, tv0_t));
     L.nty = (L.V0 + tv0 - 1) / tv0;
     L.TV0 = (L.V0 + L.nty - 1) / L.nty;
@@ -2869,8 +2484,7 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
     L.nblocks = (unsigned)ntiles;
     L.xq = L.nblocks / 8u;
     L.xrem = L.nblocks % 8u;
-    L.xcd_remap = getenv("PVI_NO_XCD") ? 0 : 1;
-    L.dbg = getenv("PVI_DBG") ? atoi(getenv("PVI_DBG")) : 0;
+    L.xcd_remap = ovr("NO_XCD") ? 0 : 1;
     h->lean_grid = dim3((unsigned)ntiles, 1, 1);
     int rc;
     if (L.win) dev_release(h, L.win);
@@ -2918,24 +2532,19 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
     // (A pitch congruent to the tile width modulo 32 -- consecutive lanes on consecutive banks across
     // tile rows -- was measured: fewer conflict cycles per LDS instruction, but the larger pitch costs
     // LDS capacity and one more address add per corner; no net gain.  PVI_RS_MODE=1 selects it.)
-    L.tb_tile = (summary[2] == 0 && !getenv("PVI_NO_TBTILE")) ? 1 : 0;
+    L.tb_tile = (summary[2] == 0 && !ovr("NO_TBTILE")) ? 1 : 0;
     int rs = (summary[1] + 1) | 1;
-    if (const char* e = getenv("PVI_RS_MODE")) {
-        if (atoi(e) == 1 && DOF == 2) rs = summary[1] + 1 + (((L.TV1 - summary[1] - 1) % 32 + 32) % 32);
-        if (atoi(e) == 2) rs = 32 * ((summary[1] + 31) / 32) + 1;
-    }
     // 2-D pair windows are a few KB: pitches 64 and 128 have their own kernels (row + 1 is an immediate offset of the read)
-    if (DOF == 1 && !getenv("PVI_NO_RS64")) rs = rs <= 64 ? 64 : (rs <= 128 ? 128 : rs);
-    if (const char* e = getenv("PVI_RS")) rs = std::max(rs, atoi(e));  // experiments: explicit row pitch
+    if (DOF == 1 && !ovr("NO_RS64")) rs = rs <= 64 ? 64 : (rs <= 128 ? 128 : rs);
     // 16-byte window DMA (4-D; J buffers with slack behind them): rows are packed with a pitch that is a multiple of
     // 4 floats, one instruction then moves 256 consecutive window floats (about four rows).  PVI_DMA16=0: 4-byte DMA.
     L.dma16 = (DOF == 2 && (h->own_J || (h->d.flags & PVI_FLAG_EXT_J_SLACK)) &&
-               !(getenv("PVI_DMA16") && !atoi(getenv("PVI_DMA16")))) ? 1 : 0;
+               !(ovr("DMA16") && !atoi(ovr("DMA16")))) ? 1 : 0;
     if (L.dma16) {
         rs = (summary[1] + 3) & ~3;
         // pitch 64 has its own kernel (the next velocity row is an immediate offset of the LDS read): rows a little
         // shorter are padded to it when the window still fits
-        if (rs > 48 && rs < 64 && (long long)summary[0] * 64 + 128 <= lds_budget_floats && !getenv("PVI_NO_RS64")) rs = 64;
+        if (rs > 48 && rs < 64 && (long long)summary[0] * 64 + 128 <= lds_budget_floats && !ovr("NO_RS64")) rs = 64;
         L.rs_magic = magic32((unsigned)rs);
     }
     // (2-D windows are staged as pairs -- 8 bytes per column, sweep_lean.inc lds_corners -- 4-D windows as single floats)
@@ -2959,7 +2568,7 @@ static int lean_setup(pvi_problem* h) {
     memset(&L, 0, sizeof(L));
     L.actc = actc;
     h->lean_ok = false;
-    if (!h->fast_ok || getenv("PVI_NO_LEAN")) return PVI_OK;
+    if (!h->fast_ok || ovr("NO_LEAN")) return PVI_OK;
     const int DOF = P.dof, M = P.m;
     int rc;
     if ((rc = dev_alloc(h, (size_t)DOF * h->owned, &L.ta))) return rc;
@@ -2983,17 +2592,17 @@ static int lean_setup(pvi_problem* h) {
             ((h->owned << (ls + 1)) <= 655360 && P.A / (2 << ls) >= 16)) &&
            (2 << ls) <= 16 && (4 << ls) <= P.A)
         ++ls;
-    if (const char* e = getenv("PVI_LSPLIT")) ls = atoi(e);
+    if (const char* e = ovr("LSPLIT")) ls = atoi(e);
     L.lsplit = ls;
     const int spb = std::max(16, 256 >> ls);  // nodes per workgroup
     int budget = DOF == 1 ? 8 * 1024 : 20 * 1024;  // floats: 32 KB (2-D), 80 KB (4-D: two workgroups per CU)
-    if (const char* e = getenv("PVI_LDS_KB")) budget = atoi(e) * 256;
+    if (const char* e = ovr("LDS_KB")) budget = atoi(e) * 256;
     budget = std::min(budget, 40000);
     int shapes[8][2];
     int ns = 0;
-    if (getenv("PVI_TV0") && getenv("PVI_TV1")) {
-        shapes[ns][0] = atoi(getenv("PVI_TV0"));
-        shapes[ns++][1] = atoi(getenv("PVI_TV1"));
+    if (ovr("TV0") && ovr("TV1")) {
+        shapes[ns][0] = atoi(ovr("TV0"));
+        shapes[ns++][1] = atoi(ovr("TV1"));
     } else if (DOF == 1) {
         // measured on 1001^2 x 51: 8x32 51.7 us, 4x63 52.3, 2x126 53.8, 1x251 55.0, 512-thread shapes 56-60
         shapes[ns][0] = std::max(1, spb / 32); shapes[ns++][1] = 32;
@@ -3015,14 +2624,14 @@ static int lean_setup(pvi_problem* h) {
     // register-resident node contexts cost the action loop more than that (C2 43.7 -> 49 us at 71 VGPRs / 7 waves,
     // 55 us squeezed to 63 VGPRs): opt-in for experiments, PVI_NPT=2
     L.npt = 1;
-    if (DOF == 1 && ls == 0 && getenv("PVI_NPT")) {
-        const int want = atoi(getenv("PVI_NPT"));
-        if (want == 2 || want == 4) L.npt = want;
+    if (DOF == 1 && ls == 0 && ovr("NPT")) {
+        const int want = atoi(ovr("NPT"));
+        if (want == 2) L.npt = want;
     }
     // 4-D: the best tile shape depends on how the grid divides (101^4: 15x34 beats 10x51 by 8 %, 151^4: 19x26 beats
     // 16x31 by 7 %) -- time the candidates (widths V1/k, as many rows as fit 512 threads) with two real sweeps each and
     // keep the fastest.  Results do not depend on the shape (same arithmetic per node).  PVI_TUNE=0 switches it off.
-    if (DOF == 2 && ls == 0 && !(getenv("PVI_TV0") && getenv("PVI_TV1")) && !(getenv("PVI_TUNE") && !atoi(getenv("PVI_TUNE")))) {
+    if (DOF == 2 && ls == 0 && !(ovr("TV0") && ovr("TV1")) && !(ovr("TUNE") && !atoi(ovr("TUNE")))) {
         const int V1 = P.dim[3];
         float best_ms = 1e30f;
         int best[2] = {0, 0};
@@ -3040,7 +2649,6 @@ static int lean_setup(pvi_problem* h) {
             if (h->lean_block > 512) continue;
             h->lean_ok = true;
             h->lean_lds_attr = false;
-            if ((rc = lean_persist_setup(h))) return rc;
             float ms = 0.f;
             for (int rep = 0; rep < 3 && rc == 0; ++rep) {  // one warm-up, two timed
                 if (rep == 1) HIPCHK(hipEventRecord(h->ev0, h->stream));
@@ -3083,7 +2691,7 @@ static int lean_setup(pvi_problem* h) {
                 if (h->lean_block > (L.npt > 1 ? 256 : 512)) continue;
                 h->lean_ok = true;
                 h->lean_lds_attr = false;
-                return lean_persist_setup(h);
+                return 0;
             }
         }
         return 0;
@@ -3092,7 +2700,7 @@ static int lean_setup(pvi_problem* h) {
     // round of resident waves instead of two) but leave less to overlap; which wins depends on the action count
     // (2001^2 x 21: 67.7 -> 59.1 us with two, 1001^2 x 51: 35.4 -> 37.5 us), so both run a few timed sweeps here and
     // the faster stays.  Results do not depend on it (same arithmetic per node).  PVI_NPT fixes it, PVI_TUNE=0 keeps 1.
-    if (DOF == 1 && ls == 0 && !getenv("PVI_NPT") && h->owned >= (1 << 17) && !(getenv("PVI_TUNE") && !atoi(getenv("PVI_TUNE")))) {
+    if (DOF == 1 && ls == 0 && !ovr("NPT") && h->owned >= (1 << 17) && !(ovr("TUNE") && !atoi(ovr("TUNE")))) {
         // (clocks ramp up during the first sweeps after a create: the candidates alternate, two rounds of 40 timed
         //  sweeps behind 20 untimed ones each, and a candidate is judged by its faster round)
         // third candidate: one node per thread in 512-thread workgroups (half as many workgroups to dispatch, the window
@@ -3138,36 +2746,10 @@ static int lean_setup(pvi_problem* h) {
     // those operands are hundreds of cells and cancel (light links with strong actuators: the default two-link arm has
     // |ta| + |tB u| up to 3800 cells), their rounding alone moves the fraction by > 1e-5 cells and J by > 1e-5
     // relative (tools/tools_fuzz.py).  Such problems run the kernel with float64 dynamics and float32 storage instead.
-    if (h->lean_opmag > 256 && !getenv("PVI_ALLOW_F32_CANCEL")) {
+    if (h->lean_opmag > 256) {
         snprintf(h->lean_why, sizeof(h->lean_why), "float32 displacement operands reach %d cells: float64 dynamics", h->lean_opmag);
         h->lean_ok = false;
         h->fast_ok = false;
-        h->tile_ok = false;
-    }
-    h->march_ok = false;
-    // the march variant is opt-in (PVI_MARCH=1): measured within 3 % of the tiled lean kernel on 101^4
-    if (h->lean_ok && DOF == 2 && getenv("PVI_MARCH") && L.lsplit == 0) {
-        MarchP& Mp = h->MP;
-        memset(&Mp, 0, sizeof(Mp));
-        Mp.ncols = (P.row_end - P.row_begin) * L.ntx * L.nty;
-        if ((rc = dev_alloc(h, (size_t)Mp.ncols * 8, &Mp.cwin))) return rc;
-        HIPCHK(hipMemsetAsync(L.summary, 0, 4 * sizeof(int), h->stream));
-        hipLaunchKernelGGL(k_march_colbox, grid_for(Mp.ncols), 256, 0, h->stream, P, L, Mp, L.summary);
-        HIPCHK(hipGetLastError());
-        int summary[4];
-        HIPCHK(hipMemcpyAsync(summary, L.summary, sizeof(summary), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        Mp.RS = (summary[1] + 1) | 1;
-        const long long need = (long long)summary[0] * Mp.RS + 128;
-        int mbudget = 20 * 1024;
-        if (const char* e = getenv("PVI_MARCH_LDS_KB")) mbudget = atoi(e) * 256;
-        if (need <= mbudget) {
-            h->march_ok = true;
-            h->march_lds = (size_t)need * 4;
-            h->march_block = ((L.TV0 * L.TV1 + 63) / 64) * 64;
-        } else {
-            snprintf(h->lean_why, sizeof(h->lean_why), "march ring needs %lld LDS floats (budget %d)", need, mbudget);
-        }
     }
     if (!h->lean_ok) {  // release the per-node arrays: the fast / tiled kernels do not need them
         dev_release(h, L.ta); dev_release(h, L.tB); dev_release(h, L.gx); dev_release(h, L.flag);
@@ -3178,6 +2760,26 @@ static int lean_setup(pvi_problem* h) {
 }
 
 extern "C" int pvi_abi_version(void) { return PVI_ABI_VERSION; }
+
+extern "C" int pvi_override(const char* key, const char* value) {
+    if (!key) {  // clear everything
+        std::lock_guard<std::mutex> lk(g_override_mu);
+        g_overrides.clear();
+        return PVI_OK;
+    }
+    bool known = false;
+    for (const char* k : OVERRIDE_KEYS) known = known || !strcmp(k, key);
+    if (!known) return fail(PVI_EINVAL, "pvi_override: unknown key '%s'", key);
+    std::lock_guard<std::mutex> lk(g_override_mu);
+    for (size_t i = 0; i < g_overrides.size(); ++i)
+        if (g_overrides[i].first == key) {
+            if (value) g_overrides[i].second = value;
+            else g_overrides.erase(g_overrides.begin() + (long)i);
+            return PVI_OK;
+        }
+    if (value) g_overrides.emplace_back(key, value);
+    return PVI_OK;
+}
 extern "C" const char* pvi_last_error(void) { return g_err; }
 
 extern "C" int pvi_device_count(int* count) {
@@ -3394,20 +2996,19 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
             if ((rc = dev_upload(h, actc.data(), actc.size(), &h->LP.actc))) return bail(rc);
         }
         h->F.guard = 1e-3f;
-        if (const char* e = getenv("PVI_GUARD")) h->F.guard = (float)atof(e);  // experiments only
         long long threads = h->owned;
         int ls = 0;
         while (threads < (1ll << 20) && (2 << ls) <= 64 && (2 << ls) <= A) {
             ++ls;
             threads <<= 1;
         }
-        if (const char* e = getenv("PVI_LSPLIT")) ls = atoi(e);
+        if (const char* e = ovr("LSPLIT")) ls = atoi(e);
         h->F.lsplit = ls;
         bool box_is_grid = true;
         for (int i = 0; i < d->n; ++i)
             box_is_grid = box_is_grid && d->x_lb[i] == P.glo[i] && d->x_ub[i] == P.ghi[i];
         if (d->dtype == PVI_F64 && d->dynamics_id != PVI_DYN_TABLE && !is_dyn3(d->dynamics_id) && box_is_grid &&
-            !getenv("PVI_NO_SWEEP64")) {
+            !ovr("NO_SWEEP64")) {
             // float64 second form: {u0, u1, gu, isavalidinput} per action, {level, RN(1 / (next level - level))} per level
             std::vector<Act64> a64((size_t)A);
             for (long long a = 0; a < A; ++a)
@@ -3432,20 +3033,7 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
             }
         }
         h->fast_ok = d->dtype == PVI_F32 && d->dynamics_id != PVI_DYN_TABLE && !is_dyn3(d->dynamics_id) && box_is_grid &&
-                     h->stored < 0x7fffffffLL && !getenv("PVI_NO_FAST");
-        // the per-sweep bounding-box tile kernel predates the lean kernel; where the lean window does not fit LDS its
-        // window does not pay either (two-link 101^4 x 121 f32: tile 167 ms, fast 35 ms): opt-in, PVI_TILE=1
-        h->tile_ok = h->fast_ok && getenv("PVI_TILE") && atoi(getenv("PVI_TILE")) && !getenv("PVI_NO_TILE") &&
-                     !is_node_dyn(d->dynamics_id);
-        h->T.guard = h->F.guard;
-        h->T.lsplit = ls;
-        // LDS window budget / workgroup size: 2-D windows are small (4 workgroups per CU); 4-D windows
-        // span the whole last axis, so larger workgroups amortise them
-        int lds_kb = d->n == 2 ? 32 : 96, blk = d->n == 2 ? 256 : 512;
-        if (const char* e = getenv("PVI_LDS_KB")) lds_kb = atoi(e);
-        if (const char* e = getenv("PVI_BLOCK")) blk = atoi(e);
-        h->T.lds_floats = lds_kb * 256;
-        h->tile_block = blk;
+                     h->stored < 0x7fffffffLL && !ovr("NO_FAST");
     }
 
     // trig tables over the angle levels: supplied by the host (numpy) or computed here with libm
@@ -3531,7 +3119,7 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
     bool grid_is_box = true;
     for (int i = 0; i < d->n; ++i) grid_is_box = grid_is_box && d->x_lb[i] == P.glo[i] && d->x_ub[i] == P.ghi[i];
     const bool exact32 = d->dtype == PVI_F32 && d->dynamics_id != PVI_DYN_TABLE && !is_dyn3(d->dynamics_id) &&
-                         !is_node_dyn(d->dynamics_id) && !h->lean_ok && !h->fast_ok && !h->tile_ok && grid_is_box;
+                         !is_node_dyn(d->dynamics_id) && !h->lean_ok && !h->fast_ok && grid_is_box;
     if (exact32 && d->n == 4 && A <= 128 && !h->act64) {
         std::vector<Act64> a64((size_t)A);
         for (long long a = 0; a < A; ++a)
@@ -3539,7 +3127,7 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
         if ((rc = dev_upload(h, a64.data(), a64.size(), &h->act64))) return bail(rc);
     }
     if (((h->use64 && h->levr_bytes + (size_t)A * sizeof(Act64) <= 48 * 1024) || exact32) && d->n == 4 && A <= 128 &&
-        !(getenv("PVI_SPARSE") && !atoi(getenv("PVI_SPARSE")))) {
+        !(ovr("SPARSE") && !atoi(ovr("SPARSE")))) {
         // SPARSE float64 sweep: validity of every (node, action) cell, once (it does not change between sweeps); kept
         // where fewer than half of the cells land in the box (PVI_SPARSE=1 keeps it regardless, =0 never builds it)
         rc = [&]() -> int {
@@ -3564,7 +3152,7 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
             HIPCHK(hipStreamSynchronize(h->stream));
             dev_release(h, cnt);
             h->infrac64 = (double)inside / ((double)h->owned * (double)A);
-            const bool forced = getenv("PVI_SPARSE") && atoi(getenv("PVI_SPARSE"));
+            const bool forced = ovr("SPARSE") && atoi(ovr("SPARSE"));
             if (h->infrac64 < 0.5 || forced) {
                 h->vmask = vm;
                 h->sparse64 = 1;
@@ -3583,9 +3171,9 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
         // The SPARSE walk (validity masks) is timed the same way where the masks were built: it wins where the loop is
         // bound by instruction issue (two-link 41^4: 0.89 -> 0.48 ms) and loses where the gathers of the in-box cells
         // wait for HBM anyway (two-link 101^4: 22.7 -> 24.4 ms).  PVI_SPARSE=1 pins it on.
-        const bool sparse_forced = getenv("PVI_SPARSE") && atoi(getenv("PVI_SPARSE"));
-        if (getenv("PVI_PATCH") && (sparse_forced || !h->sparse64)) {
-            h->patch64 = atoi(getenv("PVI_PATCH")) ? 1 : 0;
+        const bool sparse_forced = ovr("SPARSE") && atoi(ovr("SPARSE"));
+        if (ovr("PATCH") && (sparse_forced || !h->sparse64)) {
+            h->patch64 = atoi(ovr("PATCH")) ? 1 : 0;
         } else {
             float best_ms = 1e30f;
             int best = 1, best_sp = h->sparse64;
@@ -3594,7 +3182,7 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
                 const int pm = cand & 1, sp = cand >> 1;
                 if (sp && !have_mask) continue;
                 if (sparse_forced && sp != best_sp) continue;
-                if (getenv("PVI_PATCH") && pm != (atoi(getenv("PVI_PATCH")) ? 1 : 0)) continue;
+                if (ovr("PATCH") && pm != (atoi(ovr("PATCH")) ? 1 : 0)) continue;
                 h->patch64 = pm;
                 h->sparse64 = sp;
                 float ms = 0.f;
@@ -3653,10 +3241,7 @@ extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
     const char* path = h->d.dynamics_id == PVI_DYN_TABLE ? (h->packed ? "table-packed" : "table")
                        : (h->d.dtype == PVI_F64 && h->use64) ? "exact-f64v2"
                        : h->d.dtype == PVI_F64 ? "exact-f64"
-                       : h->march_ok ? "march"
-                       : (h->lean_ok && h->lean_persist) ? "lean-persistent"
                        : h->lean_ok ? "lean"
-                       : h->tile_ok ? "tile"
                        : (h->fast_ok && !is_node_dyn(h->d.dynamics_id)) ? "fast"
                        : (h->d.dynamics_id == PVI_DYN_TABLE ? (h->packed ? "table-packed" : "table") : "exact-f32");
     if (h->d.dtype == PVI_F64 && h->use64 && h->d.dynamics_id != PVI_DYN_TABLE) {
@@ -3665,11 +3250,10 @@ extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
                  (int)((unsigned long long)h->stored * 8ull < (1ull << 32)), h->sparse64, h->infrac64);
         return PVI_OK;
     }
-    snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d wgs=%u wpc=%d nbuf=%d npt=%d reach=%d opmag=%d sparse=%d note=%s",
+    snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d npt=%d reach=%d opmag=%d sparse=%d note=%s",
              path, h->LP.TV0, h->LP.TV1, h->lean_grid.x, h->lean_grid.y, h->lean_grid.z, h->lean_block, h->lean_pw1,
              h->lean_lds, h->lean_ok ? h->LP.lsplit : h->F.lsplit, h->LP.tb_tile, h->lean_ok ? h->LP.dma16 : 0,
-             (h->lean_ok && h->lean_persist) ? h->lean_pgrid : 0u, (h->lean_ok && h->lean_persist) ? h->lean_wpc : 0,
-             (h->lean_ok && h->lean_persist) ? h->LP.nbuf : 0, h->lean_ok ? h->LP.npt : 1, h->lean_reach, h->lean_opmag,
+             h->lean_ok ? h->LP.npt : 1, h->lean_reach, h->lean_opmag,
              (h->d.dtype == PVI_F32 && h->sparse64 && h->vmask) ? 1 : 0, h->lean_why);
     return PVI_OK;
 }
@@ -3850,44 +3434,10 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         return PVI_OK;
     }
     if constexpr (sizeof(REAL) == 4) {
-        if (h->march_ok && !h->force_exact) {
-            const float al = (float)alpha;
-            sc.nblocks = (unsigned)h->MP.ncols;
-#define MARCH(DYN)                                                                                                  \
-    {                                                                                                               \
-        auto kfn = k_sweep_march<DYN, PI_T>;                                                                        \
-        if (!h->march_lds_attr && h->march_lds > 48 * 1024) {                                                       \
-            HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PVI_LDS_MAX)); \
-            h->march_lds_attr = true;                                                                               \
-        }                                                                                                           \
-        hipLaunchKernelGGL(kfn, dim3(sc.nblocks), h->march_block, h->march_lds, st, h->P, h->LP, h->MP, h->F.act, h->LP.actc, Jin, \
-                           Jout, pi, al, sc);                                                                       \
-    }
-            if (h->d.dynamics_id == PVI_DYN_CARTPOLE)
-                MARCH(PVI_DYN_CARTPOLE)
-            else
-                MARCH(PVI_DYN_TWOLINK)
-#undef MARCH
-            HIPCHK(hipGetLastError());
-            return PVI_OK;
-        }
-        if (h->lean_ok && h->lean_persist && !h->force_exact) {
-            float al = (float)alpha;
-            sc.nblocks = h->lean_pgrid;
-            const float4* actp = h->F.act;
-            const float* actc = h->LP.actc;
-            const int* win = h->LP.win;
-            const float* tbt = h->LP.tbt;
-            void* args[] = {(void*)&h->P, (void*)&h->LP, (void*)&actp, (void*)&actc, (void*)&Jin, (void*)&Jout, (void*)&pi,
-                            (void*)&al, (void*)&sc, (void*)&win, (void*)&tbt};
-            HIPCHK(hipLaunchKernel(leanp_kernel(h), dim3(h->lean_pgrid), dim3(h->lean_block), args,
-                                   h->lean_lds * h->LP.nbuf, st));
-            return PVI_OK;
-        }
         if (h->lean_ok && !h->force_exact) {
             const float al = (float)alpha;
             sc.nblocks = h->lean_grid.x;
-            sc.split_finish = (sc.nblocks >= 16384u && !getenv("PVI_NO_SPLIT_FINISH")) ? 1 : 0;
+            sc.split_finish = (sc.nblocks >= 16384u && !ovr("NO_SPLIT_FINISH")) ? 1 : 0;
 #define LEAN3(DYN, U, NP) LEAN4(DYN, U, NP, 0)
 #define LEAN4(DYN, U, NP, RSK)                                                                                      \
     {                                                                                                               \
@@ -3902,9 +3452,9 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     }
 #define LEAN(DYN)                                                  \
     if (h->LP.lsplit == 0) {                                       \
-        if (h->LP.RS == 64 && !h->LP.dbg)                          \
+        if (h->LP.RS == 64)                          \
             LEAN4(DYN, true, 1, 64)                                \
-        else if (Dyn<DYN>::DOF == 1 && h->LP.RS == 128 && !h->LP.dbg) \
+        else if (Dyn<DYN>::DOF == 1 && h->LP.RS == 128) \
             LEAN4(DYN, true, 1, 128)                               \
         else                                                       \
             LEAN3(DYN, true, 1)                                    \
@@ -3912,14 +3462,12 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         LEAN3(DYN, false, 1)
             switch (h->d.dynamics_id) {
                 case PVI_DYN_PENDULUM:
-                    if (h->LP.npt == 2 && h->LP.RS == 64 && !h->LP.dbg)
+                    if (h->LP.npt == 2 && h->LP.RS == 64)
                         LEAN4(PVI_DYN_PENDULUM, true, 2, 64)
-                    else if (h->LP.npt == 2 && h->LP.RS == 128 && !h->LP.dbg)
+                    else if (h->LP.npt == 2 && h->LP.RS == 128)
                         LEAN4(PVI_DYN_PENDULUM, true, 2, 128)
                     else if (h->LP.npt == 2)
                         LEAN3(PVI_DYN_PENDULUM, true, 2)
-                    else if (h->LP.npt == 4)
-                        LEAN3(PVI_DYN_PENDULUM, true, 4)
                     else
                         LEAN(PVI_DYN_PENDULUM)
                     break;
@@ -3932,28 +3480,6 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
 #undef LEAN
 #undef LEAN3
 #undef LEAN4
-            HIPCHK(hipGetLastError());
-            return PVI_OK;
-        }
-        if (h->tile_ok && !h->force_exact) {
-            const int blk = h->tile_block;
-            const unsigned gf = grid_for(h->owned << h->T.lsplit, blk);
-            const size_t lds = (size_t)h->T.lds_floats * 4;
-            const float al = (float)alpha;
-            sc.nblocks = gf;
-#define TILE(DYN)                                                                                                 \
-    if (h->T.lsplit == 0)                                                                                         \
-        hipLaunchKernelGGL((k_sweep_tile<DYN, PI_T, true>), gf, blk, lds, st, h->P, h->T, h->F.act, Jin, Jout, pi, \
-                           al, sc);                                                                    \
-    else                                                                                                          \
-        hipLaunchKernelGGL((k_sweep_tile<DYN, PI_T, false>), gf, blk, lds, st, h->P, h->T, h->F.act, Jin, Jout, pi, \
-                           al, sc);
-            switch (h->d.dynamics_id) {
-                case PVI_DYN_PENDULUM: TILE(PVI_DYN_PENDULUM) break;
-                case PVI_DYN_CARTPOLE: TILE(PVI_DYN_CARTPOLE) break;
-                default: TILE(PVI_DYN_TWOLINK) break;
-            }
-#undef TILE
             HIPCHK(hipGetLastError());
             return PVI_OK;
         }
@@ -4008,7 +3534,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
                 sc.nblocks = gp;
             }
             const int sparse = h->sparse64;
-            sc.xcd_remap = (gp >= 64u && !(getenv("PVI_XCD64") && !atoi(getenv("PVI_XCD64")))) ? 1 : 0;
+            sc.xcd_remap = (gp >= 64u && !(ovr("XCD64") && !atoi(ovr("XCD64")))) ? 1 : 0;
             const size_t lds64 = h->levr_bytes + (sparse == 1 ? (size_t)h->P.A * sizeof(Act64) : 0);
 #define S64Q(DYN, PT, SP)                                                                                             \
     if (off32)                                                                                                        \
@@ -4074,7 +3600,6 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
                 const int A = h->A;
                 // cells of Q per pass (16 KB of LDS in float64)
                 int tab_cells = 2048;
-                if (const char* e = getenv("PVI_TAB_CELLS")) tab_cells = std::max(256, atoi(e));  // experiments
                 const int npb = A >= tab_cells ? 1 : std::max(1, std::min(256, tab_cells / A));
                 const int achunk = A >= tab_cells ? tab_cells : A;
                 if (h->packed) {
@@ -4428,7 +3953,7 @@ extern "C" int pvi_set_interpolation(pvi_handle h, int32_t kind) {
         if ((rc = dev_alloc(h, (size_t)h->P.dim[0] * h->P.dim[1], &h->SP.work))) return rc;
         if ((rc = dev_alloc(h, (size_t)h->P.dim[0] * h->P.dim[1], &h->SP.coef))) return rc;
         // chunked substitution: more parallelism than one thread per grid line.  PVI_SPLINE_CHUNK=0 disables.
-        const char* ev = getenv("PVI_SPLINE_CHUNK");
+        const char* ev = ovr("SPLINE_CHUNK");
         const int want = ev ? atoi(ev) : 64;
         const int w0 = spline_warmup(rho0, 64), w1 = spline_warmup(rho1, 64);
         h->SP.chunk0 = (want > 0 && w0 > 0 && h->P.dim[0] > 2 * want) ? want : h->P.dim[0];
@@ -4559,7 +4084,7 @@ extern "C" int pvi_set_tables(pvi_handle h, const double* x_next, const double* 
     // The linear sweep streams PACKED records (k_table_pack), built chunk by chunk from the host tables, so the raw
     // float64 tables ((n+1)*8 bytes per cell) are never resident next to the records.  The raw tables are kept only
     // where a kernel reads them: spline mode, grids beyond int32 offsets, PVI_NO_PACK=1 (the per-sweep table kernel).
-    const bool pack = h->stored < 0x7fffffffLL && !getenv("PVI_NO_PACK") && !h->spline;
+    const bool pack = h->stored < 0x7fffffffLL && !ovr("NO_PACK") && !h->spline;
     h->packed = false;
     if (!pack) {
         if (!h->d_xnext) {

@@ -452,3 +452,22 @@ def test_examples_run_from_a_checkout():
         path_insert = [n.lineno for n in ast.walk(tree) if isinstance(n, ast.Call) and getattr(n.func, "attr", "") == "insert" and
                        "sys.path" in ast.unparse(n.func)]
         assert path_insert and min(path_insert) < first_pkg_import, name
+
+
+def test_no_environment_switch_in_the_product_library():
+    """no environment variable may change what the product library computes.  The only variable
+    libpyrovi.so reads is PVI_RCCL_LIB (the file name of the RCCL library); kernel variants are pinned through the
+    explicit call pvi_override, which refuses keys it does not know."""
+    from pyro_amd import _build, _native
+    blob = open(_build.build(verbose=False), "rb").read()
+    for old in (b"PVI_DBG", b"PVI_PERSIST", b"PVI_MARCH", b"PVI_TILE", b"PVI_ALLOW_F32_CANCEL", b"PVI_GUARD", b"PVI_TV0",
+                b"PVI_LSPLIT", b"PVI_SPARSE", b"PVI_NO_LEAN", b"PVI_NO_FAST", b"PVI_NPT", b"PVI_TUNE"):
+        assert old not in blob, old             # the round-2 environment switches are gone from the binary
+    src = "".join(open(f).read() for f in _build.sources())
+    assert set(re.findall(r'getenv\("([^"]+)"\)', src)) == {"PVI_RCCL_LIB"}
+    _native.override("LSPLIT", 2)
+    _native.override("LSPLIT", None)
+    with pytest.raises(_native.NativeError) as e:
+        _native.override("DBG", 1)
+    assert e.value.code == -1 and "unknown key" in str(e.value)
+    _native.override()

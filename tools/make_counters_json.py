@@ -1,12 +1,13 @@
 """Merge gpurun_out/counters_<w>.json (tools_counters.sh) into profiles/counters.json (read by bench.py)."""
 import json, os, subprocess, sys
-ROUND = os.environ.get("PVI_ROUND", "r02")
+ROUND = os.environ.get("PVI_ROUND", "r03")
 HEAD = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("PVI_HEAD", "?")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(ROOT, "profiles", "counters.json")
 out = json.load(open(dst)) if os.path.exists(dst) else {}
 for w in sys.argv[1:]:
-    src = json.load(open(os.path.join(ROOT, "gpurun_out", "counters_%s.json" % w)))["kernels"]
+    raw = json.load(open(os.path.join(ROOT, "gpurun_out", "counters_%s.json" % w)))
+    src = raw["kernels"]
     kname, sweep = max(((k, v) for k, v in src.items() if "k_sweep" in k), key=lambda kv: (kv[1].get("calls", 0), kv[1].get("SQ_INSTS_VALU", 0.0)))   # the production variant: most launches
     cal = next((v for k, v in src.items() if "to_f64" in k), {})
     out[w] = {
@@ -19,10 +20,10 @@ for w in sys.argv[1:]:
         "calibration_k_to_f64": {k: cal[k] for k in ("FETCH_SIZE", "WRITE_SIZE") if k in cal},
         "wave_cycles_quad": sweep.get("SQ_WAVE_CYCLES"), "wait_any_quad": sweep.get("SQ_WAIT_ANY"),
         "wait_inst_any_quad": sweep.get("SQ_WAIT_INST_ANY"), "active_inst_any_quad": sweep.get("SQ_ACTIVE_INST_ANY"),
-        "kernel": kname,
+        "kernel": kname, "kernel_path": raw.get("kernel_path", ""),
         "source": "profiles/%s_counters_%s.json (rocprofv3 --pmc passes of tools/tools_counters.sh), kernel %s as of commit %s"
                   % (ROUND, w, kname.split("<")[0], HEAD),
     }
-    json.dump({"workload": w, "kernels": src}, open(os.path.join(ROOT, "profiles", "%s_counters_%s.json" % (ROUND, w)), "w"), indent=1)
+    json.dump({"workload": w, "kernel_path": raw.get("kernel_path", ""), "kernels": src}, open(os.path.join(ROOT, "profiles", "%s_counters_%s.json" % (ROUND, w)), "w"), indent=1)
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps({k: v.get("hbm_bytes_per_launch") for k, v in out.items() if isinstance(v, dict)}))

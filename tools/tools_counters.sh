@@ -15,15 +15,29 @@ res = collections.defaultdict(dict)
 for i in (1, 2, 3, 4):
     fs = glob.glob('$OUT/p%d/*counter_collection.csv' % i)
     if not fs: print('no counters pass', i); continue
+    # pvi_create times candidate variants (tile shapes, mappings) with real sweeps of the SAME kernel name: keep, per
+    # kernel, only the dispatches that have the launch geometry of its LAST dispatch -- the production launches
+    rows = list(csv.DictReader(open(fs[0])))
+    geom = lambda r: (r.get('Grid_Size'), r.get('Workgroup_Size'), r.get('LDS_Block_Size'))
+    last = {}
+    for r in rows:
+        last[r['Kernel_Name'].split('(')[0][:64]] = geom(r)
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(fs[0])):
-        acc[r['Kernel_Name'].split('(')[0][:64]][r['Counter_Name']].append(float(r['Counter_Value']))
+    for r in rows:
+        k = r['Kernel_Name'].split('(')[0][:64]
+        if geom(r) == last[k]:
+            acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
     for k, d in acc.items():
         for c, v in d.items():
             res[k][c] = sum(v) / len(v)
             res[k]['calls'] = len(v)
 keep = {k: v for k, v in res.items() if 'sweep' in k or 'to_f64' in k or 'setup' in k}
-json.dump({"workload": "$W", "kernels": keep}, open('/root/repo/gpurun_out/counters_$W.json', 'w'), indent=1)
+path = ''
+try:
+    path = [l for l in open('$OUT/p1.log') if l.startswith('nodes ')][-1].split(' ', 2)[2].strip()
+except Exception as e:
+    print('no kernel path in the log:', e)
+json.dump({"workload": "$W", "kernel_path": path, "kernels": keep}, open('/root/repo/gpurun_out/counters_$W.json', 'w'), indent=1)
 for k, v in keep.items():
     if 'sweep' in k: print(k, json.dumps(v))
 PY
