@@ -1,8 +1,11 @@
-"""Cart-pole swing-up on a 4-D grid, sharded over the GPUs of one node: axis-0 slabs, halo exchange and statistics
-all-reduce by RCCL INSIDE libpyrovi (pvi_shard_*); torch.distributed is only the launcher-side harness that hands
-every rank the communicator id.
+"""Cart-pole swing-up on a 4-D grid, sharded over the GPUs of one node -- through the reference's OWN class surface
+(DynamicProgrammingWithLookUpTable: compute_steps, solve_bellman_equation, J, pi, clean_infeasible_set,
+get_lookup_table_controller, save_latest).  Axis-0 slabs, halo exchange and statistics all-reduce run over RCCL inside
+libpyrovi (pvi_shard_*); torch.distributed is only the launcher-side harness that hands every rank the communicator id.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 examples/cartpole_sharded.py
+
+Every rank runs the same script (the methods are collective); J and pi are the WHOLE grid on every rank once accessed.
 """
 import os
 import sys
@@ -14,25 +17,33 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pyro_amd import _native, parallel
 from pyro_amd.analysis import costfunction
 from pyro_amd.dynamic import cartpole
-from pyro_amd.planning import discretizer
+from pyro_amd.planning import discretizer, dynamicprogramming
 
 local = int(os.environ.get("LOCAL_RANK", "0"))
 dist.init_process_group("gloo")                        # rendezvous only
 rank, world = dist.get_rank(), dist.get_world_size()
 
 sys_ = cartpole.CartPole()
-grid_sys = discretizer.GridDynamicSystem(sys_, [101, 101, 101, 101], [21])
+sys_.xbar = np.array([0, np.pi, 0, 0])                 # upright
+n = int(os.environ.get("GRID", "61"))                  # 101 for BASELINE configs[2]
+grid_sys = discretizer.GridDynamicSystem(sys_, [n, n, n, n], [21])
 qcf = costfunction.QuadraticCostFunction.from_sys(sys_)
-qcf.xbar = np.array([0, np.pi, 0, 0])
 qcf.INF = 1000
 
-ids = [_native.comm_unique_id() if rank == 0 else None]
-dist.broadcast_object_list(ids, src=0)
-vi = parallel.RcclValueIteration(grid_sys, qcf, rank, world, comm_id=ids[0], dtype="float32", device=local)
-for k in range(10):
-    (jmax, dmax, dmin, delta), n = vi.run(20, 1.0, -1.0)       # 20 sweeps per call, no host synchronisation in between
-    if rank == 0:
-        print("%d  max J %.3f  delta %.4f" % (20 * (k + 1), jmax, delta))
-J, pi = vi.owned()                                             # this rank's rows
-vi.close()
+ids = [_native.comm_unique_id() if rank == 0 else None]           # ncclGetUniqueId on one rank ...
+dist.broadcast_object_list(ids, src=0)                            # ... handed to the others by any means
+dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(
+    grid_sys, qcf, dtype="float32", device=local, comm=parallel.RcclComm(rank, world, ids[0]))
+dp.save_time_history = False
+dp.verbose = rank == 0                                 # finalize_backward_step prints on rank 0 (statistics every sweep)
+dp.solve_bellman_equation(tol=0.5)                     # every rank stops at the same sweep
+if rank == 0:
+    print(dp._p.describe())
+    print("per-sweep GPU ms on this rank:", dp._p.shard.timing())
+dp.clean_infeasible_set()                              # on the gathered J / pi
+ctl = dp.get_lookup_table_controller()
+if rank == 0:
+    print("u(hanging, at rest) =", ctl.c(np.array([0.0, 0.0, 0.0, 0.0]), None))
+    dp.save_latest("cartpole_sharded")
+dp._p.close()
 dist.destroy_process_group()

@@ -1840,6 +1840,7 @@ __global__ __launch_bounds__(256) void k_sweep_fast(DevP P, FastP F, const float
 
 
 #include "sweep_lean.inc"
+#include "sweep_lean4.inc"
 
 // =================================================================================================
 // tier B: table-driven sweep for arbitrary sys.f / cf.g (dynamicprogramming.py:564-570 verbatim:
@@ -2346,6 +2347,7 @@ static const char* const OVERRIDE_KEYS[] = {
     "NO_PACK",     // table tier: sweep the raw tables instead of the packed records
     "SPLINE_CHUNK",            // spline mode: rows per chunk of the substitution passes
     "WIN",         // 4-D lean sweep window layout: 0 single floats + ds_read2_b32, 1 position-paired + ds_read_b64
+    "STAGE",       // 4-D lean sweep: 2 or 4 actions staged together
     "TABLES",      // lean sweep per-node coefficient tables: 0 per-node arrays, 1 factorised where the dynamics allow
 };
 static std::vector<std::pair<std::string, std::string>> g_overrides;
@@ -2389,6 +2391,16 @@ struct pvi_problem {
     long long stage_n = 0;
     FastP F;                  // f32 fast path tables
     bool fast_ok = false;
+    Lean4P L4;                // f32 lean path of 4-D grids (sweep_lean4.inc)
+    bool lean4_ok = false;
+    int lean4_block = 512, lean4_rsk = 0, lean4_bands = 1, lean4_tables = 0;
+    void* lean4_tiles = nullptr;  // [grid] Lean4Tile, launch order
+    int lean4_stage = 4;          // actions whose gathers are in flight together (2: fewer registers, more waves)
+    int lean4_ptab_inv = 0;       // bit 0 / 1: the (position node, action) table does not depend on axis 0 / 1
+    long long lean4_ptab_groups = 0;
+    char lean4_cands[256] = "";  // the timed tile shapes of set-up: rows x columns : ms
+    unsigned lean4_grid = 0;
+    size_t lean4_lds = 0;
     LeanP LP;                 // f32 lean path (sweep_lean.inc)
     bool lean_ok = false;
     int lean_pw1 = 2, lean_block = 256;
@@ -2561,6 +2573,436 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
     return 1;
 }
 
+// =====================================================================================================================
+// lean path of 4-D grids (sweep_lean4.inc): set-up tables, tiling candidates, launch schedule
+// =====================================================================================================================
+
+template <typename PI_T>
+static int launch_lean4_t(pvi_problem* h, const float* Jin, float* Jout, float alpha, hipStream_t st, SweepCtl sc) {
+    const Lean4P& L = h->L4;
+    sc.nblocks = h->lean4_grid;
+    sc.split_finish = 1;
+    PI_T* pi = (PI_T*)h->pi;
+#define L4(DYN)                                     \
+    if (h->lean4_stage == 2)                        \
+        L4K(DYN, 2)                                 \
+    else if (h->lean4_stage == 1)                   \
+        L4K(DYN, 1)                                 \
+    else                                            \
+        L4K(DYN, 4)
+#define L4K(DYN, STG)                                                                                                  \
+    {                                                                                                                  \
+        auto kfn = k_sweep_lean4<DYN, PI_T, STG>;                                                                      \
+        if (h->lean4_lds > 48 * 1024)                                                                                  \
+            HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PVI_LDS_MAX));    \
+        hipLaunchKernelGGL(kfn, dim3(h->lean4_grid), dim3(h->lean4_block), h->lean4_lds, st, h->P, L, Jin, Jout, pi, alpha, \
+                           sc, (const float*)L.ptab, (const Lean4Tile*)h->lean4_tiles);                                \
+    }
+    switch (h->d.dynamics_id) {
+        case PVI_DYN_CARTPOLE: L4(PVI_DYN_CARTPOLE) break;
+        case PVI_DYN_NODE_2x1: L4(PVI_DYN_NODE_2x1) break;
+        case PVI_DYN_NODE_2x2: L4(PVI_DYN_NODE_2x2) break;
+        default: L4(PVI_DYN_TWOLINK) break;
+    }
+#undef L4
+#undef L4K
+    hipLaunchKernelGGL(k_sweep_finish, 1, STAT_SHARDS, 0, st, sc);
+    HIPCHK(hipGetLastError());
+    return PVI_OK;
+}
+
+// Row pieces of axis 2 for ONE row i0 of axis 0: cut where the axis-0 corner index of the position row steps (so that a
+// tile sees one pair plane), then into near-equal parts of at most `cap` rows.  Per i0, because a step that falls on a level
+// exactly (v dt / dx an integer) lands one row earlier or later depending on the rounding of x0 + v dt for that i0: one
+// segmentation for all rows would have to cut on both sides and leave one-row pieces (measured: 21 pieces instead of 16 on
+// C3, 63 % of the lanes live).
+static void lean4_row_pieces(const std::vector<int2>& pt0, int i0, int V0, int cap, std::vector<int2>& out) {
+    out.clear();
+    int a = 0;
+    for (int j = 1; j <= V0; ++j) {
+        if (j < V0) {
+            const int2 p = pt0[(size_t)i0 * V0 + j - 1], q = pt0[(size_t)i0 * V0 + j];
+            if ((p.x < 0 ? -0x40000000 : p.x) == (q.x < 0 ? -0x40000000 : q.x)) continue;
+        }
+        const int len = j - a, n = (len + cap - 1) / cap;
+        for (int k = 0; k < n; ++k) {
+            const int s0 = a + (int)((long long)len * k / n), s1 = a + (int)((long long)len * (k + 1) / n);
+            out.push_back(make_int2(s0, s1 - s0));
+        }
+        a = j;
+    }
+}
+// ... for every owned row: [rows][nty] with nty the largest count (shorter lists are padded with empty pieces)
+static void lean4_all_pieces(const std::vector<int2>& pt0, int rows, int row_begin, int V0, int cap, std::vector<int2>& out, int* nty,
+                             int* tv0) {
+    std::vector<std::vector<int2>> per((size_t)rows);
+    *nty = 1;
+    *tv0 = 1;
+    for (int r = 0; r < rows; ++r) {
+        lean4_row_pieces(pt0, row_begin + r, V0, cap, per[(size_t)r]);
+        *nty = std::max(*nty, (int)per[(size_t)r].size());
+        for (auto& pc : per[(size_t)r]) *tv0 = std::max(*tv0, pc.y);
+    }
+    out.assign((size_t)rows * *nty, make_int2(0, 0));
+    for (int r = 0; r < rows; ++r)
+        for (size_t k = 0; k < per[(size_t)r].size(); ++k) out[(size_t)r * *nty + k] = per[(size_t)r][k];
+}
+
+// Launch order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with a private 4 MiB L2.
+// XCD x sweeps ITS chunk of axis 1 for every owned row of axis 0 in turn (bands of row pieces outermost, so that the
+// planes of three consecutive axis-0 rows over the chunk fit its L2): the axis-0 planes a tile gathers from were
+// fetched for the previous row a moment ago.  Lists are interleaved into physical order and padded to equal length.
+static void lean4_schedule(int R, int N1, int nty, int ntx, int nbands, std::vector<unsigned>& out) {
+    std::vector<std::vector<unsigned>> lists(8);
+    for (int x = 0; x < 8; ++x) {
+        const int c0 = (int)((long long)N1 * x / 8), c1 = (int)((long long)N1 * (x + 1) / 8);
+        for (int b = 0; b < nbands; ++b) {
+            const int ty0 = (int)((long long)nty * b / nbands), ty1 = (int)((long long)nty * (b + 1) / nbands);
+            for (int r = 0; r < R; ++r)
+                for (int i1 = c0; i1 < c1; ++i1)
+                    for (int ty = ty0; ty < ty1; ++ty)
+                        for (int tx = 0; tx < ntx; ++tx)
+                            lists[x].push_back((unsigned)(((long long)(r * N1 + i1) * nty + ty) * ntx + tx));
+        }
+    }
+    size_t mx = 0;
+    for (auto& l : lists) mx = std::max(mx, l.size());
+    out.assign(8 * mx, 0xffffffffu);
+    for (int x = 0; x < 8; ++x)
+        for (size_t j = 0; j < lists[x].size(); ++j) out[8 * j + x] = lists[x][j];
+}
+
+struct Lean4Cand {
+    int cap, w;  // rows cap, tile width
+};
+
+// one candidate tiling: row pieces, window boxes, row pitch, schedule.  rc 0 = usable, 1 = does not fit, < 0 error
+static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int w, size_t lds_budget) {
+    const DevP& P = h->P;
+    Lean4P& L = h->L4;
+    const int rows = P.row_end - P.row_begin;
+    std::vector<int2> pieces;
+    int tv0 = 1, nty = 1;
+    lean4_all_pieces(pt0, rows, P.row_begin, P.dim[2], cap, pieces, &nty, &tv0);
+    L.V0 = P.dim[2];
+    L.V1 = P.dim[3];
+    L.ntx = (L.V1 + w - 1) / w;
+    L.TV1 = (L.V1 + L.ntx - 1) / L.ntx;
+    L.TV0 = tv0;
+    L.nty = nty;
+    const int threads = ((L.TV0 * L.TV1 + 63) / 64) * 64;
+    if (threads > 512) return 1;
+    L.tv1_magic = ((1 << 20) + L.TV1 - 1) / L.TV1;
+    L.posdim1 = P.dim[1];
+    L.pd_magic = magic32((unsigned)L.posdim1);
+    L.ntx_magic = magic32((unsigned)L.ntx);
+    L.ntxy_magic = magic32((unsigned)(L.ntx * L.nty));
+    L.vplane = (long long)L.V0 * L.V1;
+    L.owned = h->owned;
+    const long long npos = (long long)rows * P.dim[1], ntiles = npos * L.nty * L.ntx;
+    if (ntiles >= 0x7fffffffLL / 8) return 1;
+    int rc;
+    if (L.rowseg) dev_release(h, (void*)L.rowseg);
+    if (L.win) dev_release(h, L.win);
+    if (L.sched) dev_release(h, (void*)L.sched);
+    L.rowseg = nullptr;
+    L.win = nullptr;
+    L.sched = nullptr;
+    int2* d_seg = nullptr;
+    if ((rc = dev_alloc(h, pieces.size(), &d_seg))) return rc;
+    HIPCHK(hipMemcpyAsync(d_seg, pieces.data(), pieces.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    L.rowseg = d_seg;
+    if ((rc = dev_alloc(h, (size_t)ntiles * 8, &L.win))) return rc;
+    HIPCHK(hipMemsetAsync(L.summary, 0, 6 * sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_lean4_tiles, dim3((unsigned)ntiles), dim3(threads), 0, h->stream, P, L, ntiles);
+    HIPCHK(hipGetLastError());
+    int summary[8];
+    HIPCHK(hipMemcpyAsync(summary, L.summary, sizeof(summary), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));  // (also: `pieces` has been copied)
+    // Row pitch in slots: the fill writes whole groups of four columns, and the pitch is congruent to the tile width modulo
+    // 32 -- a wave covers consecutive tile nodes t = row * TV1 + column, its lanes read slot row * RS + column + shift, and
+    // ds_read_b64 has 32 slot-wide bank groups: with RS = TV1 (mod 32) the slots of the lanes that wrapped to the next tile
+    // row continue the residues of the row above instead of repeating them (measured with pitch 64 on 51-wide tiles:
+    // 3.7 LDS cycles per read instead of 2).
+    int rs = std::max(4, (summary[1] + 3) & ~3);
+    const int rsk = 0;
+    if (!ovr("NO_RS64")) rs += (((L.TV1 - rs) % 32) + 32) % 32;
+    const size_t lds = (size_t)std::max(summary[0], 1) * (size_t)rs * 8 + 256;
+    if (lds > lds_budget) {
+        snprintf(h->lean_why, sizeof(h->lean_why), "tile %dx%d needs %zu LDS bytes (%d window rows x %d pairs; budget %zu)", L.TV0, L.TV1,
+                 lds, summary[0], rs, lds_budget);
+        return 1;
+    }
+    L.RS = rs;
+    h->lean4_rsk = rsk;
+    h->lean4_lds = lds;
+    h->lean4_block = threads;
+    hipLaunchKernelGGL(k_lean4_off, grid_for(h->lean4_ptab_groups * 4), 256, 0, h->stream, L, h->lean4_ptab_groups);
+    // bands of row pieces: three axis-0 rows x (chunk of axis 1 + position reach) x band rows x V1 floats within ~1.5 MB of L2
+    const int n1c = (P.dim[1] + 7) / 8 + 3;
+    const double per_row = 3.0 * n1c * (double)L.V1 * 4.0;
+    const int band_rows = std::max(L.TV0, (int)(1.5e6 / per_row) - (summary[0] ? 12 : 0));
+    const int nbands = std::max(1, std::min(L.nty, (L.V0 + band_rows - 1) / band_rows));
+    h->lean4_bands = nbands;
+    std::vector<unsigned> sched;
+    lean4_schedule(rows, P.dim[1], L.nty, L.ntx, ovr_is("NO_XCD", 1) ? 1 : nbands, sched);
+    if (ovr_is("NO_XCD", 1)) {  // plain order (experiments, tests): tile ids ascending
+        sched.resize((size_t)ntiles);
+        for (long long t = 0; t < ntiles; ++t) sched[(size_t)t] = (unsigned)t;
+    }
+    unsigned* d_sched = nullptr;
+    if ((rc = dev_alloc(h, sched.size(), &d_sched))) return rc;
+    HIPCHK(hipMemcpy(d_sched, sched.data(), sched.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    L.sched = d_sched;
+    h->lean4_grid = (unsigned)sched.size();
+    if (h->lean4_tiles) dev_release(h, h->lean4_tiles);
+    Lean4Tile* d_tiles = nullptr;
+    if ((rc = dev_alloc(h, sched.size(), &d_tiles))) return rc;
+    h->lean4_tiles = d_tiles;
+    hipLaunchKernelGGL(k_lean4_desc, grid_for((long long)sched.size()), 256, 0, h->stream, P, L, (const unsigned*)d_sched,
+                       (long long)sched.size(), d_tiles);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static int lean4_setup(pvi_problem* h) {
+    const DevP& P = h->P;
+    Lean4P& L = h->L4;
+    memset(&L, 0, sizeof(L));
+    h->lean4_ok = false;
+    if (!h->fast_ok || P.dof != 2 || ovr("NO_LEAN") || ovr_is("WIN", 0) || h->stored >= 0x7fffffffLL) return PVI_OK;
+    if (!(h->own_J || (h->d.flags & PVI_FLAG_EXT_J_SLACK))) return PVI_OK;  // the 16-byte window loads may run 12 bytes past a row
+    const int rows = P.row_end - P.row_begin;
+    const long long npos = (long long)rows * P.dim[1];
+    int rc;
+    L.owned = h->owned;
+    h->lean4_stage = ovr("STAGE") ? atoi(ovr("STAGE")) : 2;
+    if (h->lean4_stage != 1 && h->lean4_stage != 4) h->lean4_stage = 2;
+    L.ngroups = (P.A + 3) / 4;
+    float2* tsp_node = nullptr;
+    float* gx_node = nullptr;
+    int2 *pt0 = nullptr, *pt1 = nullptr;
+    if ((rc = dev_alloc(h, (size_t)h->owned, &L.flag))) return rc;
+    if ((rc = dev_alloc(h, (size_t)P.dim[0] * P.dim[2], &pt0))) return rc;
+    if ((rc = dev_alloc(h, (size_t)P.dim[1] * P.dim[3], &pt1))) return rc;
+    if ((rc = dev_alloc(h, 8, &L.summary))) return rc;
+    float* ptab_full = nullptr;
+    if ((rc = dev_alloc(h, (size_t)npos * L.ngroups * 24, &ptab_full))) return rc;
+    if ((rc = dev_alloc(h, (size_t)2 * h->owned, &tsp_node))) return rc;
+    L.pt0 = pt0;
+    L.pt1 = pt1;
+    // g_x: a sum of per-axis terms when Q is diagonal (then no per-node array); TABLES=0 keeps the per-node arrays
+    const bool want_tables = !ovr_is("TABLES", 0);
+    bool diag = want_tables;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            if (i != j && h->d.Q[i * 4 + j] != 0.0) diag = false;
+    if (diag) {
+        for (int d = 0; d < 4; ++d) {
+            std::vector<double> t((size_t)P.dim[d]);
+            for (int k = 0; k < P.dim[d]; ++k) {
+                const double dx = h->d.x_level[d][k] - h->d.xbar[d];
+                // quad_form: row_d = sum_j Q[d][j] dx_j with the off-diagonal terms exactly zero, term = dx_d * row_d
+                t[(size_t)k] = dx * (h->d.Q[d * 4 + d] * dx);
+            }
+            if ((rc = dev_upload(h, t.data(), t.size(), &L.gt[d]))) return rc;
+        }
+    } else if ((rc = dev_alloc(h, (size_t)h->owned, &gx_node))) {
+        return rc;
+    }
+    L.gx = gx_node;
+    HIPCHK(hipMemsetAsync(L.summary, 0, 8 * sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_lean_pairs, grid_for((long long)P.dim[0] * P.dim[2]), 256, 0, h->stream, P, 0, pt0);
+    hipLaunchKernelGGL(k_lean_pairs, grid_for((long long)P.dim[1] * P.dim[3]), 256, 0, h->stream, P, 1, pt1);
+#define L4DISPATCH(MACRO)                                  \
+    switch (h->d.dynamics_id) {                            \
+        case PVI_DYN_CARTPOLE: MACRO(PVI_DYN_CARTPOLE) break; \
+        case PVI_DYN_NODE_2x1: MACRO(PVI_DYN_NODE_2x1) break; \
+        case PVI_DYN_NODE_2x2: MACRO(PVI_DYN_NODE_2x2) break; \
+        default: MACRO(PVI_DYN_TWOLINK) break;                \
+    }
+#define L4PT(DYN) hipLaunchKernelGGL((k_lean4_ptab<DYN>), grid_for(npos * L.ngroups * 4), 256, 0, h->stream, P, L, ptab_full);
+    L4DISPATCH(L4PT)
+#undef L4PT
+    // the (position node, action) table rarely depends on both position axes (cart-pole, two-link arm: H(q) depends on the
+    // second joint only): keep it over the axes it does depend on -- a CU then finds its rows in the scalar cache
+    L.pcs[0] = P.dim[1];
+    L.pcs[1] = 1;
+    L.ptab = ptab_full;
+    h->lean4_ptab_inv = 0;
+    if (want_tables) {
+        const int all = 3;
+        int inv = 0;
+        HIPCHK(hipMemcpyAsync(L.summary + 7, &all, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_lean4_ptab_inv, grid_for(npos * L.ngroups * 24), 256, 0, h->stream, P, L, (const float*)ptab_full, L.summary + 7);
+        HIPCHK(hipMemcpyAsync(&inv, L.summary + 7, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (inv) {
+            const int n0 = (inv & 1) ? 1 : rows, n1 = (inv & 2) ? 1 : P.dim[1];
+            float* compact = nullptr;
+            if ((rc = dev_alloc(h, (size_t)n0 * n1 * L.ngroups * 24, &compact))) return rc;
+            hipLaunchKernelGGL(k_lean4_ptab_compact, grid_for((long long)n0 * n1 * L.ngroups * 24), 256, 0, h->stream, P, L,
+                               (const float*)ptab_full, compact, n0, n1);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(h->stream));
+            dev_release(h, ptab_full);
+            L.ptab = compact;
+            L.pcs[0] = (inv & 1) ? 0 : n1;
+            L.pcs[1] = (inv & 2) ? 0 : 1;
+            h->lean4_ptab_inv = inv;
+        }
+    }
+    h->lean4_ptab_groups = (long long)((h->lean4_ptab_inv & 1) ? 1 : rows) * ((h->lean4_ptab_inv & 2) ? 1 : P.dim[1]) * L.ngroups;
+#define L4ND(DYN) hipLaunchKernelGGL((k_lean4_node<DYN>), grid_for(h->owned), 256, 0, h->stream, P, L, tsp_node, gx_node);
+    L4DISPATCH(L4ND)
+#undef L4ND
+#undef L4DISPATCH
+    HIPCHK(hipGetLastError());
+    int summary[8];
+    HIPCHK(hipMemcpyAsync(summary, L.summary, sizeof(summary), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    auto give_up = [&](const char* why) {
+        snprintf(h->lean_why, sizeof(h->lean_why), "%s", why);
+        dev_release(h, L.flag); dev_release(h, pt0); dev_release(h, pt1); dev_release(h, L.summary); dev_release(h, L.ptab);
+        dev_release(h, tsp_node); dev_release(h, gx_node);
+        if (L.tsp && L.tsp != tsp_node) dev_release(h, (void*)L.tsp);
+        if (L.rowseg) dev_release(h, (void*)L.rowseg);
+        if (L.win) dev_release(h, L.win);
+        if (L.sched) dev_release(h, (void*)L.sched);
+        for (int d = 0; d < 4; ++d) dev_release(h, (void*)L.gt[d]);
+        memset(&L, 0, sizeof(L));
+        return PVI_OK;
+    };
+    if (summary[3]) return give_up((summary[3] & 2) ? "an action fails isavalidinput" : "halo too small");
+    // ---- the axes the displacement does not depend on -> compact table ---------------------------------------------------
+    const long long full[4] = {P.plane, (long long)P.dim[2] * P.dim[3], P.dim[3], 1};
+    int inv = 0;
+    if (want_tables) {
+        const int all = 0xf;
+        HIPCHK(hipMemcpyAsync(L.summary + 6, &all, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_lean4_invariance, grid_for(h->owned), 256, 0, h->stream, P, L, (const float2*)tsp_node);
+        HIPCHK(hipMemcpyAsync(&inv, L.summary + 6, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    h->lean4_tables = inv;
+    if (inv) {
+        const int dims[4] = {rows, P.dim[1], P.dim[2], P.dim[3]};
+        int nk[4];
+        long long cs = 1;
+        for (int d = 3; d >= 0; --d) {
+            nk[d] = (inv >> d) & 1 ? 1 : dims[d];
+            L.cs[d] = (inv >> d) & 1 ? 0 : (int)cs;
+            cs *= nk[d];
+        }
+        L.csize = cs;
+        float2* compact = nullptr;
+        if ((rc = dev_alloc(h, (size_t)2 * cs, &compact))) return rc;
+        hipLaunchKernelGGL(k_lean4_compact, grid_for(cs), 256, 0, h->stream, P, L, (const float2*)tsp_node, compact, nk[0], nk[1], nk[2], nk[3]);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));
+        dev_release(h, tsp_node);
+        tsp_node = nullptr;
+        L.tsp = compact;
+    } else {
+        for (int d = 0; d < 4; ++d) L.cs[d] = (int)full[d];
+        L.csize = h->owned;
+        L.tsp = tsp_node;
+    }
+    // ---- tiling candidates, timed ------------------------------------------------------------------------------------------
+    std::vector<int2> hpt0((size_t)P.dim[0] * P.dim[2]);
+    HIPCHK(hipMemcpy(hpt0.data(), pt0, hpt0.size() * sizeof(int2), hipMemcpyDeviceToHost));
+    const size_t budget = ovr("LDS_KB") ? (size_t)atoi(ovr("LDS_KB")) * 1024 : (size_t)80 * 1024;  // two workgroups per CU
+    std::vector<Lean4Cand> cands;
+    const int V1 = P.dim[3];
+    if (ovr("TV0") && ovr("TV1")) {
+        cands.push_back({atoi(ovr("TV0")), atoi(ovr("TV1"))});
+    } else {
+        // Tile shapes worth timing: for every column split V1 / k, the row caps whose pieces (the step-aligned segments of
+        // axis 2 cut into near-equal parts) fill the workgroup's lanes best -- share of live lanes = nodes of a velocity
+        // plane / (tiles x threads rounded up to whole waves).  The three best caps per width are timed.
+        std::vector<int2> pieces;
+        for (int min_threads : {192, 64}) {  // (small grids: whatever fills a wave)
+            for (int k = 1; k <= 8; ++k) {
+                const int w = (V1 + k - 1) / k;
+                if (w > 128) continue;
+                if (w < 16 && k > 1) break;
+                struct Eff {
+                    double e;
+                    int cap;
+                };
+                std::vector<Eff> effs;
+                int last_tv0 = -1;
+                for (int cap = std::max(1, 512 / w); cap >= 2; --cap) {
+                    lean4_row_pieces(hpt0, P.row_begin + rows / 2, P.dim[2], cap, pieces);  // (a middle row stands for all)
+                    int tv0 = 1;
+                    for (auto& pc : pieces) tv0 = std::max(tv0, pc.y);
+                    if (tv0 == last_tv0) continue;  // the same pieces as the previous cap
+                    last_tv0 = tv0;
+                    const int threads = ((tv0 * w + 63) / 64) * 64;
+                    if (threads > 512 || threads < min_threads) continue;
+                    const double e = (double)P.dim[2] * V1 / ((double)pieces.size() * k * threads);
+                    effs.push_back({e, cap});
+                }
+                std::sort(effs.begin(), effs.end(), [](const Eff& a, const Eff& b) { return a.e > b.e; });
+                for (size_t i = 0; i < effs.size() && i < 4 && cands.size() < 24; ++i)
+                    if (effs[i].e >= 0.75 * effs[0].e) cands.push_back({effs[i].cap, w});
+            }
+            if (!cands.empty()) break;
+        }
+    }
+    const bool tune = !ovr_is("TUNE", 0) && cands.size() > 1;
+    float best_ms = 1e30f;
+    int best = -1;
+    for (size_t ci = 0; ci < cands.size(); ++ci) {
+        rc = lean4_try(h, hpt0, cands[ci].cap, cands[ci].w, budget);
+        if (rc < 0) return rc;
+        if (rc) continue;
+        if (!tune) {
+            best = (int)ci;
+            break;
+        }
+        float ms = 0.f;
+        SweepCtl sc;
+        memset(&sc, 0, sizeof(sc));
+        sc.ctrl = h->ctrl;
+        sc.slot = h->slots;
+        sc.result = h->results;
+        sc.tol = -1.0;
+        for (int rep = 0; rep < 3 && rc == 0; ++rep) {  // one warm-up, two timed
+            if (rep == 1) HIPCHK(hipEventRecord(h->ev0, h->stream));
+            hipLaunchKernelGGL(k_reset_stats, 1, STAT_WORDS, 0, h->stream, h->slots, STAT_WORDS);
+            hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, h->stream, h->ctrl);
+            rc = h->pi_size == 1 ? launch_lean4_t<unsigned char>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc)
+                                 : launch_lean4_t<unsigned short>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc);
+        }
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        {
+            const size_t at = strlen(h->lean4_cands);
+            snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, "%s%dx%d:%.2f", at ? "," : "", L.TV0, L.TV1, ms / 2.f);
+        }
+        if (ms < best_ms) {
+            best_ms = ms;
+            best = (int)ci;
+        }
+    }
+    if (best < 0) return give_up(h->lean_why[0] ? h->lean_why : "no tile shape fits the LDS budget");
+    if (tune) {
+        if ((rc = lean4_try(h, hpt0, cands[(size_t)best].cap, cands[(size_t)best].w, budget))) return rc < 0 ? rc : give_up("tile shape lost");
+        // the timed sweeps wrote into the second J buffer, pi and the control block
+        HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream));
+        HIPCHK(hipMemsetAsync(h->pi, 0, (size_t)h->owned * h->pi_size, h->stream));
+        HIPCHK(hipMemsetAsync(h->J[h->cur ^ 1], 0, (size_t)h->stored * 4, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    h->lean_why[0] = 0;
+    h->lean4_ok = true;
+    return PVI_OK;
+}
+
 static int lean_setup(pvi_problem* h) {
     const DevP& P = h->P;
     LeanP& L = h->LP;
@@ -2571,6 +3013,8 @@ static int lean_setup(pvi_problem* h) {
     if (!h->fast_ok || ovr("NO_LEAN")) return PVI_OK;
     const int DOF = P.dof, M = P.m;
     int rc;
+    if ((rc = lean4_setup(h))) return rc;
+    if (h->lean4_ok) return PVI_OK;  // 4-D grids: the paired-window kernel (sweep_lean4.inc)
     if ((rc = dev_alloc(h, (size_t)DOF * h->owned, &L.ta))) return rc;
     if ((rc = dev_alloc(h, (size_t)DOF * M * h->owned, &L.tB))) return rc;
     if ((rc = dev_alloc(h, (size_t)h->owned, &L.gx))) return rc;
@@ -3241,7 +3685,7 @@ extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
     const char* path = h->d.dynamics_id == PVI_DYN_TABLE ? (h->packed ? "table-packed" : "table")
                        : (h->d.dtype == PVI_F64 && h->use64) ? "exact-f64v2"
                        : h->d.dtype == PVI_F64 ? "exact-f64"
-                       : h->lean_ok ? "lean"
+                       : (h->lean_ok || h->lean4_ok) ? "lean"
                        : (h->fast_ok && !is_node_dyn(h->d.dynamics_id)) ? "fast"
                        : (h->d.dynamics_id == PVI_DYN_TABLE ? (h->packed ? "table-packed" : "table") : "exact-f32");
     if (h->d.dtype == PVI_F64 && h->use64 && h->d.dynamics_id != PVI_DYN_TABLE) {
@@ -3250,7 +3694,16 @@ extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
                  (int)((unsigned long long)h->stored * 8ull < (1ull << 32)), h->sparse64, h->infrac64);
         return PVI_OK;
     }
-    snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d npt=%d reach=%d opmag=%d sparse=%d note=%s",
+    if (h->lean4_ok) {
+        // win=1: position-paired window + ds_read_b64 (sweep_lean4.inc); tables: bit d set = the displacement table does
+        // not span axis d; rowpieces / bands: the step-aligned row pieces of axis 2 and their grouping in the launch order
+        snprintf(buf, (size_t)n, "path=lean tile=%dx%d grid=%ux1x1 block=%d pw1=%d lds_bytes=%zu lsplit=0 tb_tile=1 dma16=0 npt=1 "
+                 "reach=0 opmag=0 sparse=0 win=1 tables=%d ptab=%d gx=%s stage=%d rowpieces=%d bands=%d cands=%s note=%s", h->L4.TV0, h->L4.TV1,
+                 h->lean4_grid, h->lean4_block, h->L4.RS, h->lean4_lds, h->lean4_tables, h->lean4_ptab_inv, h->L4.gx ? "node" : "axes", h->lean4_stage,
+                 h->L4.nty, h->lean4_bands, h->lean4_cands[0] ? h->lean4_cands : "-", h->lean_why);
+        return PVI_OK;
+    }
+    snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d npt=%d reach=%d opmag=%d sparse=%d win=0 tables=0 note=%s",
              path, h->LP.TV0, h->LP.TV1, h->lean_grid.x, h->lean_grid.y, h->lean_grid.z, h->lean_block, h->lean_pw1,
              h->lean_lds, h->lean_ok ? h->LP.lsplit : h->F.lsplit, h->LP.tb_tile, h->lean_ok ? h->LP.dma16 : 0,
              h->lean_ok ? h->LP.npt : 1, h->lean_reach, h->lean_opmag,
@@ -3434,6 +3887,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         return PVI_OK;
     }
     if constexpr (sizeof(REAL) == 4) {
+        if (h->lean4_ok && !h->force_exact) return launch_lean4_t<PI_T>(h, Jin, Jout, (float)alpha, st, sc);
         if (h->lean_ok && !h->force_exact) {
             const float al = (float)alpha;
             sc.nblocks = h->lean_grid.x;

@@ -72,6 +72,7 @@ class DynamicProgramming:
         self.alpha = 1.0
         self.save_time_history = True
         self.verbose = True
+        self.stats_every_sweep = True   # sharded grids: all-reduce the statistics after every sweep (same on all ranks)
         self.t, self.k = self.tf, 0
         self.start_time = time.time()
         self.dtype, self.device, self.comm = np.dtype(dtype), device, comm
@@ -230,8 +231,10 @@ class DynamicProgramming:
             nb = 1 if self._history_ok() else min(self.BATCH, max_sweeps - done)
             if self.sharded:
                 # statistics cost a host synchronisation + an all-reduce per sweep on a sharded grid: every sweep when
-                # they are printed or tested (verbose, tol), else only the last of the batch
-                stats, n = self._p.sweep(nb, self.alpha, tol, every=self.verbose)
+                # they are tested (tol) or wanted (stats_every_sweep, the reference's behaviour), else only the last of the
+                # batch.  The switch decides which collectives run, so it must be the same on every rank -- unlike
+                # `verbose`, which only decides whether THIS rank prints them.
+                stats, n = self._p.sweep(nb, self.alpha, tol, every=self.stats_every_sweep)
                 quiet = n - len(stats)
                 self.k += quiet
                 self.t -= self.grid_sys.dt * quiet

@@ -1,0 +1,19 @@
+#!/bin/bash
+# round-3 profiles: for every workload (a) four rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | two SQ sets, kernel-trace
+# only) -> gpurun_out/counters_<w>.json with the kernel variant they were taken with, (b) kernel-trace stats of
+# `bench.py --workload <w> --no-cpu`; plus kernel-trace stats of the default `python bench.py`.
+cd /root/repo
+export PVI_ROUND=r03
+WL=${WL:-"c3 c4 c2 c2p c5 c5d c1"}
+for w in $WL; do
+  bash tools/tools_counters.sh $w > gpurun_out/r03_counters_$w.log 2>&1
+  S=""; ([ $w = c3 ] || [ $w = c4 ] || [ $w = c5 ] || [ $w = c5d ]) && S="--steps 10 --warmup 2"
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/r03_stats_$w -o s -- python /root/repo/bench.py --workload $w --no-cpu $S > /root/repo/gpurun_out/r03_stats_$w.log 2>&1)
+  tail -1 gpurun_out/r03_stats_$w.log | cut -c1-160
+done
+python tools/make_counters_json.py $WL
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/r03_stats_default -o s -- python /root/repo/bench.py > /root/repo/gpurun_out/r03_bench_default.json 2> /root/repo/gpurun_out/r03_bench_default.err)
+tail -c 400 gpurun_out/r03_bench_default.json
+for w in $WL default; do f=$(find gpurun_out/r03_stats_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f profiles/r03_${w}_bench_kernel_stats.csv; done
+cp gpurun_out/r03_bench_default.json profiles/r03_bench_default.json 2>/dev/null
+ls profiles | grep r03
