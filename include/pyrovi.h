@@ -236,6 +236,19 @@ int pvi_build_tables(pvi_handle h, int32_t row0, int32_t nrows, double* x_next, 
                 (base class DynamicProgramming.compute_backward_step, dynamicprogramming.py:195-236). */
 int pvi_set_tables(pvi_handle h, const double* x_next, const double* G, const uint8_t* ok);
 
+/* PolicyEvaluator.__init__ / compute_lookuptable (dynamicprogramming.py:623-677, :704-735): the one-action-per-node tables
+   of a GIVEN control law on the whole grid,
+     u = ctl.c(x, rbar, t) ; x_next = f(x, u) dt + x ; ok = isavalidinput(x, u) and isavalidstate(x_next) ; G = g(x, u) dt | INF
+   on a handle with closed-form mechanical dynamics and the in-kernel quadratic cost (else PVI_ESTATE).
+     PVI_CTL_TABLE            U [nodes][m] is supplied by the caller (any Python controller, evaluated on the host)
+     PVI_CTL_COMPUTED_TORQUE  pyro/control/nonlinear.py:23-116 on a fully actuated system (pendulum family, two-link arm);
+                              ctl_params = [q_d[dof], 2 zeta w0, w0^2]; U is an output
+   Outputs (host): x_next [nodes][n], ok [nodes], G [nodes]; feed them to a PVI_DYN_TABLE handle with one action. */
+#define PVI_CTL_TABLE 0
+#define PVI_CTL_COMPUTED_TORQUE 1
+int pvi_policy_tables(pvi_handle h, int32_t controller_id, const double* ctl_params, double* U, double* x_next, uint8_t* ok,
+                      double* G);
+
 /* ---- interpolant of J_k ------------------------------------------------------------------------------ */
 #define PVI_INTERP_LINEAR 0          /* RegularGridInterpolator('linear', fill 0), discretizer.py:570-587 (default) */
 #define PVI_INTERP_BICUBIC_SPLINE 1  /* RectBivariateSpline(kx=ky=3, s=0), discretizer.py:590-612: refit every sweep,
@@ -257,9 +270,17 @@ int pvi_set_pi(pvi_handle h, const int64_t* pi_rows, int32_t row0, int32_t nrows
    interpolation of the INPUT values selected by pi, 0 outside the grid; dynamicprogramming.py:72-107),
    dx = f(x,u) (pyro/control/controller.py:328-355), x_{i+1} = dx*dt + x_i (pyro/analysis/simulation.py:298-324).
    X_traj [B][npts][n] and U_traj [B][npts][m] may be NULL; X_end [B][n] may be NULL.  float64, whole-grid handle
-   with in-kernel dynamics. */
+   with closed-form in-kernel dynamics: the mechanical closed forms and the explicit systems PVI_DYN_HELICOPTER ..
+   PVI_DYN_LONGCAR (per-node-table dynamics PVI_DYN_NODE_* and table handles only know f on the grid: PVI_ESTATE). */
 int pvi_rollout(pvi_handle h, int64_t B, const double* X0, int32_t npts, double dt, double* X_traj, double* U_traj,
                 double* X_end);
+/* The sweeps need f only at grid nodes and grid actions (host tables over the levels); a rollout needs it at arbitrary
+   (x, u).  Constants of the CONTINUOUS closed form that are not in dyn_params (n <= 64 doubles), required before
+   pvi_rollout for:
+     PVI_DYN_QUARTERCAR  [terms, a[terms], w[terms], phi[terms]]: ground z = sum a sin(w (x - phi))   suspension.py:73-95
+     PVI_DYN_LONGCAR     [mu_max, mu_slope, rho cdA, m, g, ry, rr]                                     vehicle_propulsion.py:96-184
+   (helicopter, kinematic car, point robot and the mechanical closed forms need none). */
+int pvi_set_rollout_params(pvi_handle h, const double* params, int32_t n);
 
 /* ---- multi-GPU: axis-0 slabs, one process per GPU, RCCL inside the library (no reference counterpart) ------ */
 /* Rank r owns a contiguous block of rows of axis 0 and stores `halo_rows` more on either side.  One sweep =

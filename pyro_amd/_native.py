@@ -16,9 +16,12 @@ DYN_TABLE, DYN_PENDULUM, DYN_CARTPOLE, DYN_TWOLINK = 0, 1, 2, 3
 DYN_NODE_1x1, DYN_NODE_2x1, DYN_NODE_2x2 = 4, 5, 6        # any MechanicalSystem through per-node tables
 DYN_HELICOPTER, DYN_KINCAR, DYN_QUARTERCAR = 7, 8, 9      # the reference's three-dimensional demo systems (n = 3)
 DYN_HOLONOMIC, DYN_LONGCAR = 10, 11                       # point robot with obstacles, longitudinal car (n = 2)
-CLOSED_FORM_IDS = (DYN_PENDULUM, DYN_CARTPOLE, DYN_TWOLINK)    # dynamics pvi_eval_f / pvi_rollout can evaluate anywhere
+CLOSED_FORM_IDS = (DYN_PENDULUM, DYN_CARTPOLE, DYN_TWOLINK)    # dynamics pvi_eval_f can evaluate anywhere
+# ... and pvi_rollout: the explicit systems have continuous closed forms too (their sweeps read host tables at the nodes)
+ROLLOUT_IDS = CLOSED_FORM_IDS + (DYN_HELICOPTER, DYN_KINCAR, DYN_QUARTERCAR, DYN_HOLONOMIC, DYN_LONGCAR)
 COST_TABLE, COST_QUADRATIC, COST_TIME, COST_QUADRATIC_DOMAIN, COST_REACHABILITY = 0, 1, 2, 3, 4
 INTERP_LINEAR, INTERP_BICUBIC_SPLINE = 0, 1
+CTL_TABLE, CTL_COMPUTED_TORQUE = 0, 1
 PVI_EHALO = -5
 FLAG_EXT_J_SLACK = 1
 FLAG_HARD_INF = 2
@@ -79,10 +82,12 @@ SYMBOLS = {
     "pvi_self_check": (C.c_int, [_h, C.c_double, _dp, C.POINTER(C.c_int64)]),
     "pvi_build_tables": (C.c_int, [_h, C.c_int32, C.c_int32, _dp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), _dp]),
     "pvi_set_tables": (C.c_int, [_h, _dp, _dp, C.POINTER(C.c_uint8)]),
+    "pvi_policy_tables": (C.c_int, [_h, C.c_int32, _dp, _dp, _dp, C.POINTER(C.c_uint8), _dp]),
     "pvi_set_interpolation": (C.c_int, [_h, C.c_int32]),
     "pvi_spline_coefficients": (C.c_int, [_h, _dp]),
     "pvi_set_pi": (C.c_int, [_h, C.POINTER(C.c_int64), C.c_int32, C.c_int32]),
     "pvi_rollout": (C.c_int, [_h, C.c_int64, _dp, C.c_int32, C.c_double, _dp, _dp, _dp]),
+    "pvi_set_rollout_params": (C.c_int, [_h, _dp, C.c_int32]),
     "pvi_eval_f": (C.c_int, [C.c_int32, _dp, C.c_int32, C.c_int32, C.c_int64, _dp, _dp, _dp]),
     # multi-GPU: slabs of axis 0 with RCCL inside the library
     "pvi_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
@@ -332,6 +337,11 @@ class Problem:
             raise ValueError("Grid size does not match optimal action table size")
         check(lib().pvi_set_pi(self._h, pi.ctypes.data_as(C.POINTER(C.c_int64)), row0, nrows))
 
+    def set_rollout_params(self, params):
+        """Constants of the system's CONTINUOUS closed form for pvi_rollout (include/pyrovi.h pvi_set_rollout_params)."""
+        p = _f64(params).ravel()
+        check(lib().pvi_set_rollout_params(self._h, _ptr(p), int(p.size)))
+
     def rollout(self, X0, npts, dt, trajectory=True):
         """Closed-loop Euler rollouts of the device policy.  Returns (X [B,npts,n], U [B,npts,m]) or X_end [B,n]."""
         X0 = _f64(np.atleast_2d(X0))
@@ -397,6 +407,20 @@ class Problem:
             xo.ctypes.data_as(u8) if x_next_isok else None, ao.ctypes.data_as(u8) if action_isok else None,
             _ptr(g) if G else None))
         return xn, (xo.astype(bool) if xo is not None else None), (ao.astype(bool) if ao is not None else None), g
+
+    def policy_tables(self, controller_id, ctl_params=None, U=None):
+        """(U [nodes, m], x_next [nodes, n], ok [nodes], G [nodes]) of one control input per node (pvi_policy_tables)."""
+        nodes = self.dims[0] * self.plane
+        if controller_id == CTL_TABLE:
+            U = np.ascontiguousarray(np.asarray(U, dtype=np.float64).reshape(nodes, self.m))
+        else:
+            U = np.empty((nodes, self.m))
+        cp = None if ctl_params is None else _f64(ctl_params)
+        xn, G = np.empty((nodes, self.n)), np.empty(nodes)
+        ok = np.empty(nodes, dtype=np.uint8)
+        check(lib().pvi_policy_tables(self._h, int(controller_id), None if cp is None else _ptr(cp), _ptr(U), _ptr(xn),
+                                      ok.ctypes.data_as(C.POINTER(C.c_uint8)), _ptr(G)))
+        return U, xn, ok.astype(bool), G
 
     def set_tables(self, x_next, G, ok=None):
         """ok=None: look-up-table semantics (INF + alpha*J); ok mask: base-class semantics (exactly INF)."""

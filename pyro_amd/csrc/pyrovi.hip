@@ -54,6 +54,7 @@ struct DevP {
     double dt;
     double c[16];
     double Q[16], S[16], xbar[PVI_MAX_N];
+    double R[4], ubar[PVI_MAX_M], ulb[PVI_MAX_M], uub[PVI_MAX_M];  // policy tables: g_u and isavalidinput at arbitrary inputs
     double EPS, INF;
     int ontarget;
     // isavalidstate beyond the box: axis-aligned obstacles (include/pyrovi.h pvi_desc.obs_*), and the cost functions
@@ -2164,6 +2165,102 @@ __global__ void k_build_tables(DevP P, long long node0, long long nnodes, double
     }
 }
 
+// =================================================================================================
+// policy evaluation tables (dynamicprogramming.py:704-735): one control input per node,
+//   u = ctl.c(x, rbar, t) ; x_next = f(x, u) dt + x ; ok = isavalidinput(x, u) and isavalidstate(x_next) ; G = g(x, u) dt | INF
+// with the control law evaluated in-kernel where it is the reference's ComputedTorqueController on a fully actuated closed
+// form (pyro/control/nonlinear.py:23-116; mechanical.py:186-214):
+//   ddq_r = (0 - (2 zeta w0) dq_e) - (w0^2) q_e ;  forces = ((H ddq_r + C dq) + g) + d ;  u = inv(B) forces, B = I
+// in that operation order (1-dof: the reference's bits; 2-dof: its 2x2 BLAS dots may use fused multiply-adds).
+// =================================================================================================
+template <int DYN>
+struct CtForces;
+template <>
+struct CtForces<PVI_DYN_PENDULUM> {  // pendulum.py:80-150; c[3] = H = m1 lc1^2 + I1
+    __device__ static void u(const double* c, const double* x, const double* tr, const double* ddq, double* u) {
+        const double f = ((c[3] * ddq[0] + 0.0 * x[1]) + c[1] * tr[0]) + c[2] * x[1];
+        u[0] = 1.0 * f;
+    }
+};
+template <>
+struct CtForces<PVI_DYN_TWOLINK> {  // manipulator.py:897-992 / pendulum.py:400-493, the terms of Dyn<PVI_DYN_TWOLINK>::init
+    __device__ static void u(const double* c, const double* x, const double* tr, const double* ddq, double* u) {
+        const double s1 = tr[0], c2 = tr[1], s2 = tr[2], s12 = tr[3];
+        const double dq0 = x[2], dq1 = x[3];
+        const double H00 = (c[0] + c[1] * (c[2] + c[3] * c2)) + c[4];
+        const double H01 = (c[5] + c[6] * c2) + c[4];
+        const double H11 = c[5] + c[4];
+        const double h = c[6] * s2;
+        const double C00 = -h * dq1, C10 = h * dq0, C01 = -h * (dq0 + dq1);
+        const double G0 = -c[7] * s1 - c[8] * s12, G1 = -c[8] * s12;
+        const double f0 = (((H00 * ddq[0] + H01 * ddq[1]) + (C00 * dq0 + C01 * dq1)) + G0) + c[9] * dq0;
+        const double f1 = (((H01 * ddq[0] + H11 * ddq[1]) + (C10 * dq0 + 0.0 * dq1)) + G1) + c[10] * dq1;
+        u[0] = 1.0 * f0 + 0.0 * f1;
+        u[1] = 0.0 * f0 + 1.0 * f1;
+    }
+};
+template <>
+struct CtForces<PVI_DYN_CARTPOLE> {  // (under-actuated: the reference raises NotImplementedError; never launched)
+    __device__ static void u(const double*, const double*, const double*, const double*, double* u) { u[0] = 0.0; }
+};
+
+template <int DYN>
+__global__ void k_policy_tables(DevP P, int controller_id, const double* __restrict__ ctl, double* __restrict__ U,
+                                double* __restrict__ xnext, unsigned char* __restrict__ okout, double* __restrict__ G, long long nodes) {
+    using D = Dyn<DYN>;
+    constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nodes) return;
+    DevP Q = P;
+    Q.row_begin = 0;
+    int idx[N];
+    decode_node<N>(Q, t, idx);
+    double x[N], dx[N], tr[8], u[M], acc[DOF];
+#pragma unroll
+    for (int d = 0; d < N; ++d) {
+        x[d] = P.lev[d][idx[d]];
+        dx[d] = x[d] - P.xbar[d];
+    }
+    D::trig_from_tables(P, idx, tr);
+    if (controller_id == 1) {
+        double ddq[DOF];
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) {
+            const double q_e = x[i] - ctl[i], dq_e = x[DOF + i] - 0.0;
+            ddq[i] = (0.0 - ctl[DOF] * dq_e) - ctl[DOF + 1] * q_e;
+        }
+        CtForces<DYN>::u(P.c, x, tr, ddq, u);
+#pragma unroll
+        for (int k = 0; k < M; ++k) U[t * M + k] = u[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < M; ++k) u[k] = U[t * M + k];
+    }
+    D dyn;
+    dyn.init(P.c, x, tr);
+    dyn.accel(u, acc);
+    bool ok = true;
+    double xn[N], du[M];
+#pragma unroll
+    for (int i = 0; i < DOF; ++i) {
+        xn[i] = x[DOF + i] * P.dt + x[i];
+        xn[DOF + i] = acc[i] * P.dt + x[DOF + i];
+    }
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        ok = ok && !(u[k] < P.ulb[k]) && !(u[k] > P.uub[k]);  // isavalidinput, system.py:208-215
+        du[k] = u[k] - P.ubar[k];
+    }
+#pragma unroll
+    for (int d = 0; d < N; ++d) ok = ok && !(xn[d] < P.lb[d]) && !(xn[d] > P.ub[d]);
+#pragma unroll
+    for (int d = 0; d < N; ++d) xnext[t * N + d] = xn[d];
+    okout[t] = ok;
+    const bool on_target = P.ontarget && (l2norm<N>(dx) < P.EPS);
+    const double g = on_target ? 0.0 : (quad_form<N>(P.Q, dx) + quad_form<M>(P.R, du));
+    G[t] = ok ? g * P.dt : P.INF;
+}
+
 // batched f(x,u) with in-kernel trig (mechanical.py:238-263)
 template <int DYN>
 __global__ void k_eval_f(const double* __restrict__ c16, long long B, const double* __restrict__ X,
@@ -2194,56 +2291,138 @@ __global__ void k_eval_f(const double* __restrict__ c16, long long B, const doub
 // =================================================================================================
 // batched closed-loop Euler rollouts of the look-up-table policy (one thread per trajectory, float64)
 // =================================================================================================
-template <int DYN, typename PI_T>
-__global__ void k_rollout(DevP P, const PI_T* __restrict__ pi, long long B, const double* __restrict__ X0, int npts,
-                          double dt, double* __restrict__ Xt, double* __restrict__ Ut, double* __restrict__ Xe) {
-    using D = Dyn<DYN>;
-    constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M;
+// u_k = n-linear interpolation of input_from_action_id[pi[node], k] over the grid, 0 outside (LookUpTableController.c,
+// dynamicprogramming.py:72-107; scipy's corner order)
+template <int N, int M, typename PI_T>
+__device__ inline void rollout_policy(const DevP& P, const PI_T* __restrict__ pi, const double* x, double* u) {
+    double y[N];
+    int ci[N];
+    bool inb = true;
+    long long base = 0;
+#pragma unroll
+    for (int d = 0; d < N; ++d) {
+        inb = inb && !(x[d] < P.glo[d]) && !(x[d] > P.ghi[d]);
+        ci[d] = find_interval(P.lev[d], P.dim[d], P.glo[d], P.inv_step[d], x[d]);
+        y[d] = (x[d] - P.lev[d][ci[d]]) / (P.lev[d][ci[d] + 1] - P.lev[d][ci[d]]);
+        base += ci[d] * P.strd[d];
+    }
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        double val = 0.0;
+        if (inb) {
+            if (N == 2) {
+                const double v00 = P.utab[(int)pi[base] * M + k], v01 = P.utab[(int)pi[base + P.strd[1]] * M + k];
+                const double v10 = P.utab[(int)pi[base + P.strd[0]] * M + k];
+                const double v11 = P.utab[(int)pi[base + P.strd[0] + P.strd[1]] * M + k];
+                const double a0 = 1.0 - y[0], a1 = 1.0 - y[1];
+                val = v00 * a0 * a1 + v01 * a0 * y[1] + v10 * y[0] * a1 + v11 * y[0] * y[1];
+            } else {
+#pragma unroll
+                for (int corner = 0; corner < (1 << N); ++corner) {
+                    double w = 1.0;
+                    long long off = base;
+#pragma unroll
+                    for (int d = 0; d < N; ++d) {
+                        const int bit = (corner >> (N - 1 - d)) & 1;
+                        w = w * (bit ? y[d] : (1.0 - y[d]));
+                        off += bit ? P.strd[d] : 0;
+                    }
+                    val = val + P.utab[(int)pi[off] * M + k] * w;
+                }
+            }
+        }
+        u[k] = val;
+    }
+}
+
+// mechanical closed forms: f = [dq; ddq] anywhere in the state space
+template <int DYN>
+struct RollMech {
+    static constexpr int N = 2 * Dyn<DYN>::DOF, M = Dyn<DYN>::M;
+    __device__ static void f(const DevP& P, const double*, const double* x, const double* u, double* dx) {
+        constexpr int DOF = Dyn<DYN>::DOF;
+        double tr[8], acc[DOF];
+        Dyn<DYN>::trig_from_state(x, tr);
+        Dyn<DYN> dyn;
+        dyn.init(P.c, x, tr);
+        dyn.accel(u, acc);
+#pragma unroll
+        for (int j = 0; j < DOF; ++j) {
+            dx[j] = x[DOF + j];
+            dx[DOF + j] = acc[j];
+        }
+    }
+};
+// the explicit systems, as functions of a CONTINUOUS state and input (the sweep kernels only need them at grid nodes and
+// grid actions and read host tables there).  rp = pvi_set_rollout_params: per-system constants, see include/pyrovi.h.
+template <int DYN>
+struct RollExpl;
+template <>
+struct RollExpl<PVI_DYN_HELICOPTER> {  // drone.py:613-636
+    static constexpr int N = 3, M = 1;
+    __device__ static void f(const DevP& P, const double*, const double* x, const double* u, double* dx) {
+        dx[0] = P.c[0] * u[0];
+        dx[1] = x[0];
+        dx[2] = P.c[1];
+    }
+};
+template <>
+struct RollExpl<PVI_DYN_KINCAR> {  // vehicle_steering.py:64-86; c = [1 / length]
+    static constexpr int N = 3, M = 2;
+    __device__ static void f(const DevP& P, const double*, const double* x, const double* u, double* dx) {
+        dx[0] = u[0] * cos(x[2]);
+        dx[1] = u[0] * sin(x[2]);
+        dx[2] = u[0] * tan(u[1]) * P.c[0];
+    }
+};
+template <>
+struct RollExpl<PVI_DYN_QUARTERCAR> {  // suspension.py:73-124; rp = [terms, a[terms], w[terms], phi[terms]]
+    static constexpr int N = 3, M = 1;
+    __device__ static void f(const DevP& P, const double* rp, const double* x, const double* u, double* dx) {
+        const int nt = (int)rp[0];
+        double z = 0.0, dz = 0.0;
+        for (int i = 0; i < nt; ++i) {
+            const double a = rp[1 + i], w = rp[1 + nt + i], ph = rp[1 + 2 * nt + i];
+            z = z + a * sin(w * (x[2] - ph));
+            dz = dz + a * w * cos(w * (x[2] - ph));
+        }
+        dx[0] = P.c[0] * ((u[0] - P.c[1] * (x[1] - z)) - P.c[2] * (x[0] - dz));
+        dx[1] = x[0];
+        dx[2] = P.c[3];
+    }
+};
+template <>
+struct RollExpl<PVI_DYN_HOLONOMIC> {  // vehicle_steering.py:238-259
+    static constexpr int N = 2, M = 2;
+    __device__ static void f(const DevP&, const double*, const double*, const double* u, double* dx) {
+        dx[0] = u[0];
+        dx[1] = u[1];
+    }
+};
+template <>
+struct RollExpl<PVI_DYN_LONGCAR> {  // vehicle_propulsion.py:96-184; rp = [mu_max, mu_slope, rho cdA, m, g, ry, rr]
+    static constexpr int N = 2, M = 1;
+    __device__ static void f(const DevP&, const double* rp, const double* x, const double* u, double* dx) {
+        const double mu = rp[0] * (2.0 / (1.0 + exp(-rp[1] * u[0])) - 1.0);
+        const double v = x[1], m = rp[3], g = rp[4];
+        const double fd = 0.5 * rp[2] * v * fabs(v);
+        dx[0] = v;
+        dx[1] = (mu * m * g * rp[6] - fd) / (m * (1.0 + mu * rp[5]));
+    }
+};
+
+template <typename F, typename PI_T>
+__global__ void k_rollout(DevP P, const PI_T* __restrict__ pi, const double* __restrict__ rp, long long B, const double* __restrict__ X0,
+                          int npts, double dt, double* __restrict__ Xt, double* __restrict__ Ut, double* __restrict__ Xe) {
+    constexpr int N = F::N, M = F::M;
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     double x[N];
 #pragma unroll
     for (int d = 0; d < N; ++d) x[d] = X0[b * N + d];
     for (int i = 0; i < npts; ++i) {
-        // u_k = interpolation of input_from_action_id[pi[node], k] over the grid, fill 0 outside
-        double u[M], y[N];
-        int ci[N];
-        bool inb = true;
-        long long base = 0;
-#pragma unroll
-        for (int d = 0; d < N; ++d) {
-            inb = inb && !(x[d] < P.glo[d]) && !(x[d] > P.ghi[d]);
-            ci[d] = find_interval(P.lev[d], P.dim[d], P.glo[d], P.inv_step[d], x[d]);
-            y[d] = (x[d] - P.lev[d][ci[d]]) / (P.lev[d][ci[d] + 1] - P.lev[d][ci[d]]);
-            base += ci[d] * P.strd[d];
-        }
-#pragma unroll
-        for (int k = 0; k < M; ++k) {
-            double val = 0.0;
-            if (inb) {
-                if (N == 2) {
-                    const double v00 = P.utab[(int)pi[base] * M + k], v01 = P.utab[(int)pi[base + P.strd[1]] * M + k];
-                    const double v10 = P.utab[(int)pi[base + P.strd[0]] * M + k];
-                    const double v11 = P.utab[(int)pi[base + P.strd[0] + P.strd[1]] * M + k];
-                    const double a0 = 1.0 - y[0], a1 = 1.0 - y[1];
-                    val = v00 * a0 * a1 + v01 * a0 * y[1] + v10 * y[0] * a1 + v11 * y[0] * y[1];
-                } else {
-#pragma unroll
-                    for (int corner = 0; corner < (1 << N); ++corner) {
-                        double w = 1.0;
-                        long long off = base;
-#pragma unroll
-                        for (int d = 0; d < N; ++d) {
-                            const int bit = (corner >> (N - 1 - d)) & 1;
-                            w = w * (bit ? y[d] : (1.0 - y[d]));
-                            off += bit ? P.strd[d] : 0;
-                        }
-                        val = val + P.utab[(int)pi[off] * M + k] * w;
-                    }
-                }
-            }
-            u[k] = val;
-        }
+        double u[M];
+        rollout_policy<N, M, PI_T>(P, pi, x, u);  // controller.py:328-355: u = ctl.c(x)
         if (Xt) {
 #pragma unroll
             for (int d = 0; d < N; ++d) Xt[(b * npts + i) * N + d] = x[d];
@@ -2252,19 +2431,11 @@ __global__ void k_rollout(DevP P, const PI_T* __restrict__ pi, long long B, cons
 #pragma unroll
             for (int k = 0; k < M; ++k) Ut[(b * npts + i) * M + k] = u[k];
         }
-        if (i + 1 < npts) {
-            double tr[8], acc[DOF], xn[N];
-            D::trig_from_state(x, tr);
-            D dyn;
-            dyn.init(P.c, x, tr);
-            dyn.accel(u, acc);
+        if (i + 1 < npts) {  // simulation.py:298-324: x <- f(x, u) dt + x
+            double dx[N];
+            F::f(P, rp, x, u, dx);
 #pragma unroll
-            for (int j = 0; j < DOF; ++j) {
-                xn[j] = x[DOF + j] * dt + x[j];
-                xn[DOF + j] = acc[j] * dt + x[DOF + j];
-            }
-#pragma unroll
-            for (int d = 0; d < N; ++d) x[d] = xn[d];
+            for (int d = 0; d < N; ++d) x[d] = dx[d] * dt + x[d];
         }
     }
     if (Xe) {
@@ -2420,6 +2591,7 @@ struct pvi_problem {
     double infrac64 = -1.0;   // share of the (node, action) cells that land in the box (4-D float64 handles)
     int patch64 = -1;         // 4-D wave mapping of k_sweep64: 1 = 8 x 8 velocity patches, 0 = consecutive nodes (timed at set-up)
     size_t levr_bytes = 0;
+    const double* roll_params = nullptr;  // constants of the continuous closed form (pvi_set_rollout_params)
     SplineP SP;               // bicubic-spline interpolation mode (sweep_spline.inc)
     bool spline = false;
 };
@@ -3375,6 +3547,12 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
     if (d->cost_id == PVI_COST_TIME || d->cost_id == PVI_COST_REACHABILITY) {
         memset(P.Q, 0, sizeof(P.Q));
         memset(P.S, 0, sizeof(P.S));
+    }
+    memcpy(P.R, d->R, sizeof(double) * d->m * d->m);
+    for (int k = 0; k < d->m; ++k) {
+        P.ubar[k] = d->ubar[k];
+        P.ulb[k] = d->u_lb[k];
+        P.uub[k] = d->u_ub[k];
     }
     P.EPS = d->EPS;
     P.INF = d->INF;
@@ -4529,6 +4707,56 @@ extern "C" int pvi_build_tables(pvi_handle h, int32_t row0, int32_t nrows, doubl
     return PVI_OK;
 }
 
+extern "C" int pvi_policy_tables(pvi_handle h, int32_t controller_id, const double* ctl_params, double* U, double* x_next,
+                                 uint8_t* ok, double* G) {
+    if (!h || !U || !x_next || !ok || !G) return fail(PVI_EINVAL, "NULL argument");
+    const int dyn = h->d.dynamics_id;
+    if (dyn != PVI_DYN_PENDULUM && dyn != PVI_DYN_CARTPOLE && dyn != PVI_DYN_TWOLINK)
+        return fail(PVI_ESTATE, "policy tables need one of the closed-form mechanical dynamics");
+    if (h->d.cost_id != PVI_COST_QUADRATIC) return fail(PVI_ESTATE, "policy tables need the in-kernel quadratic cost");
+    if (controller_id != PVI_CTL_TABLE && controller_id != PVI_CTL_COMPUTED_TORQUE) return fail(PVI_EINVAL, "unknown controller_id %d", controller_id);
+    if (controller_id == PVI_CTL_COMPUTED_TORQUE && (dyn == PVI_DYN_CARTPOLE || !ctl_params))
+        return fail(PVI_EINVAL, "computed torque needs a fully actuated system and its parameters [q_d, 2 zeta w0, w0^2]");
+    HIPCHK(hipSetDevice(h->device));
+    const int N = h->P.n, M = h->P.m;
+    const long long nodes = (long long)h->P.dim[0] * h->plane;
+    double *dU = nullptr, *dX = nullptr, *dG = nullptr, *dC = nullptr;
+    unsigned char* dO = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(dU); (void)hipFree(dX); (void)hipFree(dG); (void)hipFree(dC); (void)hipFree(dO);
+    };
+    hipError_t e = hipMalloc((void**)&dU, (size_t)nodes * M * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&dX, (size_t)nodes * N * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&dG, (size_t)nodes * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&dO, (size_t)nodes);
+    if (e == hipSuccess) e = hipMalloc((void**)&dC, 8 * 8);
+    if (e == hipSuccess && controller_id == PVI_CTL_TABLE) e = hipMemcpyAsync(dU, U, (size_t)nodes * M * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && ctl_params) e = hipMemcpyAsync(dC, ctl_params, (size_t)(N / 2 + 2) * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        const unsigned g = grid_for(nodes);
+        switch (dyn) {
+            case PVI_DYN_PENDULUM:
+                hipLaunchKernelGGL((k_policy_tables<PVI_DYN_PENDULUM>), g, 256, 0, h->stream, h->P, controller_id, dC, dU, dX, dO, dG, nodes);
+                break;
+            case PVI_DYN_CARTPOLE:
+                hipLaunchKernelGGL((k_policy_tables<PVI_DYN_CARTPOLE>), g, 256, 0, h->stream, h->P, controller_id, dC, dU, dX, dO, dG, nodes);
+                break;
+            default:
+                hipLaunchKernelGGL((k_policy_tables<PVI_DYN_TWOLINK>), g, 256, 0, h->stream, h->P, controller_id, dC, dU, dX, dO, dG, nodes);
+                break;
+        }
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(U, dU, (size_t)nodes * M * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(x_next, dX, (size_t)nodes * N * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(G, dG, (size_t)nodes * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ok, dO, (size_t)nodes, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(PVI_EHIP, "pvi_policy_tables failed: %s", hipGetErrorString(e));
+    return PVI_OK;
+}
+
 extern "C" int pvi_set_tables(pvi_handle h, const double* x_next, const double* G, const uint8_t* ok) {
     if (!h || !x_next || !G) return fail(PVI_EINVAL, "NULL argument");
     if (h->d.dynamics_id != PVI_DYN_TABLE) return fail(PVI_ESTATE, "handle was created with in-kernel dynamics");
@@ -4654,11 +4882,24 @@ extern "C" int pvi_set_pi(pvi_handle h, const int64_t* pr, int32_t row0, int32_t
     return PVI_OK;
 }
 
+extern "C" int pvi_set_rollout_params(pvi_handle h, const double* params, int32_t n) {
+    if (!h || (n > 0 && !params) || n < 0 || n > 64) return fail(PVI_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<double> buf(64, 0.0);
+    for (int i = 0; i < n; ++i) buf[(size_t)i] = params[i];
+    if (h->roll_params) dev_release(h, (void*)h->roll_params);
+    h->roll_params = nullptr;
+    return dev_upload(h, buf.data(), buf.size(), &h->roll_params);
+}
+
 extern "C" int pvi_rollout(pvi_handle h, int64_t B, const double* X0, int32_t npts, double dt, double* X_traj,
                            double* U_traj, double* X_end) {
     if (!h || !X0) return fail(PVI_EINVAL, "NULL argument");
-    if (h->d.dynamics_id == PVI_DYN_TABLE || is_node_dyn(h->d.dynamics_id) || is_dyn3(h->d.dynamics_id))
-        return fail(PVI_ESTATE, "rollouts need the closed-form mechanical dynamics (node / level tables only cover the grid nodes)");
+    const int dyn = h->d.dynamics_id;
+    if (dyn == PVI_DYN_TABLE || is_node_dyn(dyn))
+        return fail(PVI_ESTATE, "rollouts need closed-form dynamics (look-up / per-node tables only cover the grid nodes)");
+    if ((dyn == PVI_DYN_QUARTERCAR || dyn == PVI_DYN_LONGCAR) && !h->roll_params)
+        return fail(PVI_ESTATE, "this system's continuous closed form needs pvi_set_rollout_params first");
     if (h->P.store_begin != 0 || h->P.store_end != h->P.dim[0] || h->P.row_begin != 0 || h->P.row_end != h->P.dim[0])
         return fail(PVI_ESTATE, "rollouts need a whole-grid handle");
     if (B <= 0 || npts < 1) return PVI_OK;
@@ -4675,17 +4916,22 @@ extern "C" int pvi_rollout(pvi_handle h, int64_t B, const double* X0, int32_t np
     if (e == hipSuccess) e = hipMemcpyAsync(dX0, X0, (size_t)B * N * 8, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
         const unsigned g = grid_for(B, 64);
-#define ROLL(DYN)                                                                                                    \
+#define ROLL(F)                                                                                                      \
     if (h->pi_size == 1)                                                                                             \
-        hipLaunchKernelGGL((k_rollout<DYN, unsigned char>), g, 64, 0, h->stream, h->P, (const unsigned char*)h->pi,   \
-                           (long long)B, dX0, npts, dt, dXt, dUt, dXe);                                              \
+        hipLaunchKernelGGL((k_rollout<F, unsigned char>), g, 64, 0, h->stream, h->P, (const unsigned char*)h->pi,     \
+                           h->roll_params, (long long)B, dX0, npts, dt, dXt, dUt, dXe);                              \
     else                                                                                                             \
-        hipLaunchKernelGGL((k_rollout<DYN, unsigned short>), g, 64, 0, h->stream, h->P, (const unsigned short*)h->pi, \
-                           (long long)B, dX0, npts, dt, dXt, dUt, dXe);
-        switch (h->d.dynamics_id) {
-            case PVI_DYN_PENDULUM: ROLL(PVI_DYN_PENDULUM) break;
-            case PVI_DYN_CARTPOLE: ROLL(PVI_DYN_CARTPOLE) break;
-            default: ROLL(PVI_DYN_TWOLINK) break;
+        hipLaunchKernelGGL((k_rollout<F, unsigned short>), g, 64, 0, h->stream, h->P, (const unsigned short*)h->pi,   \
+                           h->roll_params, (long long)B, dX0, npts, dt, dXt, dUt, dXe);
+        switch (dyn) {
+            case PVI_DYN_PENDULUM: ROLL(RollMech<PVI_DYN_PENDULUM>) break;
+            case PVI_DYN_CARTPOLE: ROLL(RollMech<PVI_DYN_CARTPOLE>) break;
+            case PVI_DYN_TWOLINK: ROLL(RollMech<PVI_DYN_TWOLINK>) break;
+            case PVI_DYN_HELICOPTER: ROLL(RollExpl<PVI_DYN_HELICOPTER>) break;
+            case PVI_DYN_KINCAR: ROLL(RollExpl<PVI_DYN_KINCAR>) break;
+            case PVI_DYN_QUARTERCAR: ROLL(RollExpl<PVI_DYN_QUARTERCAR>) break;
+            case PVI_DYN_HOLONOMIC: ROLL(RollExpl<PVI_DYN_HOLONOMIC>) break;
+            default: ROLL(RollExpl<PVI_DYN_LONGCAR>) break;
         }
 #undef ROLL
         e = hipGetLastError();

@@ -59,6 +59,12 @@ class MechanicalSystem(system.ContinuousDynamicSystem):
     def generalized_forces(self, q, dq, ddq, t=0):
         return self.H(q) @ ddq + self.C(q, dq) @ dq + self.g(q) + self.d(q, dq)
 
+    def actuator_forces(self, q, dq, ddq, t=0):
+        """Inverse dynamics u = inv(B)(H ddq + C dq + g + d), fully actuated systems only (mechanical.py:201-218)."""
+        if self.dof != self.m:
+            raise NotImplementedError
+        return np.dot(np.linalg.inv(self.B(q)), self.generalized_forces(q, dq, ddq, t))
+
     def ddq(self, q, dq, u, t=0):
         rhs = self.B(q) @ u - self.C(q, dq) @ dq - self.g(q) - self.d(q, dq)
         return np.linalg.inv(self.H(q)) @ rhs

@@ -48,7 +48,7 @@ class SinglePendulum(mechanical.MechanicalSystem):
             return mechanical.MechanicalSystem.device_dynamics(self)
         H = self.m1 * self.lc1 ** 2 + self.I1
         gc = self.m1 * self.gravity * self.lc1
-        return _native.DYN_PENDULUM, [1.0 / float(H), self._gravity_sign * gc, float(self.d1)]
+        return _native.DYN_PENDULUM, [1.0 / float(H), self._gravity_sign * gc, float(self.d1), float(H)]
 
     def device_trig(self, x_level):
         if not self._closed_form():

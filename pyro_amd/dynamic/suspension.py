@@ -55,6 +55,13 @@ class QuarterCarOnRoughTerrain(system.ContinuousDynamicSystem):
             return None
         return _native.DYN_QUARTERCAR, [1. / self.mass, float(self.k), float(self.b), float(self.vx)]
 
+    def device_rollout_params(self):
+        """Constants of the continuous closed form for GPU rollouts (pvi_set_rollout_params): the stock sum-of-sines ground
+        [terms, a, w, phi]; a subclass with its own z / dz gets None -> the host loop."""
+        if not self.stock_model(QuarterCarOnRoughTerrain, ("f", "z", "dz")) or 1 + 3 * self.a.size > 64:
+            return None
+        return np.concatenate([[float(self.a.size)], self.a, self.w, self.phi]).astype(float)
+
     def device_trig(self, x_level):
         lv = x_level[2]
         return (np.array([self.z(lv[i]) for i in range(len(lv))], dtype=float),

@@ -83,6 +83,11 @@ class LongitudinalFrontWheelDriveCarWithWheelSlipInput(system.ContinuousDynamicS
         m, g = self.mass, self.gravity
         return _native.DYN_LONGCAR, [float(m), float(ry), float(m * g * rr), float(m * g * rf)]
 
+    def device_rollout_params(self):
+        """Constants of the continuous closed form for GPU rollouts: [mu_max, mu_slope, rho cdA, m, g, ry, rr]."""
+        ry, rr, rf = self.compute_ratios()
+        return np.array([self.mu_max, self.mu_slope, self.rho * self.cdA, self.mass, self.gravity, ry, rr], dtype=float)
+
     def device_trig(self, x_level):
         rcda = self.rho * self.cdA
         v = x_level[1]

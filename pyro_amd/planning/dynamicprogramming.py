@@ -336,12 +336,17 @@ class DynamicProgramming:
         (controller.py:328-355, simulation.py:298-324).  Returns t [n], X [B,n,sys.n], U [B,n,sys.m]."""
         dt = (tf + 0.0) / (n - 1)
         t = np.linspace(0, tf, n)
-        closed_form = self.tier == "fused" and not self.sharded and self._p.dynamics_id in _native.CLOSED_FORM_IDS
+        closed_form = self.tier == "fused" and not self.sharded and self._p.dynamics_id in _native.ROLLOUT_IDS
+        rp = self.sys.device_rollout_params() if (closed_form and hasattr(self.sys, "device_rollout_params")) else ()
+        if rp is None:
+            closed_form = False                 # e.g. a quarter car with its own terrain: arbitrary Python again
         if closed_form:
+            if len(rp):                         # constants of the continuous closed form (terrain, tyre curve)
+                self._p.set_rollout_params(rp)
             self._p.set_pi(self.pi)             # the host policy may have been edited (clean_infeasible_set)
             X, U = self._p.rollout(X0, n, dt)
             return t, X, U
-        # systems without a closed-form kernel (table tier, per-node tables): the reference's own loop --
+        # systems whose f is arbitrary Python (table tier, per-node tables of generic mechanical systems): the reference's loop --
         # u = ctl.c(x, t), x <- x + f(x, u, t) dt (controller.py:328-355, simulation.py:298-324) -- on the host
         ctl = self.get_lookup_table_controller()
         X0 = np.atleast_2d(np.asarray(X0, dtype=float))
@@ -504,18 +509,45 @@ class PolicyEvaluator(DynamicProgramming):
     def _make_engine(self):
         g, s = self.grid_sys, self.sys
         N = g.nodes_n
-        X = g.state_from_node_id
-        self.x_next_table = np.zeros((N, s.n))
-        self.G = np.zeros(N)
-        ok = np.zeros(N, dtype=bool)
-        r = self.ctl.rbar
-        for i in range(N):
-            x = X[i]
-            u = self.ctl.c(x, r, self.t)
-            x_next = s.f(x, u, self.t) * g.dt + x
-            self.x_next_table[i] = x_next
-            ok[i] = s.isavalidinput(x, u) and s.isavalidstate(x_next)
-            self.G[i] = self.cf.g(x, u, self.t) * g.dt if ok[i] else self.cf.INF
+        if self.comm is not None:
+            raise NotImplementedError("policy evaluation over a sharded grid")
+        self.tables_on = "host"
+        dd = device_dynamics_of(s)
+        cost = device_cost_of(self.cf, s)
+        closed = (dd is not None and dd[0] in _native.CLOSED_FORM_IDS and cost is not None and "kind" not in cost)
+        ctl_dev = self.ctl.device_controller(s) if (closed and hasattr(self.ctl, "device_controller")) else None
+        if closed:
+            # u(x) by the library when the control law has a kernel (the reference's ComputedTorqueController), else by
+            # the O(N) Python calls of ctl.c; f, isavalidinput / isavalidstate and g in ONE kernel either way (the
+            # reference loops over the nodes in Python for all of it, dynamicprogramming.py:704-735)
+            p = g._device_problem(cost=cost, device=self.device)
+            try:
+                if ctl_dev is not None:
+                    q = np.asarray(ctl_dev[1], dtype=float)
+                    k1, k2 = 2 * q[-2] * q[-1], q[-1] ** 2           # (2 zeta) w0 and w0^2: nonlinear.py:107
+                    U, xn, ok, G = p.policy_tables(ctl_dev[0], np.concatenate([q[:-2], [k1, k2]]))
+                    self.tables_on = "gpu: controller + dynamics + cost"
+                else:
+                    X, r = g.state_from_node_id, self.ctl.rbar
+                    U0 = np.array([np.atleast_1d(self.ctl.c(X[i], r, self.t)) for i in range(N)], dtype=float)
+                    U, xn, ok, G = p.policy_tables(_native.CTL_TABLE, None, U0)
+                    self.tables_on = "gpu: dynamics + cost (controller on the host)"
+            finally:
+                p.close()
+            self.U, self.x_next_table, self.G = U, xn, G
+        else:
+            X = g.state_from_node_id
+            self.x_next_table = np.zeros((N, s.n))
+            self.G = np.zeros(N)
+            ok = np.zeros(N, dtype=bool)
+            r = self.ctl.rbar
+            for i in range(N):
+                x = X[i]
+                u = self.ctl.c(x, r, self.t)
+                x_next = s.f(x, u, self.t) * g.dt + x
+                self.x_next_table[i] = x_next
+                ok[i] = s.isavalidinput(x, u) and s.isavalidstate(x_next)
+                self.G[i] = self.cf.g(x, u, self.t) * g.dt if ok[i] else self.cf.INF
         one = [np.zeros(1) for _ in range(s.m)]                     # a single placeholder action
         self.tier = "table"
         self._p = _native.Problem(g.x_level, one, s.x_lb, s.x_ub, np.zeros(s.m), np.zeros(s.m), g.dt, dtype=self.dtype,

@@ -902,6 +902,76 @@ def test_policy_evaluator_classes():
     assert (ev.pi == 0).all()
 
 
+def test_policy_evaluator_tables_are_built_on_the_gpu():
+    """examples/demos_by_tool/dynamicprogramming/policy_evaluator_with_computed_torque.py without its O(N)
+    Python loop.  With the reference's ComputedTorqueController (pyro/control/nonlinear.py:23-116, mirrored in
+    pyro_amd.control.nonlinear) on a closed-form system the control law, f, the validity tests and g all run in one kernel
+    (pvi_policy_tables); the inputs equal the reference controller's bit for bit (golden U), the tables its x_next_table / G,
+    J after 10 sweeps its J.  Any other controller: ctl.c on the host, the rest on the GPU; a system without a closed form:
+    the reference's loop."""
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.control import controller, nonlinear
+    from pyro_amd.dynamic import manipulator, mountaincar, pendulum
+    from pyro_amd.planning import discretizer, dynamicprogramming
+    g = load("policy_eval_41x41")
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = pendulum.SinglePendulum()
+        s.x_ub, s.x_lb = g["x_ub"].copy(), g["x_lb"].copy()
+        s.u_ub, s.u_lb = g["u_ub"].copy(), g["u_lb"].copy()
+        grid = discretizer.GridDynamicSystem(s, [41, 41], [11], 0.05, False)
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+        q.xbar, q.INF = g["xbar"].copy(), float(g["INF"])
+        q.S = g["S"].copy()
+        ctl = nonlinear.ComputedTorqueController(s)
+        ctl.rbar = np.array([-3.14])
+        ev = dynamicprogramming.PolicyEvaluatorWithLookUpTable(ctl, grid, q)
+        ev.save_time_history = False
+    assert ev.tables_on == "gpu: controller + dynamics + cost"
+    assert np.array_equal(ev.U, g["U"])                                     # the reference controller's inputs, bit for bit
+    np.testing.assert_allclose(ev.x_next_table, g["x_next_table"], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(ev.G, g["G"], rtol=1e-13, atol=1e-13)
+    assert np.array_equal(ev.J, g["J0"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        ev.compute_steps(10)
+    assert relerr(ev.J, g["J_10"]) < 1e-12 and (ev.pi == 0).all()
+
+    # an arbitrary Python controller on the same system: inputs on the host, tables on the GPU, same tables
+    class Wrapped(controller.StaticController):
+        def __init__(self):
+            super().__init__(1, 1, 2)
+            self.rbar = np.array([-3.14])
+
+        def c(self, y, r, t=0):
+            return ctl.c(y, r, t)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ev2 = dynamicprogramming.PolicyEvaluatorWithLookUpTable(Wrapped(), grid, q)
+    assert ev2.tables_on == "gpu: dynamics + cost (controller on the host)"
+    assert np.array_equal(ev2.x_next_table, ev.x_next_table) and np.array_equal(ev2.G, ev.G)
+
+    # the two-link arm (dof = m = 2): kernel against the mirror of the reference's controller + its own loop
+    with contextlib.redirect_stdout(io.StringIO()):
+        s2 = manipulator.TwoLinkManipulator()
+        s2.u_ub, s2.u_lb = np.array([400.0, 400.0]), np.array([-400.0, -400.0])
+        g2 = discretizer.GridDynamicSystem(s2, [7, 7, 7, 7], [3, 3], 0.01)
+        q2 = costfunction.QuadraticCostFunction.from_sys(s2)
+        c2 = nonlinear.ComputedTorqueController(s2)
+        c2.rbar = np.array([0.3, -0.2]); c2.w0, c2.zeta = 2, 0.9
+        ev3 = dynamicprogramming.PolicyEvaluator(c2, g2, q2)
+    assert ev3.tables_on == "gpu: controller + dynamics + cost"
+    X = g2.state_from_node_id
+    Uh = np.array([c2.c(X[i], c2.rbar, 0) for i in range(g2.nodes_n)])
+    assert np.abs(ev3.U - Uh).max() <= 1e-12 * np.abs(Uh).max()
+    Xn = np.array([s2.f(X[i], Uh[i]) * g2.dt + X[i] for i in range(g2.nodes_n)])
+    assert np.abs(ev3.x_next_table - Xn).max() <= 1e-10 * np.abs(Xn).max()
+
+    # no closed form (generic mechanical tier): the reference's loop, as before
+    with contextlib.redirect_stdout(io.StringIO()):
+        s4 = mountaincar.MountainCar()
+        g4 = discretizer.GridDynamicSystem(s4, [21, 21], [3])
+        ev4 = dynamicprogramming.PolicyEvaluator(Wrapped(), g4, costfunction.QuadraticCostFunction.from_sys(s4))
+    assert ev4.tables_on == "host"
+
+
 # ------------------------------------------------------------------------------------- edge cases
 def _custom_problem(kind, dims, udims, dt=0.05, alpha=1.0, seed=0, fancy_cost=False, INF=500.0, EPS=1e-3, bounds=None):
     rng = np.random.default_rng(seed)
@@ -1373,6 +1443,79 @@ def test_closed_loop_rollout_of_a_node_tier_system_falls_back_to_the_host_loop()
     assert np.allclose(U[0, 0], ctl.c(np.array([-1.0, 0.0]), 0))
     assert np.allclose(X[0, 1], X[0, 0] + dp.sys.f(X[0, 0], U[0, 0], 0) * (20.0 / 2000))
     assert np.all(np.isfinite(X)) and np.all(X[:, :, 0] > -1.8) and np.all(X[:, :, 0] < 0.3)
+
+
+def _host_closed_loop(dp, X0, tf, n):
+    """The reference's own closed loop: u = ctl.c(x, t), x <- x + f(x, u, t) dt (controller.py:328-355, simulation.py:298-324)."""
+    ctl = dp.get_lookup_table_controller()
+    dt = tf / (n - 1)
+    X0 = np.atleast_2d(np.asarray(X0, dtype=float))
+    X = np.empty((X0.shape[0], n, dp.sys.n)); U = np.empty((X0.shape[0], n, dp.sys.m))
+    for b, x in enumerate(X0):
+        for i in range(n):
+            u = np.atleast_1d(ctl.c(x, i * dt))
+            X[b, i], U[b, i] = x, u
+            x = x + np.asarray(dp.sys.f(x, u, i * dt), dtype=float) * dt
+    return X, U
+
+
+@pytest.mark.gpu
+def test_closed_loop_rollouts_of_the_explicit_systems_run_on_the_gpu():
+    """pvi_rollout for the explicit (non-mechanical) demo systems -- helicopter tunnel, kinematic car,
+    quarter car on its sum-of-sines ground, point robot, longitudinal car with the tyre curve -- as functions of a
+    CONTINUOUS state and input; simulate_closed_loop no longer drops to the Python double loop for them.  Against the
+    reference's own loop (controller interpolation + system f + Euler) on the same policy."""
+    from pyro_amd import _native
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import drone, suspension, vehicle_propulsion, vehicle_steering
+    from pyro_amd.planning import discretizer, dynamicprogramming
+    rng = np.random.default_rng(5)
+    cases = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = drone.ConstantSpeedHelicopterTunnel()
+        cases.append((s, discretizer.GridDynamicSystem(s, [11, 11, 11], [5], 0.3), {}))
+        s = vehicle_steering.KinematicCarModelwithObstacles()
+        cases.append((s, discretizer.GridDynamicSystem(s, [21, 21, 11], [3, 3], 0.1), {}))
+        s = suspension.QuarterCarOnRoughTerrain()
+        cases.append((s, discretizer.GridDynamicSystem(s, [13, 11, 21], [5], 0.05), {}))
+        s = vehicle_steering.HolonomicMobileRobotwithObstacles()
+        cases.append((s, discretizer.GridDynamicSystem(s, [21, 21], [3, 3]), {}))
+        s = vehicle_propulsion.LongitudinalFrontWheelDriveCarWithWheelSlipInput()
+        s.x_ub[1] = 15; s.x_lb[1] = 0
+        cases.append((s, discretizer.GridDynamicSystem(s, [31, 31], [7], 0.05), {}))
+    for s, gs, _ in cases:
+        with contextlib.redirect_stdout(io.StringIO()):
+            cf = costfunction.QuadraticCostFunction.from_sys(s)
+            cf.INF = 1e4
+            dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(gs, cf)
+            dp.save_time_history = False
+            dp.compute_steps(15)
+        assert dp.tier == "fused" and dp._p.dynamics_id in _native.ROLLOUT_IDS, s.name
+        X0 = s.x_lb + (0.2 + 0.6 * rng.random((6, s.n))) * (s.x_ub - s.x_lb)
+        t, X, U = dp.simulate_closed_loop(X0, tf=2.0, n=201)
+        Xh, Uh = _host_closed_loop(dp, X0, 2.0, 201)
+        assert X.shape == Xh.shape and U.shape == Uh.shape
+        scale = np.abs(Xh).max()
+        assert np.abs(X - Xh).max() <= 1e-9 * scale, (s.name, np.abs(X - Xh).max())
+        assert np.abs(U - Uh).max() <= 1e-9 * max(np.abs(Uh).max(), 1.0), s.name
+    # a quarter car with ITS OWN ground keeps the sweep kernel (tables over the levels) but not the continuous closed form
+    class Bumpy(suspension.QuarterCarOnRoughTerrain):
+        def z(self, x):
+            return 0.1 * np.cos(x)
+
+        def dz(self, x):
+            return -0.1 * np.sin(x)
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = Bumpy()
+        gs = discretizer.GridDynamicSystem(s, [9, 9, 11], [3], 0.05)
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(gs, costfunction.QuadraticCostFunction.from_sys(s))
+        dp.save_time_history = False
+        dp.compute_steps(3)
+    assert dp.tier == "fused" and s.device_rollout_params() is None
+    X0 = np.array([[0.5, -0.5, 1.0]])
+    t, X, U = dp.simulate_closed_loop(X0, tf=0.5, n=51)
+    Xh, Uh = _host_closed_loop(dp, X0, 0.5, 51)
+    assert np.array_equal(X, Xh) and np.array_equal(U, Uh)
 
 
 @pytest.mark.gpu
