@@ -2,7 +2,7 @@
 """
 bench.py -- value-iteration sweep throughput on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c2|c2p|c3|c4|c5|<custom>]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c2|c2p|c3|c4|c5|c5d|h3|<custom>]
 
 A "step" is one VI sweep (one Bellman backup of every state-action cell of the grid); J is resident in HBM before the
 timed region.  W untimed sweeps, then batches of exactly K sweeps, each batch bracketed by a device synchronisation,
@@ -251,7 +251,9 @@ def measure(name, steps, warmup, keep_handle=False):
     desc = p.describe()
     ctr, ctr_err = check_counters(load_counters(cfg["name"]), desc)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    flops_cell = {2: 30, 4: 90}[g.sys.n] if g.sys.m == 1 else 120
+    # pendulum 30, cart-pole 90, two-link 120; the helicopter's dynamics are three multiplies, its trilinear
+    # interpolation 14 lerp flops + cost and minimum
+    flops_cell = ({2: 30, 3: 40, 4: 90}[g.sys.n] if g.sys.m == 1 else 120)
     # Cells whose x_next leaves the grid box cost exactly INF (Q = INF + alpha*0): the sweeps that walk set-up's validity
     # masks (sparse=1) never evaluate them.  `value` counts every state-action cell of the grid (BASELINE's metric: each
     # one IS updated); flop rates must only count the cells that were computed.
@@ -383,7 +385,7 @@ def run_single(args):
     if args.with_secondary:
         sec = {}
         for name, st, wu in (("c2", 2000, 200), ("c2p", 2000, 200), ("c5", 10, 2), ("c5d", 5, 2), ("c4", 5, 2),
-                             ("c1", 2000, 200)):
+                             ("c1", 2000, 200), ("h3", 200, 20)):
             try:
                 frag, scfg, sp = measure(name, st, wu, keep_handle=(name == "c2p"))
                 if sp is not None:                       # north-star grid: small enough for its own CPU leg

@@ -8,7 +8,7 @@ import io
 import numpy as np
 
 from pyro_amd.analysis import costfunction
-from pyro_amd.dynamic import cartpole, manipulator, pendulum
+from pyro_amd.dynamic import cartpole, drone, manipulator, pendulum
 from pyro_amd.planning import discretizer
 
 
@@ -49,6 +49,24 @@ def _twolink(xdims, udims, dtype, dt=0.05):
     return s, g, cf, dtype
 
 
+def _helicopter(xdims, udims, dtype):
+    """examples/demos_by_tool/dynamicprogramming/helicopter_tunnel.py:18-58 (the reference's 3-D demo: obstacle boxes in
+    isavalidstate, QuadraticCostFunctionWithDomainCheck) on a finer grid."""
+    s = drone.ConstantSpeedHelicopterTunnel()
+    s.obstacles = [[(2, 2), (4, 4)], [(8, 5), (10, 10)], [(14, 0), (16, 4)]]
+    s.mass, s.vx, s.width = 0.1, 5.0, 1.0
+    s.x_ub, s.x_lb = np.array([+60.0, 10.0, +20.0]), np.array([-60.0, 0.0, 0.0])
+    s.u_ub, s.u_lb = np.array([+20.0]), np.array([-20.0])
+    g = _quiet(discretizer.GridDynamicSystem, s, list(xdims), list(udims), 0.05)
+    cf = costfunction.QuadraticCostFunctionWithDomainCheck.from_sys(s)
+    cf.xbar = np.array([0.0, 2.0, 20.0])
+    cf.INF, cf.EPS = 100000, 0.2
+    cf.Q[0, 0], cf.Q[1, 1], cf.Q[2, 2] = 2.0, 200.0, 0.0
+    cf.R[0, 0] = 5.0
+    cf.S[0, 0], cf.S[1, 1], cf.S[2, 2] = 20.0, 50.0, 0.0
+    return s, g, cf, dtype
+
+
 CONFIGS = {
     # name: (description, builder)
     "c1": ("pendulum 101x101 x 11 actions, f64 (BASELINE configs[0])", lambda: _pendulum((101, 101), (11,), "float64")),
@@ -62,6 +80,10 @@ CONFIGS = {
     # H(q)^-1 dynamics that configs[4] names is skipped; dt = 0.01 keeps most of them in (the dense variant)
     "c5d": ("two-link 101^4 x 11x11 torques, dt = 0.01, f64 (BASELINE configs[4], dense variant of SURVEY 8d)",
             lambda: _twolink((101,) * 4, (11, 11), "float64", dt=0.01)),
+    # the explicit (non-mechanical) systems: the reference's 3-D demo on a grid 64 times the demo's 51^3
+    "h3": ("helicopter tunnel 201x201x401 x 11 actions, obstacles + domain-check cost, f32 (helicopter_tunnel.py at 64x the nodes)",
+           lambda: _helicopter((201, 201, 401), (11,), "float32")),
+    "h3s": ("helicopter tunnel 51^3 x 11 actions, f32 (the demo's own grid)", lambda: _helicopter((51, 51, 51), (11,), "float32")),
     # reduced twins for quick checks
     "c3s": ("cart-pole 41^4 x 21 actions, f32", lambda: _cartpole((41,) * 4, (21,), "float32")),
     "c5s": ("two-link 41^4 x 11x11 torques, f64", lambda: _twolink((41,) * 4, (11, 11), "float64")),

@@ -1591,6 +1591,153 @@ __global__ __launch_bounds__(256) void k_sweep3(DevP P, const REAL* __restrict__
     sweep_finish(sc);
 }
 
+// -------------------------------------------------------------------------------------------------
+// float32 production form of the explicit systems ("fast3").  What k_sweep3 spends its time on does not change from sweep
+// to sweep or does not need float64 levels:
+//   * ok(node, a) = isavalidinput and isavalidstate(x_next) -- the obstacle boxes are a loop of float64 compares per cell
+//     -- is decided ONCE at set-up by k_mask3 (the same float64 expressions) into one 64-bit mask per node (A <= 64);
+//   * the interval of x_next on a linspace axis and its fraction come from t = (x_next - lo) * (1 / step) in float64
+//     (floor, then ONE rounding of t - floor(t) to float32) instead of a level search and a float64 division: the same cell
+//     and fraction up to 1e-16 of a cell (float32 handles carry 1e-5);
+//   * axes whose x_next does not depend on the action keep their interval from the node prologue, as in k_sweep3.
+// Gathers stay in global memory: the lanes of a wave are consecutive nodes of the LAST axis and every explicit system moves
+// along it by a node-uniform amount, so each of the 2^n gathers of a wave is one coalesced row segment.
+// Measured on the helicopter tunnel 201 x 201 x 401 x 11 (float32): see DESIGN.md section 4.6.
+// -------------------------------------------------------------------------------------------------
+template <int DYN>
+__global__ __launch_bounds__(256) void k_mask3(DevP P, unsigned long long* __restrict__ okmask) {
+    using D = Dyn3<DYN>;
+    constexpr int N = D::N, M = D::M;
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
+    if (o >= owned) return;
+    int idx[N];
+    decode_node<N>(P, o, idx);
+    double x[N];
+#pragma unroll
+    for (int d = 0; d < N; ++d) x[d] = P.lev[d][idx[d]];
+    D dyn;
+    dyn.init(P, idx, x);
+    unsigned long long m = 0ull;
+    for (int a = 0; a < P.A; ++a) {
+        double u[M], fa[N], xn[N];
+#pragma unroll
+        for (int k = 0; k < M; ++k) u[k] = P.utab[a * M + k];
+        dyn.f(P, x, u, a, fa);
+#pragma unroll
+        for (int d = 0; d < N; ++d) xn[d] = fa[d] * P.dt + x[d];  // discretizer.py:363
+        const bool ok = P.aok[a] != 0 && dyn.action_ok(P, x, a) && state_valid<N>(P, xn);
+        if (ok) m |= 1ull << a;
+    }
+    okmask[o] = m;
+}
+
+template <int DYN, typename PI_T>
+__global__ __launch_bounds__(256) void k_sweep3_fast(DevP P, const float* __restrict__ Jin, float* __restrict__ Jout, PI_T* __restrict__ pi,
+                                                     float alpha, SweepCtl sc, const double* __restrict__ utab,
+                                                     const double* __restrict__ gutab, const unsigned long long* __restrict__ okmask) {
+    using D = Dyn3<DYN>;
+    constexpr int N = D::N, M = D::M;
+    if (sc.ctrl->done) return;
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
+    double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
+    if (o < owned) {
+        int idx[N];
+        decode_node<N>(P, o, idx);
+        double x[N], dx[N];
+        long long self = (long long)(idx[0] - P.store_begin) * P.strd[0];
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+            x[d] = P.lev[d][idx[d]];
+            dx[d] = x[d] - P.xbar[d];
+            if (d > 0) self += idx[d] * P.strd[d];
+        }
+        const double gx = quad_form<N>(P.Q, dx);
+        const bool on_target = P.ontarget && (l2norm<N>(dx) < P.EPS);
+        const bool node_bad = P.domain_check && !state_valid<N>(P, x);
+        const unsigned long long okm = okmask[o];
+        D dyn;
+        dyn.init(P, idx, x);
+        double xn[N], u0[M];
+        float y[N];
+        int ci[N];
+        bool inb_fix = true;
+#pragma unroll
+        for (int k = 0; k < M; ++k) u0[k] = 0.0;
+        {
+            double f0[N];
+            dyn.f(P, x, u0, 0, f0);
+#pragma unroll
+            for (int d = 0; d < N; ++d) {
+                if (!((D::UDEP >> d) & 1)) {
+                    xn[d] = f0[d] * P.dt + x[d];
+                    inb_fix = inb_fix && !(xn[d] < P.glo[d]) && !(xn[d] > P.ghi[d]);
+                    double l0, l1;
+                    ci[d] = find_interval_lv(P.lev[d], P.dim[d], P.glo[d], P.inv_step[d], xn[d], l0, l1);
+                    y[d] = (float)((xn[d] - l0) / (l1 - l0));
+                }
+            }
+        }
+        float best = 0.f;
+        int arg = 0;
+        const float INF_F = (float)P.INF;
+        for (int a = 0; a < P.A; ++a) {
+            double u[M], fa[N];
+#pragma unroll
+            for (int k = 0; k < M; ++k) u[k] = utab[a * M + k];  // (wave-uniform: scalar loads)
+            dyn.f(P, x, u, a, fa);
+            bool inb = inb_fix;
+#pragma unroll
+            for (int d = 0; d < N; ++d) {
+                if ((D::UDEP >> d) & 1) {
+                    xn[d] = fa[d] * P.dt + x[d];
+                    inb = inb && !(xn[d] < P.glo[d]) && !(xn[d] > P.ghi[d]);
+                    const double t = (xn[d] - P.glo[d]) * P.inv_step[d];
+                    double fl = floor(t);
+                    fl = fl < 0.0 ? 0.0 : (fl > (double)(P.dim[d] - 2) ? (double)(P.dim[d] - 2) : fl);
+                    ci[d] = (int)fl;
+                    y[d] = (float)(t - fl);
+                }
+            }
+            const bool ok = (okm >> a) & 1ull;
+            float Jn = 0.f;
+            if (inb) {
+                long long b = 0;
+#pragma unroll
+                for (int d = 0; d < N; ++d) {
+                    int c = ci[d];
+                    if (d == 0) {
+                        if (c < P.store_begin || c + 1 >= P.store_end) {
+                            atomicOr(&sc.ctrl->halo_err, 1);
+                            c = min(max(c, P.store_begin), P.store_end - 2);
+                        }
+                        c -= P.store_begin;
+                    }
+                    b += c * P.strd[d];
+                }
+                Jn = interp_f32<N>(Jin, P.strd, b, y);
+            }
+            const double g = on_target ? 0.0 : (node_bad ? P.INF : (gx + gutab[a]));
+            const float G = ok ? (float)(g * P.dt) : INF_F;
+            float q = fmaf(alpha, Jn, G);
+            if (P.hard_inf && !ok) q = INF_F;
+            if (a == 0 || q < best) {
+                best = q;
+                arg = a;
+            }
+        }
+        Jout[self] = best;
+        pi[o] = (PI_T)arg;
+        const double jn = (double)best, d = jn - (double)Jin[self];
+        st_j = jn;
+        st_dmax = d;
+        st_ndmin = -d;
+    }
+    block_stats(st_j, st_dmax, st_ndmin, sc.slot);
+    sweep_finish(sc);
+}
+
 // reference tables of the n = 3 systems: x_next_table, x_next_isok, action_isok, G (one thread per cell)
 template <int DYN>
 __global__ void k_build_tables3(DevP P, long long node0, long long nnodes, double* __restrict__ xnext,
@@ -2591,6 +2738,7 @@ struct pvi_problem {
     double infrac64 = -1.0;   // share of the (node, action) cells that land in the box (4-D float64 handles)
     int patch64 = -1;         // 4-D wave mapping of k_sweep64: 1 = 8 x 8 velocity patches, 0 = consecutive nodes (timed at set-up)
     size_t levr_bytes = 0;
+    const unsigned long long* okmask3 = nullptr;  // fast3: validity of every (node, action) cell of an explicit system
     const double* roll_params = nullptr;  // constants of the continuous closed form (pvi_set_rollout_params)
     SplineP SP;               // bicubic-spline interpolation mode (sweep_spline.inc)
     bool spline = false;
@@ -3737,6 +3885,26 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
     HCHK(hipStreamSynchronize(h->stream));
 #undef HCHK
     if ((rc = lean_setup(h))) return bail(rc);
+    if (d->dtype == PVI_F32 && is_dyn3(d->dynamics_id) && A <= 64 && !ovr("NO_FAST")) {
+        // fast3: the validity of every cell of an explicit system, once (sweep_lean.inc's idea applied to the obstacle tests)
+        unsigned long long* m = nullptr;
+        if ((rc = dev_alloc(h, (size_t)h->owned, &m))) return bail(rc);
+        const unsigned gm = grid_for(h->owned);
+        switch (d->dynamics_id) {
+            case PVI_DYN_HELICOPTER: hipLaunchKernelGGL((k_mask3<PVI_DYN_HELICOPTER>), gm, 256, 0, h->stream, h->P, m); break;
+            case PVI_DYN_KINCAR: hipLaunchKernelGGL((k_mask3<PVI_DYN_KINCAR>), gm, 256, 0, h->stream, h->P, m); break;
+            case PVI_DYN_QUARTERCAR: hipLaunchKernelGGL((k_mask3<PVI_DYN_QUARTERCAR>), gm, 256, 0, h->stream, h->P, m); break;
+            case PVI_DYN_HOLONOMIC: hipLaunchKernelGGL((k_mask3<PVI_DYN_HOLONOMIC>), gm, 256, 0, h->stream, h->P, m); break;
+            default: hipLaunchKernelGGL((k_mask3<PVI_DYN_LONGCAR>), gm, 256, 0, h->stream, h->P, m); break;
+        }
+        rc = [&]() -> int {
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(h->stream));
+            return PVI_OK;
+        }();
+        if (rc) return bail(rc);
+        h->okmask3 = m;
+    }
     // the float32-storage exact path (float64 dynamics: systems whose float32 displacement cancels) walks the same masks
     bool grid_is_box = true;
     for (int i = 0; i < d->n; ++i) grid_is_box = grid_is_box && d->x_lb[i] == P.glo[i] && d->x_ub[i] == P.ghi[i];
@@ -3865,6 +4033,7 @@ extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
                        : h->d.dtype == PVI_F64 ? "exact-f64"
                        : (h->lean_ok || h->lean4_ok) ? "lean"
                        : (h->fast_ok && !is_node_dyn(h->d.dynamics_id)) ? "fast"
+                       : h->okmask3 ? "fast3"
                        : (h->d.dynamics_id == PVI_DYN_TABLE ? (h->packed ? "table-packed" : "table") : "exact-f32");
     if (h->d.dtype == PVI_F64 && h->use64 && h->d.dynamics_id != PVI_DYN_TABLE) {
         snprintf(buf, (size_t)n, "path=exact-f64v2 mapping=%s off32=%d sparse=%d inbox=%.4f note=",
@@ -4206,6 +4375,23 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
 #undef S64
 #undef S64P
 #undef S64Q
+            HIPCHK(hipGetLastError());
+            return PVI_OK;
+        }
+    }
+    if constexpr (sizeof(REAL) == 4) {
+        if (h->okmask3 && !h->force_exact) {
+#define FAST3(DYN)                                                                                                  \
+    hipLaunchKernelGGL((k_sweep3_fast<DYN, PI_T>), g, 256, 0, st, h->P, Jin, Jout, pi, (float)alpha, sc, h->P.utab, h->P.gu, \
+                       h->okmask3)
+            switch (h->d.dynamics_id) {
+                case PVI_DYN_HELICOPTER: FAST3(PVI_DYN_HELICOPTER); break;
+                case PVI_DYN_KINCAR: FAST3(PVI_DYN_KINCAR); break;
+                case PVI_DYN_QUARTERCAR: FAST3(PVI_DYN_QUARTERCAR); break;
+                case PVI_DYN_HOLONOMIC: FAST3(PVI_DYN_HOLONOMIC); break;
+                default: FAST3(PVI_DYN_LONGCAR); break;
+            }
+#undef FAST3
             HIPCHK(hipGetLastError());
             return PVI_OK;
         }

@@ -1445,6 +1445,46 @@ def test_closed_loop_rollout_of_a_node_tier_system_falls_back_to_the_host_loop()
     assert np.all(np.isfinite(X)) and np.all(X[:, :, 0] > -1.8) and np.all(X[:, :, 0] < 0.3)
 
 
+def test_fast3_explicit_systems_float32_matches_the_plain_kernel(variants):
+    """the float32 production form of the explicit systems (validity of every cell decided once at set-up:
+    the obstacle tests leave the sweep; intervals from (x - lo) / step in float64 instead of a level search + division)
+    against the operation-for-operation kernel k_sweep3 on the same handle type: the helicopter tunnel with its obstacles
+    and domain-check cost (the reference's 3-D demo), the car park and the point robot; and pvi_self_check on it."""
+    from pyro_amd import configs
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import vehicle_steering
+    from pyro_amd.planning import discretizer, dynamicprogramming
+    cases = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        c = configs.build("h3s")
+        cases.append((c["grid_sys"], c["cf"]))
+        s = vehicle_steering.KinematicCarModelwithObstacles()
+        cases.append((discretizer.GridDynamicSystem(s, [31, 31, 21], [3, 5], 0.1), costfunction.QuadraticCostFunctionWithDomainCheck.from_sys(s)))
+        s = vehicle_steering.HolonomicMobileRobotwithObstacles()
+        cases.append((discretizer.GridDynamicSystem(s, [41, 41], [5, 5]), costfunction.QuadraticCostFunction.from_sys(s)))
+    for gs, cf in cases:
+        outs = {}
+        for tag, env in (("fast3", {}), ("plain", {"PVI_NO_FAST": "1"})):
+            variants.delenv("PVI_NO_FAST")
+            for k, v in env.items():
+                variants.setenv(k, v)
+            with contextlib.redirect_stdout(io.StringIO()):
+                dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(gs, cf, dtype="float32")
+                dp.save_time_history = False
+                dp.compute_steps(12)
+            desc = dp._p.describe()
+            assert desc.startswith("path=fast3" if tag == "fast3" else "path=exact-f32"), desc
+            outs[tag] = (dp.J.copy(), dp.pi.copy(), dp._p.get_J(prev=True))
+            if tag == "fast3":
+                d, n = dp._p.self_check(1.0)
+                assert d <= 2e-6, (gs.sys.name, d, n)
+            dp._p.close()
+        variants.delenv("PVI_NO_FAST")
+        scale = np.abs(outs["plain"][0]).max()
+        assert np.abs(outs["fast3"][0] - outs["plain"][0]).max() <= 2e-6 * scale, gs.sys.name
+        assert (outs["fast3"][1] != outs["plain"][1]).mean() < 2e-3, gs.sys.name        # ties / last-bit argmin flips only
+
+
 def _host_closed_loop(dp, X0, tf, n):
     """The reference's own closed loop: u = ctl.c(x, t), x <- x + f(x, u, t) dt (controller.py:328-355, simulation.py:298-324)."""
     ctl = dp.get_lookup_table_controller()

@@ -4,7 +4,7 @@
 # `bench.py --workload <w> --no-cpu`; plus kernel-trace stats of the default `python bench.py`.
 cd /root/repo
 export PVI_ROUND=r03
-WL=${WL:-"c3 c4 c2 c2p c5 c5d c1"}
+WL=${WL:-"c3 c4 c2 c2p c5 c5d c1 h3"}
 for w in $WL; do
   bash tools/tools_counters.sh $w > gpurun_out/r03_counters_$w.log 2>&1
   S=""; ([ $w = c3 ] || [ $w = c4 ] || [ $w = c5 ] || [ $w = c5d ]) && S="--steps 10 --warmup 2"
