@@ -303,8 +303,8 @@ class Problem:
         return int(row0), int(nrows)
 
     def describe(self):
-        buf = C.create_string_buffer(512)
-        check(lib().pvi_describe(self._h, buf, 512))
+        buf = C.create_string_buffer(2048)
+        check(lib().pvi_describe(self._h, buf, 1024))
         return buf.value.decode()
 
     def terminal_cost(self):
@@ -551,7 +551,7 @@ class ShardedProblem:
         return out
 
     def describe(self):
-        buf = C.create_string_buffer(1024)
+        buf = C.create_string_buffer(2048)
         check(lib().pvi_shard_describe(self._h, buf, 1024))
         return buf.value.decode()
 

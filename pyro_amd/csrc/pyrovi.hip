@@ -2716,7 +2716,7 @@ struct pvi_problem {
     int lean4_stage = 4;          // actions whose gathers are in flight together (2: fewer registers, more waves)
     int lean4_ptab_inv = 0;       // bit 0 / 1: the (position node, action) table does not depend on axis 0 / 1
     long long lean4_ptab_groups = 0;
-    char lean4_cands[256] = "";  // the timed tile shapes of set-up: rows x columns : ms
+    char lean4_cands[960] = "";  // the timed tile shapes of set-up: rows x columns : ms
     unsigned lean4_grid = 0;
     size_t lean4_lds = 0;
     LeanP LP;                 // f32 lean path (sweep_lean.inc)
@@ -2952,37 +2952,37 @@ static void lean4_row_pieces(const std::vector<int2>& pt0, int i0, int V0, int c
         a = j;
     }
 }
-// ... for every owned row: [rows][nty] with nty the largest count (shorter lists are padded with empty pieces)
-static void lean4_all_pieces(const std::vector<int2>& pt0, int rows, int row_begin, int V0, int cap, std::vector<int2>& out, int* nty,
-                             int* tv0) {
-    std::vector<std::vector<int2>> per((size_t)rows);
-    *nty = 1;
-    *tv0 = 1;
-    for (int r = 0; r < rows; ++r) {
-        lean4_row_pieces(pt0, row_begin + r, V0, cap, per[(size_t)r]);
-        *nty = std::max(*nty, (int)per[(size_t)r].size());
-        for (auto& pc : per[(size_t)r]) *tv0 = std::max(*tv0, pc.y);
+// Tiles of the velocity plane for ONE row i0: every row piece is split into near-equal column chunks as wide as the
+// workgroup allows (rows x columns <= threads), so that short pieces get wide tiles and every workgroup is about full
+// (with one column split for all pieces 20 % of the lanes were idle on C3).  `wmax` bounds the width: the window of a wide tile
+// of a far-reaching system (C4: 32 pairs of reach along axis 3) may cost a workgroup of occupancy.
+static void lean4_row_tiles(const std::vector<int2>& pt0, int i0, int V0, int V1, int cap, int threads, int wmax, std::vector<int4>& out) {
+    std::vector<int2> pieces;
+    lean4_row_pieces(pt0, i0, V0, cap, pieces);
+    out.clear();
+    for (const int2& pc : pieces) {
+        const int w = std::max(1, std::min(std::min(V1, wmax), threads / pc.y));
+        const int n = (V1 + w - 1) / w;
+        for (int k = 0; k < n; ++k) {
+            const int c0 = (int)((long long)V1 * k / n), c1 = (int)((long long)V1 * (k + 1) / n);
+            out.push_back(make_int4(pc.x, pc.y, c0, c1 - c0));
+        }
     }
-    out.assign((size_t)rows * *nty, make_int2(0, 0));
-    for (int r = 0; r < rows; ++r)
-        for (size_t k = 0; k < per[(size_t)r].size(); ++k) out[(size_t)r * *nty + k] = per[(size_t)r][k];
 }
 
 // Launch order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with a private 4 MiB L2.
-// XCD x sweeps ITS chunk of axis 1 for every owned row of axis 0 in turn (bands of row pieces outermost, so that the
-// planes of three consecutive axis-0 rows over the chunk fit its L2): the axis-0 planes a tile gathers from were
+// XCD x sweeps ITS chunk of axis 1 for every owned row of axis 0 in turn (bands of the row's tile list outermost, so that
+// the planes of three consecutive axis-0 rows over the chunk fit its L2): the axis-0 planes a tile gathers from were
 // fetched for the previous row a moment ago.  Lists are interleaved into physical order and padded to equal length.
-static void lean4_schedule(int R, int N1, int nty, int ntx, int nbands, std::vector<unsigned>& out) {
+static void lean4_schedule(int R, int N1, int ntr, int nbands, std::vector<unsigned>& out) {
     std::vector<std::vector<unsigned>> lists(8);
     for (int x = 0; x < 8; ++x) {
         const int c0 = (int)((long long)N1 * x / 8), c1 = (int)((long long)N1 * (x + 1) / 8);
         for (int b = 0; b < nbands; ++b) {
-            const int ty0 = (int)((long long)nty * b / nbands), ty1 = (int)((long long)nty * (b + 1) / nbands);
+            const int k0 = (int)((long long)ntr * b / nbands), k1 = (int)((long long)ntr * (b + 1) / nbands);
             for (int r = 0; r < R; ++r)
                 for (int i1 = c0; i1 < c1; ++i1)
-                    for (int ty = ty0; ty < ty1; ++ty)
-                        for (int tx = 0; tx < ntx; ++tx)
-                            lists[x].push_back((unsigned)(((long long)(r * N1 + i1) * nty + ty) * ntx + tx));
+                    for (int k = k0; k < k1; ++k) lists[x].push_back((unsigned)((long long)(r * N1 + i1) * ntr + k));
         }
     }
     size_t mx = 0;
@@ -2993,79 +2993,89 @@ static void lean4_schedule(int R, int N1, int nty, int ntx, int nbands, std::vec
 }
 
 struct Lean4Cand {
-    int cap, w;  // rows cap, tile width
+    int cap, w, wmax;  // rows cap, workgroup threads, widest tile
 };
 
-// one candidate tiling: row pieces, window boxes, row pitch, schedule.  rc 0 = usable, 1 = does not fit, < 0 error
-static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int w, size_t lds_budget) {
+// one candidate tiling: tile lists, window boxes, row pitch, schedule.  rc 0 = usable, 1 = does not fit, < 0 error
+static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int threads, int wmax, size_t lds_budget, int* narrower = nullptr) {
     const DevP& P = h->P;
     Lean4P& L = h->L4;
     const int rows = P.row_end - P.row_begin;
-    std::vector<int2> pieces;
-    int tv0 = 1, nty = 1;
-    lean4_all_pieces(pt0, rows, P.row_begin, P.dim[2], cap, pieces, &nty, &tv0);
+    if (threads > 512 || threads < 64 || (threads & 63)) return 1;
+    std::vector<std::vector<int4>> per((size_t)rows);
+    int ntr = 1, tv0 = 1, tv1 = 1;
+    for (int r = 0; r < rows; ++r) {
+        lean4_row_tiles(pt0, P.row_begin + r, P.dim[2], P.dim[3], cap, threads, wmax, per[(size_t)r]);
+        ntr = std::max(ntr, (int)per[(size_t)r].size());
+        for (auto& t : per[(size_t)r]) {
+            tv0 = std::max(tv0, t.y);
+            tv1 = std::max(tv1, t.w);
+        }
+    }
+    std::vector<int4> tlist((size_t)rows * ntr, make_int4(0, 0, 0, 0));
+    for (int r = 0; r < rows; ++r)
+        for (size_t k = 0; k < per[(size_t)r].size(); ++k) tlist[(size_t)r * ntr + k] = per[(size_t)r][k];
     L.V0 = P.dim[2];
     L.V1 = P.dim[3];
-    L.ntx = (L.V1 + w - 1) / w;
-    L.TV1 = (L.V1 + L.ntx - 1) / L.ntx;
     L.TV0 = tv0;
-    L.nty = nty;
-    const int threads = ((L.TV0 * L.TV1 + 63) / 64) * 64;
-    if (threads > 512) return 1;
-    L.tv1_magic = ((1 << 20) + L.TV1 - 1) / L.TV1;
+    L.TV1 = tv1;
+    L.ntr = ntr;
     L.posdim1 = P.dim[1];
     L.pd_magic = magic32((unsigned)L.posdim1);
-    L.ntx_magic = magic32((unsigned)L.ntx);
-    L.ntxy_magic = magic32((unsigned)(L.ntx * L.nty));
+    L.ntr_magic = magic32((unsigned)ntr);
     L.vplane = (long long)L.V0 * L.V1;
     L.owned = h->owned;
-    const long long npos = (long long)rows * P.dim[1], ntiles = npos * L.nty * L.ntx;
+    const long long npos = (long long)rows * P.dim[1], ntiles = npos * ntr;
     if (ntiles >= 0x7fffffffLL / 8) return 1;
     int rc;
-    if (L.rowseg) dev_release(h, (void*)L.rowseg);
+    if (L.tlist) dev_release(h, (void*)L.tlist);
     if (L.win) dev_release(h, L.win);
     if (L.sched) dev_release(h, (void*)L.sched);
-    L.rowseg = nullptr;
+    L.tlist = nullptr;
     L.win = nullptr;
     L.sched = nullptr;
-    int2* d_seg = nullptr;
-    if ((rc = dev_alloc(h, pieces.size(), &d_seg))) return rc;
-    HIPCHK(hipMemcpyAsync(d_seg, pieces.data(), pieces.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
-    L.rowseg = d_seg;
+    int4* d_tl = nullptr;
+    if ((rc = dev_alloc(h, tlist.size(), &d_tl))) return rc;
+    HIPCHK(hipMemcpyAsync(d_tl, tlist.data(), tlist.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+    L.tlist = d_tl;
     if ((rc = dev_alloc(h, (size_t)ntiles * 8, &L.win))) return rc;
     HIPCHK(hipMemsetAsync(L.summary, 0, 6 * sizeof(int), h->stream));
     hipLaunchKernelGGL(k_lean4_tiles, dim3((unsigned)ntiles), dim3(threads), 0, h->stream, P, L, ntiles);
     HIPCHK(hipGetLastError());
     int summary[8];
     HIPCHK(hipMemcpyAsync(summary, L.summary, sizeof(summary), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));  // (also: `pieces` has been copied)
-    // Row pitch in slots: the fill writes whole groups of four columns, and the pitch is congruent to the tile width modulo
-    // 32 -- a wave covers consecutive tile nodes t = row * TV1 + column, its lanes read slot row * RS + column + shift, and
-    // ds_read_b64 has 32 slot-wide bank groups: with RS = TV1 (mod 32) the slots of the lanes that wrapped to the next tile
-    // row continue the residues of the row above instead of repeating them (measured with pitch 64 on 51-wide tiles:
-    // 3.7 LDS cycles per read instead of 2).
-    int rs = std::max(4, (summary[1] + 3) & ~3);
-    const int rsk = 0;
-    if (!ovr("NO_RS64")) rs += (((L.TV1 - rs) % 32) + 32) % 32;
+    HIPCHK(hipStreamSynchronize(h->stream));  // (also: `tlist` has been copied)
+    // Row pitch in slots: the fill writes whole groups of four columns.  (Tiles differ in width, so no pitch is congruent to
+    // all of them; tools/ldsgather.hip: a row wrap or a displacement step inside a wave costs a ds_read_b64 4.3 -> 5.0 clk at
+    // worst, whatever the pitch -- the 4.4 clk of the conflict-free read is what counts.)
+    const int rs = std::max(4, (summary[1] + 3) & ~3);
     const size_t lds = (size_t)std::max(summary[0], 1) * (size_t)rs * 8 + 256;
+    if (narrower) {  // the widest tile whose window lets as many workgroups onto a CU as the register budget does (24 waves)
+        *narrower = 0;
+        const size_t room = (size_t)160 * 1024 / (size_t)std::max(1, 1536 / threads) - 1536;
+        if (lds > room && summary[0] > 0) {
+            const int rs_fit = (int)((room - 256) / 8 / (size_t)summary[0]) & ~3, w_fit = tv1 - (rs - rs_fit);
+            if (w_fit >= 12 && w_fit < tv1) *narrower = w_fit;
+        }
+    }
     if (lds > lds_budget) {
-        snprintf(h->lean_why, sizeof(h->lean_why), "tile %dx%d needs %zu LDS bytes (%d window rows x %d pairs; budget %zu)", L.TV0, L.TV1,
-                 lds, summary[0], rs, lds_budget);
+        snprintf(h->lean_why, sizeof(h->lean_why), "tiles of %d threads, <= %d rows need %zu LDS bytes (%d window rows x %d pairs; budget %zu)",
+                 threads, cap, lds, summary[0], rs, lds_budget);
         return 1;
     }
     L.RS = rs;
-    h->lean4_rsk = rsk;
+    h->lean4_rsk = 0;
     h->lean4_lds = lds;
     h->lean4_block = threads;
     hipLaunchKernelGGL(k_lean4_off, grid_for(h->lean4_ptab_groups * 4), 256, 0, h->stream, L, h->lean4_ptab_groups);
-    // bands of row pieces: three axis-0 rows x (chunk of axis 1 + position reach) x band rows x V1 floats within ~1.5 MB of L2
+    // bands of the tile list: three axis-0 rows x (chunk of axis 1 + position reach) x band rows x V1 floats within ~1.5 MB of L2
     const int n1c = (P.dim[1] + 7) / 8 + 3;
     const double per_row = 3.0 * n1c * (double)L.V1 * 4.0;
     const int band_rows = std::max(L.TV0, (int)(1.5e6 / per_row) - (summary[0] ? 12 : 0));
-    const int nbands = std::max(1, std::min(L.nty, (L.V0 + band_rows - 1) / band_rows));
+    const int nbands = std::max(1, std::min(ntr, (L.V0 + band_rows - 1) / band_rows));
     h->lean4_bands = nbands;
     std::vector<unsigned> sched;
-    lean4_schedule(rows, P.dim[1], L.nty, L.ntx, ovr_is("NO_XCD", 1) ? 1 : nbands, sched);
+    lean4_schedule(rows, P.dim[1], ntr, ovr_is("NO_XCD", 1) ? 1 : nbands, sched);
     if (ovr_is("NO_XCD", 1)) {  // plain order (experiments, tests): tile ids ascending
         sched.resize((size_t)ntiles);
         for (long long t = 0; t < ntiles; ++t) sched[(size_t)t] = (unsigned)t;
@@ -3187,7 +3197,7 @@ static int lean4_setup(pvi_problem* h) {
         dev_release(h, L.flag); dev_release(h, pt0); dev_release(h, pt1); dev_release(h, L.summary); dev_release(h, L.ptab);
         dev_release(h, tsp_node); dev_release(h, gx_node);
         if (L.tsp && L.tsp != tsp_node) dev_release(h, (void*)L.tsp);
-        if (L.rowseg) dev_release(h, (void*)L.rowseg);
+        if (L.tlist) dev_release(h, (void*)L.tlist);
         if (L.win) dev_release(h, L.win);
         if (L.sched) dev_release(h, (void*)L.sched);
         for (int d = 0; d < 4; ++d) dev_release(h, (void*)L.gt[d]);
@@ -3235,38 +3245,34 @@ static int lean4_setup(pvi_problem* h) {
     const size_t budget = ovr("LDS_KB") ? (size_t)atoi(ovr("LDS_KB")) * 1024 : (size_t)80 * 1024;  // two workgroups per CU
     std::vector<Lean4Cand> cands;
     const int V1 = P.dim[3];
-    if (ovr("TV0") && ovr("TV1")) {
-        cands.push_back({atoi(ovr("TV0")), atoi(ovr("TV1"))});
+    if (ovr("TV0") && ovr("TV1")) {  // rows cap, and the tile width the workgroup is sized for (cap x width threads)
+        cands.push_back({atoi(ovr("TV0")), std::min(512, ((atoi(ovr("TV0")) * atoi(ovr("TV1")) + 63) / 64) * 64), atoi(ovr("TV1"))});
     } else {
-        // Tile shapes worth timing: for every column split V1 / k, the row caps whose pieces (the step-aligned segments of
-        // axis 2 cut into near-equal parts) fill the workgroup's lanes best -- share of live lanes = nodes of a velocity
-        // plane / (tiles x threads rounded up to whole waves).  The three best caps per width are timed.
-        std::vector<int2> pieces;
+        // Tilings worth timing: workgroups of 3 .. 8 waves, and for each the row caps whose tiles (step-aligned row pieces,
+        // each split into columns as wide as the workgroup allows) keep the largest share of the lanes busy = nodes of a
+        // velocity plane / (tiles x threads), judged on a middle row.  The best caps per workgroup size are timed.
+        std::vector<int4> tl;
         for (int min_threads : {192, 64}) {  // (small grids: whatever fills a wave)
-            for (int k = 1; k <= 8; ++k) {
-                const int w = (V1 + k - 1) / k;
-                if (w > 128) continue;
-                if (w < 16 && k > 1) break;
+            for (int threads : {512, 384, 320, 256, 192, 128, 64}) {
+                if (threads < min_threads || (min_threads == 64 && threads >= 192)) continue;
                 struct Eff {
                     double e;
                     int cap;
                 };
                 std::vector<Eff> effs;
-                int last_tv0 = -1;
-                for (int cap = std::max(1, 512 / w); cap >= 2; --cap) {
-                    lean4_row_pieces(hpt0, P.row_begin + rows / 2, P.dim[2], cap, pieces);  // (a middle row stands for all)
-                    int tv0 = 1;
-                    for (auto& pc : pieces) tv0 = std::max(tv0, pc.y);
-                    if (tv0 == last_tv0) continue;  // the same pieces as the previous cap
-                    last_tv0 = tv0;
-                    const int threads = ((tv0 * w + 63) / 64) * 64;
-                    if (threads > 512 || threads < min_threads) continue;
-                    const double e = (double)P.dim[2] * V1 / ((double)pieces.size() * k * threads);
-                    effs.push_back({e, cap});
+                size_t last_n = 0;
+                for (int cap = std::min(P.dim[2], threads / 8); cap >= 2; --cap) {
+                    lean4_row_tiles(hpt0, P.row_begin + rows / 2, P.dim[2], V1, cap, threads, V1, tl);
+                    if (tl.size() == last_n) continue;  // (most caps give the same pieces as their neighbour)
+                    last_n = tl.size();
+                    int wmin = V1;
+                    for (auto& t : tl) wmin = std::min(wmin, t.w);
+                    if (wmin < std::min(V1, 12)) continue;  // very narrow tiles: the window is all halo
+                    effs.push_back({(double)P.dim[2] * V1 / ((double)tl.size() * threads), cap});
                 }
                 std::sort(effs.begin(), effs.end(), [](const Eff& a, const Eff& b) { return a.e > b.e; });
-                for (size_t i = 0; i < effs.size() && i < 4 && cands.size() < 24; ++i)
-                    if (effs[i].e >= 0.75 * effs[0].e) cands.push_back({effs[i].cap, w});
+                for (size_t i = 0; i < effs.size() && i < 6 && cands.size() < 36; ++i)
+                    if (effs[i].e >= 0.8 * effs[0].e) cands.push_back({effs[i].cap, threads, V1});
             }
             if (!cands.empty()) break;
         }
@@ -3275,7 +3281,8 @@ static int lean4_setup(pvi_problem* h) {
     float best_ms = 1e30f;
     int best = -1;
     for (size_t ci = 0; ci < cands.size(); ++ci) {
-        rc = lean4_try(h, hpt0, cands[ci].cap, cands[ci].w, budget);
+        int narrower = 0;
+        rc = lean4_try(h, hpt0, cands[ci].cap, cands[ci].w, cands[ci].wmax, budget, &narrower);
         if (rc < 0) return rc;
         if (rc) continue;
         if (!tune) {
@@ -3302,8 +3309,13 @@ static int lean4_setup(pvi_problem* h) {
         HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
         {
             const size_t at = strlen(h->lean4_cands);
-            snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, "%s%dx%d:%.2f", at ? "," : "", L.TV0, L.TV1, ms / 2.f);
+            if (cands[ci].wmax < V1)
+                snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, ",%d/%d/%d:%.2f", cands[ci].cap, cands[ci].w, cands[ci].wmax, ms / 2.f);
+            else
+                snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, "%s%d/%d:%.2f", at ? "," : "", cands[ci].cap, cands[ci].w, ms / 2.f);
         }
+        // (a narrower twin of a shape that is in the running: one more workgroup per CU may pay for the extra window halo)
+        if (narrower && cands[ci].wmax == V1 && ms < 1.1f * best_ms && cands.size() < 48) cands.push_back({cands[ci].cap, cands[ci].w, narrower});
         if (ms < 0.98f * best_ms) {  // a later candidate must win by 2 %: within the timing noise the choice stays put, so the
             best_ms = ms;            // shape (and with it the committed counter passes) is the same from run to run
             best = (int)ci;
@@ -3311,7 +3323,7 @@ static int lean4_setup(pvi_problem* h) {
     }
     if (best < 0) return give_up(h->lean_why[0] ? h->lean_why : "no tile shape fits the LDS budget");
     if (tune) {
-        if ((rc = lean4_try(h, hpt0, cands[(size_t)best].cap, cands[(size_t)best].w, budget))) return rc < 0 ? rc : give_up("tile shape lost");
+        if ((rc = lean4_try(h, hpt0, cands[(size_t)best].cap, cands[(size_t)best].w, cands[(size_t)best].wmax, budget))) return rc < 0 ? rc : give_up("tile shape lost");
         // the timed sweeps wrote into the second J buffer, pi and the control block
         HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream));
         HIPCHK(hipMemsetAsync(h->pi, 0, (size_t)h->owned * h->pi_size, h->stream));
@@ -4045,9 +4057,9 @@ extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
         // win=1: position-paired window + ds_read_b64 (sweep_lean4.inc); tables: bit d set = the displacement table does
         // not span axis d; rowpieces / bands: the step-aligned row pieces of axis 2 and their grouping in the launch order
         snprintf(buf, (size_t)n, "path=lean tile=%dx%d grid=%ux1x1 block=%d pw1=%d lds_bytes=%zu lsplit=0 tb_tile=1 dma16=0 npt=1 "
-                 "reach=0 opmag=0 sparse=0 win=1 tables=%d ptab=%d gx=%s stage=%d rowpieces=%d bands=%d cands=%s note=%s", h->L4.TV0, h->L4.TV1,
+                 "reach=0 opmag=0 sparse=0 win=1 tables=%d ptab=%d gx=%s stage=%d tiles_per_plane=%d bands=%d cands=%s note=%s", h->L4.TV0, h->L4.TV1,
                  h->lean4_grid, h->lean4_block, h->L4.RS, h->lean4_lds, h->lean4_tables, h->lean4_ptab_inv, h->L4.gx ? "node" : "axes", h->lean4_stage,
-                 h->L4.nty, h->lean4_bands, h->lean4_cands[0] ? h->lean4_cands : "-", h->lean_why);
+                 h->L4.ntr, h->lean4_bands, h->lean4_cands[0] ? h->lean4_cands : "-", h->lean_why);
         return PVI_OK;
     }
     snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d npt=%d reach=%d opmag=%d sparse=%d win=0 tables=0 note=%s",

@@ -21,7 +21,7 @@ def test_cpu_baseline_whole_sweeps_and_slice_modes():
     from pyro_amd import configs
     with contextlib.redirect_stdout(io.StringIO()):
         cfg = configs.build("pendulum:61,61:5:float32")
-    rec, J, n, rows = bench.cpu_baseline(cfg, budget_s=3.0)
+    rec, J, n, rows, _twin = bench.cpu_baseline(cfg, budget_s=3.0)
     assert rec["kind"] == "port" and rec["unit"] == "cells/s" and rec["value"] > 0 and rec["per_core_value"] > 0
     assert 1 <= rec["cores"] <= (os.cpu_count() or 1) and rows is None and n >= 1
     assert "whole sweeps" in rec["sample"] and 0 < rec["efficiency"] < 4
@@ -33,7 +33,7 @@ def test_cpu_baseline_whole_sweeps_and_slice_modes():
     # a budget too small for whole sweeps falls back to a slice of one sweep from J0
     with contextlib.redirect_stdout(io.StringIO()):
         cfg = configs.build("cartpole:21,21,21,21:7:float32")
-    rec, Js, n, rows = bench.cpu_baseline(cfg, budget_s=0.05)
+    rec, Js, n, rows, _twin = bench.cpu_baseline(cfg, budget_s=0.05)
     assert n == 1 and rows is not None and "nodes [" in rec["sample"]
     p = bench.oracle_problem(cfg)
     Jr, _ = O.sweep(p, O.terminal_cost(p), ids=np.arange(rows[0], rows[1]))

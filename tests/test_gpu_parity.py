@@ -732,7 +732,7 @@ def test_full_size_sampled_against_c_oracle(name):
         # the round-3 kernel: position-paired window, the cart-pole's displacement table spans (theta, dtheta) only
         # (axes 0 and 2 dropped: bits 0 and 2), g_x from per-axis terms, step-aligned row pieces, banded XCD schedule
         assert fields["win"] == "1" and fields["tables"] == "5" and fields["gx"] == "axes", desc
-        assert tv0 * tv1 <= 512 and tv0 * tv1 >= 128 and int(fields["lds_bytes"]) <= 80 * 1024, desc
+        assert 128 <= int(fields["block"]) <= 512 and tv0 >= 2 and tv1 >= 12 and int(fields["lds_bytes"]) <= 80 * 1024, desc
         assert int(fields["grid"].split("x")[0]) >= p.dims[0] * p.dims[1] * 6, desc        # tiles
     c = CO.CProblem(p)
     f32 = cfg["dtype"] == "float32"
