@@ -43,7 +43,7 @@ for case in range(n_cases):
             dp.alpha = alpha
             dp.compute_steps(nsw)
             d_ = dp._p.describe().split()
-            res[dtype] = (dp.J.copy(), dp.pi.copy(), d_[0] + " " + " ".join(w for w in d_ if w.startswith(("reach", "opmag"))))
+            res[dtype] = (dp.J.copy(), dp.pi.copy(), " ".join(w for w in d_ if w.startswith(("path", "tile=", "block", "tiles_per", "win="))))
             dp._p.close()
     J64, J32 = res["float64"][0], res["float32"][0]
     err = np.abs(J32 - J64).max() / max(np.abs(J64).max(), 1e-300)
@@ -53,14 +53,12 @@ for case in range(n_cases):
     print("%3d %-14s dims %-18s A %-8s dt %.2f a %.2f sw %2d  %s  err %.2e %s" %
           (case, kind, dims, udims, dt, alpha, nsw, res["float32"][2] + " " + [w for w in dp._p.describe().split() if w.startswith(("reach", "opmag"))][0] if False else res["float32"][2], err, "FAIL" if bad else ""), flush=True)
     if bad:                                         # where, and what does the f64-dynamics / f32-storage kernel say?
-        import os
-        os.environ["PVI_NO_FAST"] = "1"
-        with contextlib.redirect_stdout(io.StringIO()):
+        from pyro_amd import _native
+        with _native.overrides(NO_FAST=1), contextlib.redirect_stdout(io.StringIO()):
             dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(grid, cf, dtype="float32")
             dp.save_time_history = False
             dp.alpha = alpha
             dp.compute_steps(nsw)
-        del os.environ["PVI_NO_FAST"]
         Jx = dp.J.copy()
         dp._p.close()
         top = np.argsort(-np.abs(J32 - J64))[:4]
