@@ -139,22 +139,22 @@ def cpu_baseline(cfg, budget_s=20.0, J_start=None, depth=0):
 
 
 N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9          # 256 CUs x 4 SIMDs, 2.4 GHz
-VALU_CLK, LDS_CLK = 2.33, 15.0             # cheapest issue cost per wave64 instruction, measured by tools/valubench.hip
+VALU_CLK = 2.0                             # architectural floor per wave64 vector instruction (157.3 TF f32 = 32 FMA lanes/clk/SIMD)
 
 
 def issue_roofline(ctr, kern_ms, cells):
-    """What actually bounds the fused sweeps: SIMD instruction issue.  On gfx950 the vector-ALU, LDS and scalar streams
-    of a SIMD add up instead of overlapping (tools/valubench.hip: 64 v_fma + 8 ds_read2_b32 take 153 + 120 clk,
-    not max); cheapest costs per wave64 instruction: VALU 2.33 clk (v_fma; v_cmp / v_cndmask / v_cvt 4, v_pk 4.5),
-    ds_read2_b32 15 clk.  `frac` = instruction counts (rocprofv3 PMC, profiles/counters.json) priced at those
-    cheapest costs / SIMD cycles the kernel was resident: the share of the kernel time that is issue at the
-    hardware's best rate; the rest is dearer instruction kinds, scalar work and exposed latency.  This is the
-    builder's additive model, not a vendor roofline; the instruction counts are the committed PMC passes named in
-    `counters_source`, the kernel time is measured in this run."""
+    """What actually bounds the fused sweeps: SIMD instruction issue.  A SIMD issues one vector instruction of a wave64 in
+    2 clk at best (32 lanes per clock: the 157.3 TF f32 vector peak); tools/valubench.hip measures 2.3 clk for v_fma_f32,
+    ~4 for v_cmp / v_cndmask / v_cvt and float64, 4.5 for v_pk_fma_f32.  `frac` = vector instructions of one launch
+    (rocprofv3 PMC, profiles/counters.json) priced at that 2 clk floor / SIMD cycles the kernel was resident: the share of
+    the kernel that is vector issue at the hardware's best rate (always < 1); the rest is dearer instruction kinds, LDS and
+    scalar instructions taking issue slots (tools/valubench.hip: the streams of a SIMD add up rather than overlap) and
+    exposed latency.  The LDS side is its own object (`roofline_lds`: array-busy share from SQ_LDS_IDX_ACTIVE).  The
+    instruction counts are the committed PMC passes named in `counters_source`, the kernel time is measured in this run."""
     simd_clk = kern_ms * 1e-3 * CLOCK_HZ
-    acc = (ctr["valu_insts_per_launch"] * VALU_CLK + ctr.get("lds_insts_per_launch", 0.0) * LDS_CLK) / N_SIMD
+    acc = ctr["valu_insts_per_launch"] * VALU_CLK / N_SIMD
     return {"bound": "simd-issue", "achieved": acc, "peak": simd_clk, "unit": "clk per SIMD", "frac": acc / simd_clk,
-            "model": "VALU %.2f clk + LDS %.0f clk per wave64 instruction, additive" % (VALU_CLK, LDS_CLK),
+            "model": "vector instructions x %.0f clk per wave64 instruction (the f32 vector peak); LDS: see roofline_lds" % VALU_CLK,
             "valu_insts_per_cell": ctr["valu_insts_per_launch"] * 64.0 / cells,
             "lds_insts_per_cell": ctr.get("lds_insts_per_launch", 0.0) * 64.0 / cells,
             "salu_insts_per_cell": ctr.get("salu_insts_per_launch", 0.0) * 64.0 / cells,
@@ -163,18 +163,20 @@ def issue_roofline(ctr, kern_ms, cells):
             "counters_source": ctr.get("source")}
 
 
-def lds_roofline(ctr, kern_ms, cells, n, w, lean):
+def lds_roofline(ctr, kern_ms, cells, n, w, lean, pairs=False):
     """The second on-chip ceiling of the float32 sweeps: LDS bandwidth.  Every cell gathers 2^n values of w bytes from the
-    LDS window (N*A*2^n*w bytes per sweep, C3 140 GB -- not HBM traffic); the narrow-read class they use
-    (ds_read2_b32, ds_read_b32) moves 128 B per clock per CU (MI355X_MICROARCH.md, LDS), 256 CUs at 2.4 GHz = 78.6 TB/s.
+    LDS window (N*A*2^n*w bytes per sweep, C3 140 GB -- not HBM traffic).  Peak by read class
+    (MI355X_MICROARCH.md, LDS): ds_read_b32 / ds_read2_b32 (the 2-D kernel) move 128 B per clock per CU = 78.6 TB/s over
+    256 CUs at 2.4 GHz; ds_read_b64 (the 4-D kernel's position pairs, `pairs`) 256 B per clock = 157 TB/s.
     `lds_busy_frac` = LDS-array cycles per CU (SQ_LDS_IDX_ACTIVE, committed PMC pass) / kernel cycles measured in this run;
     `bank_conflict_share` of those cycles are conflict cycles."""
     if not lean or not ctr.get("lds_idx_active_cycles"):
         return None
     alg = cells * (1 << n) * w
-    peak = 256 * 128 * CLOCK_HZ / 1e12
+    peak = 256 * (256 if pairs else 128) * CLOCK_HZ / 1e12
     ach = alg / (kern_ms * 1e-3) / 1e12
     return {"bound": "lds", "achieved": ach, "peak": peak, "unit": "TB/s", "frac": ach / peak,
+            "read_class": "ds_read_b64" if pairs else "ds_read_b32 / ds_read2_b32",
             "algorithmic_bytes_per_launch": alg,
             "lds_busy_frac": ctr["lds_idx_active_cycles"] / 256.0 / (kern_ms * 1e-3 * CLOCK_HZ),
             "bank_conflict_share": ctr["lds_bank_conflict_cycles"] / ctr["lds_idx_active_cycles"],
@@ -279,7 +281,8 @@ def measure(name, steps, warmup, keep_handle=False):
         "cells_evaluated_per_sec": N * A * walked * timed / elapsed,
         "counters_error": ctr_err,
         "roofline_issue": None if not ctr.get("valu_insts_per_launch") else issue_roofline(ctr, kern_ms, N * A),
-        "roofline_lds": lds_roofline(ctr, kern_ms, N * A, g.sys.n, w, w == 4 and "k_sweep_lean" in str(ctr.get("kernel", ""))),
+        "roofline_lds": lds_roofline(ctr, kern_ms, N * A, g.sys.n, w, w == 4 and "k_sweep_lean" in str(ctr.get("kernel", "")),
+                                     pairs=tok.get("win") == "1"),
         "flops_frac_vector_peak": {"dtype": dt_name, "peak_tflops": VALU_PEAK_TFLOPS[dt_name],
                                    "algorithmic_flops_per_cell": flops_cell, "cells": "evaluated cells only",
                                    "frac": cells_per_s_kernel * flops_cell / (VALU_PEAK_TFLOPS[dt_name] * 1e12)},

@@ -2665,7 +2665,6 @@ static const char* const OVERRIDE_KEYS[] = {
     "NO_PACK",     // table tier: sweep the raw tables instead of the packed records
     "SPLINE_CHUNK",            // spline mode: rows per chunk of the substitution passes
     "WIN",         // 4-D lean sweep window layout: 0 single floats + ds_read2_b32, 1 position-paired + ds_read_b64
-    "STAGE",       // 4-D lean sweep: 2 or 4 actions staged together
     "TABLES",      // lean sweep per-node coefficient tables: 0 per-node arrays, 1 factorised where the dynamics allow
 };
 static std::vector<std::pair<std::string, std::string>> g_overrides;
@@ -2713,7 +2712,7 @@ struct pvi_problem {
     bool lean4_ok = false;
     int lean4_block = 512, lean4_rsk = 0, lean4_bands = 1, lean4_tables = 0;
     void* lean4_tiles = nullptr;  // [grid] Lean4Tile, launch order
-    int lean4_stage = 4;          // actions whose gathers are in flight together (2: fewer registers, more waves)
+    int lean4_stage = 2;          // actions whose gathers are in flight together (sweep_lean4.inc)
     int lean4_ptab_inv = 0;       // bit 0 / 1: the (position node, action) table does not depend on axis 0 / 1
     long long lean4_ptab_groups = 0;
     char lean4_cands[960] = "";  // the timed tile shapes of set-up: rows x columns : ms
@@ -2898,26 +2897,24 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
 // =====================================================================================================================
 
 template <typename PI_T>
-static int launch_lean4_t(pvi_problem* h, const float* Jin, float* Jout, float alpha, hipStream_t st, SweepCtl sc) {
+static int launch_lean4_t(pvi_problem* h, const float* Jin, float* Jout, float alpha, hipStream_t st, SweepCtl sc, bool probe = false) {
     const Lean4P& L = h->L4;
     sc.nblocks = h->lean4_grid;
     sc.split_finish = 1;
     PI_T* pi = (PI_T*)h->pi;
-#define L4(DYN)                                     \
-    if (h->lean4_stage == 2)                        \
-        L4K(DYN, 2)                                 \
-    else if (h->lean4_stage == 1)                   \
-        L4K(DYN, 1)                                 \
-    else                                            \
-        L4K(DYN, 4)
-#define L4K(DYN, STG)                                                                                                  \
+#define L4K(KFN)                                                                                                       \
     {                                                                                                                  \
-        auto kfn = k_sweep_lean4<DYN, PI_T, STG>;                                                                      \
+        auto kfn = KFN;                                                                                                \
         if (h->lean4_lds > 48 * 1024)                                                                                  \
             HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PVI_LDS_MAX));    \
         hipLaunchKernelGGL(kfn, dim3(h->lean4_grid), dim3(h->lean4_block), h->lean4_lds, st, h->P, L, Jin, Jout, pi, alpha, \
                            sc, (const float*)L.ptab, (const Lean4Tile*)h->lean4_tiles);                                \
     }
+#define L4(DYN)                                   \
+    if (probe)                                    \
+        L4K((k_sweep_lean4_probe<DYN, PI_T>))     \
+    else                                          \
+        L4K((k_sweep_lean4<DYN, PI_T>))
     switch (h->d.dynamics_id) {
         case PVI_DYN_CARTPOLE: L4(PVI_DYN_CARTPOLE) break;
         case PVI_DYN_NODE_2x1: L4(PVI_DYN_NODE_2x1) break;
@@ -3107,8 +3104,7 @@ static int lean4_setup(pvi_problem* h) {
     const long long npos = (long long)rows * P.dim[1];
     int rc;
     L.owned = h->owned;
-    h->lean4_stage = ovr("STAGE") ? atoi(ovr("STAGE")) : 2;
-    if (h->lean4_stage != 1 && h->lean4_stage != 4) h->lean4_stage = 2;
+    h->lean4_stage = 2;
     L.ngroups = (P.A + 3) / 4;
     float2* tsp_node = nullptr;
     float* gx_node = nullptr;
@@ -3300,8 +3296,8 @@ static int lean4_setup(pvi_problem* h) {
             if (rep == 1) HIPCHK(hipEventRecord(h->ev0, h->stream));
             hipLaunchKernelGGL(k_reset_stats, 1, STAT_WORDS, 0, h->stream, h->slots, STAT_WORDS);
             hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, h->stream, h->ctrl);
-            rc = h->pi_size == 1 ? launch_lean4_t<unsigned char>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc)
-                                 : launch_lean4_t<unsigned short>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc);
+            rc = h->pi_size == 1 ? launch_lean4_t<unsigned char>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc, true)
+                                 : launch_lean4_t<unsigned short>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc, true);
         }
         if (rc) return rc;
         HIPCHK(hipEventRecord(h->ev1, h->stream));

@@ -4,10 +4,20 @@
 W=$1
 cd /tmp && export TMPDIR=/tmp
 OUT=/root/repo/gpurun_out/counters_$W; mkdir -p $OUT
+# 2-D lean sweeps: the timed choice between near-equal tile shapes flips under the profiler (counter collection serialises
+# the launches): take the shape an UNPROFILED create chooses and pin it for the passes, so that the counters describe the
+# variant bench.py runs
+PIN=$(python /root/repo/tools/tools_describe.py $W 2>/dev/null | python3 -c "
+import sys,re
+d=dict(t.split('=',1) for t in sys.stdin.read().split() if '=' in t)
+if d.get('path')=='lean' and d.get('win')=='0' and d.get('lsplit')=='0' and 'tile' in d:
+    a,b=d['tile'].split('x'); print('TV0=%s TV1=%s NPT=%s' % (a,b,d.get('npt','1')))
+")
+echo "pins: $PIN"
 i=0
 for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -o p -- python /root/repo/tools/tools_traffic.py $W > $OUT/p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -o p -- python /root/repo/tools/tools_traffic.py $W $PIN > $OUT/p$i.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, json

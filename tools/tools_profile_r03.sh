@@ -14,6 +14,11 @@ done
 python tools/make_counters_json.py $WL
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/r03_stats_default -o s -- python /root/repo/bench.py > /root/repo/gpurun_out/r03_bench_default.json 2> /root/repo/gpurun_out/r03_bench_default.err)
 tail -c 400 gpurun_out/r03_bench_default.json
-for w in $WL default; do f=$(find gpurun_out/r03_stats_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f profiles/r03_${w}_bench_kernel_stats.csv; done
-cp gpurun_out/r03_bench_default.json profiles/r03_bench_default.json 2>/dev/null
+# the GPU box merges only gpurun_out/ back: tools/collect_profiles.sh (run in the repository afterwards) copies the summaries
+# into profiles/
+for w in $WL default; do
+  t=$(find gpurun_out/r03_stats_$w -name "*kernel_trace.csv" | head -1)
+  [ -n "$t" ] && python tools/kernel_trace_summary.py $t 0.05 > gpurun_out/r03_stats_$w/by_launch.txt
+done
+bash tools/collect_profiles.sh
 ls profiles | grep r03

@@ -5,9 +5,11 @@ import contextlib, io, sys
 sys.path.insert(0, "/root/repo")
 from pyro_amd import configs
 from pyro_amd.planning import dynamicprogramming
+from pyro_amd import _native
 name = sys.argv[1]
+ov = dict(a.split("=", 1) for a in sys.argv[2:] if "=" in a)     # pvi_override pins (the variant an unprofiled run chose)
 cfg = configs.build(name)
-with contextlib.redirect_stdout(io.StringIO()):
+with _native.overrides(**ov), contextlib.redirect_stdout(io.StringIO()):
     dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype=cfg["dtype"])
 dp.save_time_history = False
 p = dp._p
