@@ -173,7 +173,10 @@ def _fragment(cfg, drv, world, steps, warmup, elapsed, batches, st, setup_s, per
         k = [b + i for b, i in zip(per_rank["kernel_boundary_ms"], per_rank["kernel_interior_ms"])]
         out["kernel_ms_max_rank"] = max(k)
         out["exposed_exchange_ms_max_rank"] = max(per_rank["exposed_exchange_ms"])
-        out["overlap_efficiency"] = 1.0 - max(per_rank["exposed_exchange_ms"]) / max(max(per_rank["exchange_ms"]), 1e-9)
+        # share of the exchange hidden behind the interior kernel; undefined when there is nothing to exchange (one rank:
+        # both numbers are event noise)
+        ex = max(per_rank["exchange_ms"])
+        out["overlap_efficiency"] = (max(0.0, 1.0 - max(per_rank["exposed_exchange_ms"]) / ex) if ex >= 0.05 else None)
     if drv.fallback_reason:
         out["in_library_rccl_error"] = drv.fallback_reason
     return out
