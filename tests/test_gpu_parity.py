@@ -2217,3 +2217,37 @@ def test_example_sharded_script_runs_on_one_rank():
                            capture_output=True, text=True, timeout=900, env=env, cwd=tmp)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         assert "u(hanging, at rest)" in r.stdout and "comm=rccl" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_h3_full_size_fast_sweep_against_the_plain_kernel(variants):
+    """The n = 3 bench workload (helicopter tunnel 201 x 201 x 401 x 9, float32) at FULL size: the mask-walking production
+    sweep k_sweep3_fast against k_sweep3 -- the operation-for-operation kernel that the reference's goldens pin at small sizes
+    (test_3d_systems_fused_kernels_match_reference) -- on the whole grid after 1, 5 and 30 sweeps; policies differ on ties
+    and last-bit flips only; obstacle nodes cost the same INF in both."""
+    from pyro_amd import configs
+    from pyro_amd.planning import dynamicprogramming
+    with contextlib.redirect_stdout(io.StringIO()):
+        c = configs.build("h3")
+    outs = {}
+    for tag, env in (("fast3", {}), ("plain", {"PVI_NO_FAST": "1"})):
+        variants.delenv("PVI_NO_FAST")
+        for k, v in env.items():
+            variants.setenv(k, v)
+        with contextlib.redirect_stdout(io.StringIO()):
+            dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(c["grid_sys"], c["cf"], dtype="float32")
+        dp.save_time_history = False
+        desc = dp._p.describe()
+        assert desc.startswith("path=fast3" if tag == "fast3" else "path=exact-f32"), desc
+        res, done = [], 0
+        for k in (1, 5, 30):
+            dp._p.sweep(k - done, 1.0, -1.0)
+            done = k
+            res.append((dp._p.get_J(), dp._p.get_pi()))
+        outs[tag] = res
+        dp._p.close()
+    variants.delenv("PVI_NO_FAST")
+    for (Jf, pf), (Jp, pp_) in zip(outs["fast3"], outs["plain"]):
+        scale = np.abs(Jp).max()
+        assert np.abs(Jf - Jp).max() <= 2e-6 * scale
+        assert (pf != pp_).mean() < 2e-3
