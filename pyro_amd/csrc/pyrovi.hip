@@ -3235,6 +3235,39 @@ static int lean4_setup(pvi_problem* h) {
         L.csize = h->owned;
         L.tsp = tsp_node;
     }
+    // ---- the velocity cells every node reaches, once: each candidate tiling folds them into its window boxes ---------------
+    struct BoxGuard {  // (set-up scratch: four bytes per owned node, gone on every way out)
+        Lean4P& L;
+        ~BoxGuard() {
+            if (L.box) (void)hipFree((void*)L.box);
+            L.box = nullptr;
+        }
+    } box_guard{L};
+    if (!ovr_is("TUNE", 0) && !(ovr("TV0") && ovr("TV1"))) {  // (a single candidate computes its boxes directly)
+        char4* box = nullptr;
+        if (hipMalloc((void**)&box, (size_t)h->owned * sizeof(char4)) != hipSuccess) {
+            (void)hipGetLastError();  // no room: the direct path
+            box = nullptr;
+        }
+        if (box) {
+            L.box = box;
+            L.V0 = P.dim[2];  // (the geometry fields every candidate sets again in lean4_try)
+            L.V1 = P.dim[3];
+            L.posdim1 = P.dim[1];
+            L.vplane = (long long)L.V0 * L.V1;
+            L.owned = h->owned;
+            int over = 0;
+            HIPCHK(hipMemcpyAsync(L.summary + 7, &over, sizeof(int), hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(k_lean4_nodebox, grid_for(h->owned), 256, 0, h->stream, P, L, box);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(&over, L.summary + 7, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (over) {  // a reach beyond +-126 cells does not fit a byte
+                (void)hipFree(box);
+                L.box = nullptr;
+            }
+        }
+    }
     // ---- tiling candidates, timed ------------------------------------------------------------------------------------------
     std::vector<int2> hpt0((size_t)P.dim[0] * P.dim[2]);
     HIPCHK(hipMemcpy(hpt0.data(), pt0, hpt0.size() * sizeof(int2), hipMemcpyDeviceToHost));
@@ -3267,8 +3300,8 @@ static int lean4_setup(pvi_problem* h) {
                     effs.push_back({(double)P.dim[2] * V1 / ((double)tl.size() * threads), cap});
                 }
                 std::sort(effs.begin(), effs.end(), [](const Eff& a, const Eff& b) { return a.e > b.e; });
-                for (size_t i = 0; i < effs.size() && i < 6 && cands.size() < 36; ++i)
-                    if (effs[i].e >= 0.8 * effs[0].e) cands.push_back({effs[i].cap, threads, V1});
+                for (size_t i = 0; i < effs.size() && i < 4 && cands.size() < 24; ++i)
+                    if (effs[i].e >= 0.85 * effs[0].e) cands.push_back({effs[i].cap, threads, V1});
             }
             if (!cands.empty()) break;
         }
@@ -3292,17 +3325,31 @@ static int lean4_setup(pvi_problem* h) {
         sc.slot = h->slots;
         sc.result = h->results;
         sc.tol = -1.0;
-        for (int rep = 0; rep < 3 && rc == 0; ++rep) {  // one warm-up, two timed
-            if (rep == 1) HIPCHK(hipEventRecord(h->ev0, h->stream));
+        bool hopeless = false;
+        for (int rep = 0; rep < 3 && rc == 0 && !hopeless; ++rep) {  // one warm-up, two timed
+            if (rep <= 1) HIPCHK(hipEventRecord(h->ev0, h->stream));
             hipLaunchKernelGGL(k_reset_stats, 1, STAT_WORDS, 0, h->stream, h->slots, STAT_WORDS);
             hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, h->stream, h->ctrl);
             rc = h->pi_size == 1 ? launch_lean4_t<unsigned char>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc, true)
                                  : launch_lean4_t<unsigned short>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc, true);
+            if (rc) return rc;
+            if (rep == 0) {  // (the warm-up sweep of a shape far off the best: not worth two more)
+                float warm = 0.f;
+                HIPCHK(hipEventRecord(h->ev1, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                HIPCHK(hipEventElapsedTime(&warm, h->ev0, h->ev1));
+                if (best >= 0 && warm > 1.5f * best_ms / 2.f) {
+                    hopeless = true;
+                    ms = 2.f * warm;
+                }
+            }
         }
         if (rc) return rc;
-        HIPCHK(hipEventRecord(h->ev1, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        if (!hopeless) {
+            HIPCHK(hipEventRecord(h->ev1, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        }
         {
             const size_t at = strlen(h->lean4_cands);
             if (cands[ci].wmax < V1)

@@ -1,10 +1,8 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out
-L=gpurun_out/r03_c2p_lsplit.log; : > $L
-for ls in "" LSPLIT=1 LSPLIT=2 LSPLIT=3 LSPLIT=4 LSPLIT=5; do
-python tools/tools_time.py c2p 2000 $ls | grep -E "TIME|nodes" | cut -c1-260 >> $L 2>&1
-done
-for ls in "" LSPLIT=1 LSPLIT=2 LSPLIT=3; do
-python tools/tools_time.py pendulum:101,101:11:float32 2000 $ls | grep -E "TIME|nodes" | cut -c1-260 >> $L 2>&1
-done
+L=gpurun_out/r03_stage.log; : > $L
+python tools/tools_time.py c3 30 | grep -E "TIME|nodes" >> $L 2>&1
+python tools/tools_time.py c4 10 | grep -E "TIME|nodes" >> $L 2>&1
+python tools/tools_time.py cartpole:21,21,21,21:7:float32 10 | grep -E "TIME|nodes" >> $L 2>&1
 cat $L
+python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "variants_agree or sampled_against_c_oracle or world1 or shard" > gpurun_out/r03_l4_variants.log 2>&1; grep -E "^E  |passed|failed" gpurun_out/r03_l4_variants.log | head -20
