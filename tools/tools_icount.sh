@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 for W in "$@"; do
   T=$(echo $W | tr ':,' '__')
   OUT=/root/repo/gpurun_out/icount_$T; mkdir -p $OUT
-  PVI_LSPLIT=0 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT -o p -- python /root/repo/tools/tools_traffic.py $W > $OUT.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT -o p -- python /root/repo/tools/tools_traffic.py $W LSPLIT=0 > $OUT.log 2>&1
   python3 - <<PY
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
