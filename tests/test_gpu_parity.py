@@ -2251,3 +2251,48 @@ def test_h3_full_size_fast_sweep_against_the_plain_kernel(variants):
         scale = np.abs(Jp).max()
         assert np.abs(Jf - Jp).max() <= 2e-6 * scale
         assert (pf != pp_).mean() < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,path", [
+    ("cartpole:13,11,15,14:300:float32", "lean"),      # 4-D LDS-window sweep, two-byte policy
+    ("cartpole:9,9,9,9:300:float64", "exact-f64v2"),
+    ("pendulum:61,57:300:float32", "lean"),            # 2-D
+    ("pendulum:61,57:300:float64", "exact-f64v2"),
+    ("twolink:7,8,9,10:17,16:float32", None),          # 272 torque pairs
+])
+def test_action_sets_beyond_one_byte(name, path):
+    """A > 255 actions: pi is stored in two bytes on the device (pvi_pi_itemsize; the sweeps' `unsigned short`
+    instantiations) -- J and the first-argmin policy against the oracle's C twin on the whole grid after 1, 2 and 6 sweeps."""
+    from oracle import c_oracle as CO
+    cfg, p = _full_problem(name)
+    g = cfg["grid_sys"]
+    assert g.actions_n > 255
+    with contextlib.redirect_stdout(io.StringIO()):
+        h = g._device_problem(cost=cfg["cf"].device_cost(), dtype=cfg["dtype"])
+    desc = h.describe()
+    if path:
+        assert desc.startswith("path=" + path), desc
+    f32 = cfg["dtype"] == "float32"
+    c = CO.CProblem(p)
+    h.terminal_cost()
+    N = p.nodes_n
+    done = 0
+    for k in (1, 2, 6):
+        if k - 1 - done > 0:
+            h.sweep(k - 1 - done, 1.0, -1.0)
+        Jk = h.get_J()
+        h.sweep(1, 1.0, -1.0)
+        done = k
+        Jk1, pik1 = h.get_J(), h.get_pi()
+        assert pik1.max() > 255 or k == 1, (name, k, pik1.max())       # the high actions do get chosen
+        Jo, pio = c.sweep(Jk, 1.0, 0, N, f32=f32)
+        scale = max(np.abs(Jo).max(), 1e-300)
+        assert np.abs(Jk1 - Jo).max() <= (REL_F32 if f32 else 1e-12) * scale, (name, k, desc)
+        if not f32:
+            assert np.array_equal(pik1, pio), (name, k)
+        else:
+            nodes = np.arange(N)
+            q, qmin = c.q_at(Jk, nodes, pik1)
+            assert (q - qmin).max() <= 1e-5 * scale, (name, k)
+    h.close()
