@@ -223,6 +223,19 @@ int pvi_synchronize(pvi_handle h);
    that is not counted.  float64 handles: both paths are exact, the result must be 0 / 0. */
 int pvi_self_check(pvi_handle h, double alpha, double* max_rel_diff, int64_t* pi_mismatches);
 
+/* diagnostics, host only (no device is touched; callable on a machine without a GPU): the tiling of one velocity plane that
+   the 4-D float32 sweep would use.  corner0[V0] = axis-0 corner index of the position row reached from
+   velocity row j (negative: the row leaves the box) -- tiles never straddle a change of it; `cap` = most rows per tile,
+   `threads` = workgroup size (a multiple of 64, <= 512), `wmax` = widest tile.  Writes up to `max_tiles` rectangles
+   {row0, nrows, col0, ncols} and returns their number (or a negative error code).  The rectangles partition the V0 x V1
+   plane and hold at most `threads` nodes each. */
+int pvi_plan_plane_tiles(int32_t V0, int32_t V1, const int32_t* corner0, int32_t cap, int32_t threads, int32_t wmax,
+                         int32_t* tiles4, int32_t max_tiles);
+/* ... and the launch order of `rows` x `n1` position nodes x `tiles_per_plane` tiles in `bands` bands: out[k] = tile id
+   ((r * n1 + i1) * tiles_per_plane + t) of physical block k, 0xffffffff = padding; block k runs on XCD k % 8, XCD x sweeps
+   its chunk of axis 1 for every row in turn.  Returns the number of blocks (a multiple of 8), writing at most `max_blocks`. */
+int64_t pvi_plan_schedule(int32_t rows, int32_t n1, int32_t tiles_per_plane, int32_t bands, uint32_t* out, int64_t max_blocks);
+
 /* ---- tables (tier B and reference attributes) ---------------------------------------------- */
 /* compute_xnext_table / compute_action_set_table / compute_cost_lookuptable for rows
    [row0,row0+nrows) (discretizer.py:342-376, :314-338; dynamicprogramming.py:517-553).

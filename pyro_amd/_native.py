@@ -80,6 +80,9 @@ SYMBOLS = {
     "pvi_device_pi": (C.c_int, [_h, C.POINTER(C.c_void_p)]),
     "pvi_synchronize": (C.c_int, [_h]),
     "pvi_self_check": (C.c_int, [_h, C.c_double, _dp, C.POINTER(C.c_int64)]),
+    "pvi_plan_plane_tiles": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32,
+                                       C.POINTER(C.c_int32), C.c_int32]),
+    "pvi_plan_schedule": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.c_int64]),
     "pvi_build_tables": (C.c_int, [_h, C.c_int32, C.c_int32, _dp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), _dp]),
     "pvi_set_tables": (C.c_int, [_h, _dp, _dp, C.POINTER(C.c_uint8)]),
     "pvi_policy_tables": (C.c_int, [_h, C.c_int32, _dp, _dp, _dp, C.POINTER(C.c_uint8), _dp]),
@@ -455,6 +458,33 @@ MAX3_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double))
 
 class pvi_transport(C.Structure):
     _fields_ = [("user", C.c_void_p), ("sendrecv", SENDRECV_FN), ("max3", MAX3_FN)]
+
+
+def plan_plane_tiles(V0, V1, corner0, cap, threads, wmax=None):
+    """Host-only diagnostic (pvi_plan_plane_tiles): the rectangles {row0, nrows, col0, ncols} the 4-D float32 sweep would cut
+    one V0 x V1 velocity plane into; corner0[j] = axis-0 corner index reached from velocity row j."""
+    c0 = np.ascontiguousarray(corner0, dtype=np.int32)
+    if c0.shape != (int(V0),):
+        raise ValueError("corner0 must have V0 entries")
+    wmax = int(V1 if wmax is None else wmax)
+    i32 = C.POINTER(C.c_int32)
+    n = lib().pvi_plan_plane_tiles(int(V0), int(V1), c0.ctypes.data_as(i32), int(cap), int(threads), wmax, None, 0)
+    if n < 0:
+        check(n)
+    out = np.zeros((n, 4), dtype=np.int32)
+    check(min(0, lib().pvi_plan_plane_tiles(int(V0), int(V1), c0.ctypes.data_as(i32), int(cap), int(threads), wmax,
+                                           out.ctypes.data_as(i32), n)))
+    return out
+
+
+def plan_schedule(rows, n1, tiles_per_plane, bands):
+    """Host-only diagnostic (pvi_plan_schedule): tile id of every physical block of the 4-D sweep's launch (0xffffffff = padding)."""
+    n = lib().pvi_plan_schedule(int(rows), int(n1), int(tiles_per_plane), int(bands), None, 0)
+    if n < 0:
+        check(int(n))
+    out = np.zeros(n, dtype=np.uint32)
+    lib().pvi_plan_schedule(int(rows), int(n1), int(tiles_per_plane), int(bands), out.ctypes.data_as(C.POINTER(C.c_uint32)), n)
+    return out
 
 
 def comm_unique_id():

@@ -3093,6 +3093,34 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
     return 0;
 }
 
+extern "C" int pvi_plan_plane_tiles(int32_t V0, int32_t V1, const int32_t* corner0, int32_t cap, int32_t threads, int32_t wmax,
+                                    int32_t* tiles4, int32_t max_tiles) {
+    if (V0 < 1 || V1 < 1 || !corner0 || cap < 1 || wmax < 1 || (!tiles4 && max_tiles > 0) || max_tiles < 0)
+        return fail(PVI_EINVAL, "pvi_plan_plane_tiles: bad argument");
+    if (threads < 64 || threads > 512 || (threads & 63)) return fail(PVI_EINVAL, "threads must be 64 ... 512 in steps of 64");
+    std::vector<int2> pt0((size_t)V0);
+    for (int j = 0; j < V0; ++j) pt0[(size_t)j] = make_int2(corner0[j], 0);
+    std::vector<int4> out;
+    lean4_row_tiles(pt0, 0, V0, V1, cap, threads, wmax, out);
+    for (size_t k = 0; k < out.size() && (int)k < max_tiles; ++k) {
+        tiles4[4 * k] = out[k].x;
+        tiles4[4 * k + 1] = out[k].y;
+        tiles4[4 * k + 2] = out[k].z;
+        tiles4[4 * k + 3] = out[k].w;
+    }
+    return (int)out.size();
+}
+
+extern "C" int64_t pvi_plan_schedule(int32_t rows, int32_t n1, int32_t tiles_per_plane, int32_t bands, uint32_t* out, int64_t max_blocks) {
+    if (rows < 1 || n1 < 1 || tiles_per_plane < 1 || bands < 1 || bands > tiles_per_plane || (!out && max_blocks > 0) || max_blocks < 0)
+        return fail(PVI_EINVAL, "pvi_plan_schedule: bad argument");
+    if ((long long)rows * n1 * tiles_per_plane >= 0x7fffffffLL / 8) return fail(PVI_EINVAL, "pvi_plan_schedule: too many tiles");
+    std::vector<unsigned> sched;
+    lean4_schedule(rows, n1, tiles_per_plane, bands, sched);
+    for (size_t k = 0; k < sched.size() && (long long)k < max_blocks; ++k) out[k] = sched[k];
+    return (int64_t)sched.size();
+}
+
 static int lean4_setup(pvi_problem* h) {
     const DevP& P = h->P;
     Lean4P& L = h->L4;

@@ -471,3 +471,60 @@ def test_no_environment_switch_in_the_product_library():
         _native.override("DBG", 1)
     assert e.value.code == -1 and "unknown key" in str(e.value)
     _native.override()
+
+
+def test_plane_tilings_partition_the_plane_and_fit_the_workgroup():
+    """Host logic of the 4-D float32 sweep (pyrovi.hip lean4_row_tiles, through the host-only diagnostic
+    pvi_plan_plane_tiles): for random plane sizes, step patterns of the axis-0 corner index, row caps, workgroup sizes and
+    width bounds the rectangles cover every node exactly once, hold at most `threads` nodes, never straddle a step of the
+    corner index, and respect the cap and the width bound."""
+    from pyro_amd import _native
+    rng = np.random.default_rng(5)
+    for case in range(300):
+        V0, V1 = int(rng.integers(1, 160)), int(rng.integers(1, 160))
+        # corner index: steps every `period` rows (cart-pole: v dt / dx), negative (row leaves the box) at the ends sometimes
+        period = float(rng.uniform(1.5, 40.0))
+        corner = np.floor((np.arange(V0) - V0 / 2 + rng.uniform(0, 1)) / period).astype(np.int32) + 7
+        if rng.random() < 0.3:
+            corner[: int(rng.integers(0, max(1, V0 // 4)))] = -1
+            corner[V0 - int(rng.integers(0, max(1, V0 // 4))):] = -5
+        threads = int(rng.choice([64, 128, 192, 256, 320, 384, 448, 512]))
+        cap = int(rng.integers(1, 70))
+        wmax = int(rng.integers(1, V1 + 1)) if rng.random() < 0.5 else V1
+        t = _native.plan_plane_tiles(V0, V1, corner, cap, threads, wmax)
+        cover = np.zeros((V0, V1), dtype=np.int32)
+        for r0, nr, c0, nc in t:
+            assert nr >= 1 and nc >= 1 and r0 >= 0 and c0 >= 0 and r0 + nr <= V0 and c0 + nc <= V1, (case, t)
+            cover[r0:r0 + nr, c0:c0 + nc] += 1
+            # one axis-0 corner pair per tile (rows that leave the box count as one kind)
+            kinds = np.where(corner[r0:r0 + nr] < 0, -(1 << 30), corner[r0:r0 + nr])
+            assert (kinds == kinds[0]).all(), (case, r0, nr)
+            assert nr <= cap and nc <= wmax, (case, nr, nc, cap, wmax)
+            # a tile wider than the workgroup only where even one column of the piece does not fit it (rows > threads)
+            assert nr * nc <= threads or nc == 1, (case, nr, nc, threads)
+        assert (cover == 1).all(), (case, V0, V1, cap, threads, wmax)
+    with pytest.raises(Exception):
+        _native.plan_plane_tiles(5, 5, np.zeros(5, dtype=np.int32), 4, 100)           # threads not a multiple of 64
+
+
+def test_launch_schedule_is_a_permutation_dealt_to_the_xcds():
+    """pvi_plan_schedule (lean4_schedule): every tile exactly once, padding only at the tails of the per-XCD lists, XCD x =
+    blocks k with k % 8 == x holds a contiguous chunk of axis 1 for every row, rows ascending inside a band."""
+    from pyro_amd import _native
+    rng = np.random.default_rng(6)
+    for case in range(40):
+        rows, n1, tpp = int(rng.integers(1, 12)), int(rng.integers(1, 40)), int(rng.integers(1, 30))
+        bands = int(rng.integers(1, tpp + 1))
+        s = _native.plan_schedule(rows, n1, tpp, bands)
+        assert len(s) % 8 == 0
+        live = s[s != 0xFFFFFFFF]
+        assert len(live) == rows * n1 * tpp and len(np.unique(live)) == len(live) and live.max() == rows * n1 * tpp - 1
+        for x in range(8):
+            lst = s[x::8]
+            pad = lst == 0xFFFFFFFF
+            assert not pad[:len(lst) - pad.sum()].any()                      # padding at the tail only
+            ids = lst[~pad].astype(np.int64)
+            i1 = (ids // tpp) % n1
+            if len(ids):
+                assert i1.max() - i1.min() + 1 == len(np.unique(i1))         # a contiguous chunk of axis 1
+                assert i1.min() == n1 * x // 8 and i1.max() == n1 * (x + 1) // 8 - 1
