@@ -1,6 +1,7 @@
 """A tour of the C ABI for the sanitizer host build (run with LD_PRELOAD=<ubsan runtime> PYROVI_LIB=.../libpyrovi_ubsan.so):
 create / destroy of every handle kind, sweeps with a stop, uploads and downloads, tables, packed tables, spline mode,
-rollouts, the explicit systems with obstacles, self check, a one-rank shard, error paths."""
+rollouts, the explicit systems with obstacles, self check, one-rank shards (agreed halo, gathers, history, timing), variant
+pins, policy tables, planning diagnostics, error paths."""
 import contextlib, io, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -62,6 +63,35 @@ with contextlib.redirect_stdout(io.StringIO()):
     sh.terminal_cost(); sh.sweep(4, 1.0, -1.0); sh.get_J(); sh.get_pi(); sh.describe(); sh.close()
     sh = cfg["grid_sys"]._shard_problem(0, 1, 3, comm_id=_native.comm_unique_id(), cost=cfg["cf"].device_cost(), dtype="float32")
     sh.terminal_cost(); sh.sweep(4, 1.0, 0.5); sh.close()
+    sh = cfg["grid_sys"]._shard_problem(0, 1, -3, comm_id=_native.comm_unique_id(), cost=cfg["cf"].device_cost(), dtype="float32")
+    sh.terminal_cost(); sh.stats_every_sweep(True); sh.sweep(5, 1.0, -1.0)
+    assert sh.halo == 3 and sh.sweep_history().shape == (5, 4) and len(sh.timing()) == 6
+    sh.gather_J(); sh.gather_J(prev=True); sh.gather_pi(); sh.get_J(prev=True); sh.close()
+    # round-3 entry points: variant pins, policy tables (controller in-kernel), rollouts of an explicit system, planning diagnostics
+    from pyro_amd.control import nonlinear
+    with _native.overrides(NO_LEAN=1, TUNE=0):
+        cfgp = configs.build("pendulum:31,31:5:float32")
+        p = cfgp["grid_sys"]._device_problem(cost=cfgp["cf"].device_cost(), dtype="float32")
+        p.terminal_cost(); p.sweep(3, 1.0, -1.0); p.close()
+    try:
+        _native.override("NOT_A_KEY", 1)
+    except RuntimeError:
+        pass
+    pend = pendulum.SinglePendulum()
+    ctl = nonlinear.ComputedTorqueController(pend)
+    ctl.rbar = np.array([-3.14])
+    gsp = discretizer.GridDynamicSystem(pend, [31, 31], [3], 0.05, False)
+    ev = dynamicprogramming.PolicyEvaluatorWithLookUpTable(ctl, gsp, costfunction.QuadraticCostFunction.from_sys(pend))
+    assert ev.tables_on.startswith("gpu")
+    ev.compute_steps(4)
+    heli = drone.ConstantSpeedHelicopterTunnel()
+    gsh = discretizer.GridDynamicSystem(heli, (11, 11, 11), [5], 0.05)
+    dph = dynamicprogramming.DynamicProgrammingWithLookUpTable(gsh, costfunction.QuadraticCostFunctionWithDomainCheck.from_sys(heli), dtype="float32")
+    dph.compute_steps(3)
+    dph.simulate_closed_loop(np.array([[0.0, 5.0, 0.0]]), tf=0.5, n=51)
+    t = _native.plan_plane_tiles(37, 41, np.arange(37) // 9, 8, 256, 19)
+    assert t[:, 1].max() <= 8 and (t[:, 1] * t[:, 3]).max() <= 256
+    assert len(_native.plan_schedule(3, 9, len(t), 2)) % 8 == 0
     # error paths
     try:
         _native.Problem([np.linspace(0, 1, 1)] * 2, [np.linspace(0, 1, 2)], [0, 0], [1, 1], [0], [1], 0.1)
