@@ -3049,7 +3049,7 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
     const size_t lds = (size_t)std::max(summary[0], 1) * (size_t)rs * 8 + 256;
     if (narrower) {  // the widest tile whose window lets as many workgroups onto a CU as the register budget does (24 waves)
         *narrower = 0;
-        const size_t room = (size_t)160 * 1024 / (size_t)std::max(1, 1536 / threads) - 1536;
+        const size_t room = (size_t)160 * 1024 / (size_t)std::max(1, 1536 / threads) - 512;
         if (lds > room && summary[0] > 0) {
             const int rs_fit = (int)((room - 256) / 8 / (size_t)summary[0]) & ~3, w_fit = tv1 - (rs - rs_fit);
             if (w_fit >= 12 && w_fit < tv1) *narrower = w_fit;
