@@ -306,8 +306,8 @@ class Problem:
         return int(row0), int(nrows)
 
     def describe(self):
-        buf = C.create_string_buffer(2048)
-        check(lib().pvi_describe(self._h, buf, 1024))
+        buf = C.create_string_buffer(4096)
+        check(lib().pvi_describe(self._h, buf, 4096))
         return buf.value.decode()
 
     def terminal_cost(self):

@@ -2670,11 +2670,22 @@ static const char* const OVERRIDE_KEYS[] = {
 static std::vector<std::pair<std::string, std::string>> g_overrides;
 static std::mutex g_override_mu;
 
-// value of an override or NULL (the returned pointer stays valid until the key is set again)
+// value of an override or NULL.  The string is a thread-local COPY taken under the lock (one slot per key, so several
+// values can be held at once): a concurrent pvi_override cannot pull it from under the reader.
 static const char* ovr(const char* key) {
+    static thread_local std::vector<std::pair<std::string, std::string>> held;
     std::lock_guard<std::mutex> lk(g_override_mu);
     for (auto& kv : g_overrides)
-        if (kv.first == key) return kv.second.c_str();
+        if (kv.first == key) {
+            for (auto& h : held)
+                if (h.first == key) {
+                    h.second = kv.second;
+                    return h.second.c_str();
+                }
+            held.reserve(64);          // (fewer keys than that exist: no reallocation moves the strings of other keys)
+            held.emplace_back(kv.first, kv.second);
+            return held.back().second.c_str();
+        }
     return nullptr;
 }
 static inline bool ovr_is(const char* key, int v) {
@@ -2741,7 +2752,29 @@ struct pvi_problem {
     const double* roll_params = nullptr;  // constants of the continuous closed form (pvi_set_rollout_params)
     SplineP SP;               // bicubic-spline interpolation mode (sweep_spline.inc)
     bool spline = false;
+    char kname[128] = "";     // the sweep kernel of the last launch, as a kernel trace prints it (spaces removed): pvi_describe `kernel=`
 };
+
+// Name of a kernel template instantiation the way the demangler (rocprofv3's kernel trace) prints it, without spaces:
+// "k_sweep64<3,unsignedchar,true,true,true>".  Recorded at every sweep launch, reported by pvi_describe, so that counter
+// passes and trace summaries can be tied to the kernel a handle really runs (tools/make_counters_json.py, bench.py).
+template <typename T> static const char* tname();
+template <> const char* tname<float>() { return "float"; }
+template <> const char* tname<double>() { return "double"; }
+template <> const char* tname<unsigned char>() { return "unsignedchar"; }
+template <> const char* tname<unsigned short>() { return "unsignedshort"; }
+static inline void kn_arg(std::string& s, int v) { s += std::to_string(v); }
+static inline void kn_arg(std::string& s, bool v) { s += v ? "true" : "false"; }
+static inline void kn_arg(std::string& s, const char* v) { s += v; }
+template <typename... T>
+static void set_kname(pvi_problem* h, const char* base, T... args) {
+    std::string s(base);
+    s += "<";
+    bool first = true;
+    ((s += first ? "" : ",", first = false, kn_arg(s, args)), ...);
+    s += ">";
+    snprintf(h->kname, sizeof(h->kname), "%s", s.c_str());
+}
 
 template <typename T>
 static int dev_upload(pvi_problem* h, const T* src, size_t n, const T** out) {
@@ -2913,8 +2946,10 @@ static int launch_lean4_t(pvi_problem* h, const float* Jin, float* Jout, float a
 #define L4(DYN)                                   \
     if (probe)                                    \
         L4K((k_sweep_lean4_probe<DYN, PI_T>))     \
-    else                                          \
-        L4K((k_sweep_lean4<DYN, PI_T>))
+    else {                                        \
+        set_kname(h, "k_sweep_lean4", (int)DYN, tname<PI_T>()); \
+        L4K((k_sweep_lean4<DYN, PI_T>))           \
+    }
     switch (h->d.dynamics_id) {
         case PVI_DYN_CARTPOLE: L4(PVI_DYN_CARTPOLE) break;
         case PVI_DYN_NODE_2x1: L4(PVI_DYN_NODE_2x1) break;
@@ -4104,8 +4139,22 @@ extern "C" int64_t pvi_stored_nodes(pvi_handle h) { return h ? h->stored : 0; }
 extern "C" int64_t pvi_owned_nodes(pvi_handle h) { return h ? h->owned : 0; }
 extern "C" int pvi_pi_itemsize(pvi_handle h) { return h ? h->pi_size : 0; }
 
+static int describe_impl(pvi_handle h, char* buf, int32_t n);
 extern "C" int pvi_describe(pvi_handle h, char* buf, int32_t n) {
     if (!h || !buf || n <= 0) return fail(PVI_EINVAL, "bad argument");
+    std::vector<char> tmp((size_t)n + 256);
+    int rc = describe_impl(h, tmp.data(), (int32_t)tmp.size());
+    if (rc) return rc;
+    // `kernel=`: the sweep kernel of the last launch as a kernel trace names it, spaces removed ("-" before the first sweep);
+    // the second token, right behind `path=`
+    std::string d(tmp.data());
+    const std::string k = std::string(" kernel=") + (h->kname[0] ? h->kname : "-");
+    const size_t at = d.find(' ');
+    if (at == std::string::npos) d += k; else d.insert(at, k);
+    snprintf(buf, (size_t)n, "%s", d.c_str());
+    return PVI_OK;
+}
+static int describe_impl(pvi_handle h, char* buf, int32_t n) {
     if (h->spline) {
         snprintf(buf, (size_t)n, "path=spline-%s chunk0=%d warm0=%d chunk1=%d warm1=%d",
                  h->d.dynamics_id == PVI_DYN_TABLE ? "table" : "fused", h->SP.chunk0, h->SP.warm0, h->SP.chunk1, h->SP.warm1);
@@ -4304,6 +4353,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     if (h->spline) {
         const SplineP& S = h->SP;
         spline_fit_launch<REAL>(h, Jin, st);
+        set_kname(h, "k_sweep_spline", h->d.dynamics_id == PVI_DYN_TABLE ? (int)PVI_DYN_TABLE : (int)PVI_DYN_PENDULUM, tname<REAL>(), tname<PI_T>());
         if (h->d.dynamics_id == PVI_DYN_TABLE) {
             if (!h->d_xnext || !h->d_G) return fail(PVI_ESTATE, "spline sweep without the raw tables: pvi_set_tables after pvi_set_interpolation");
             hipLaunchKernelGGL((k_sweep_spline<PVI_DYN_TABLE, REAL, PI_T>), g, 256, 0, st, h->P, S, h->d_xnext, h->d_G,
@@ -4326,6 +4376,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
 #define LEAN4(DYN, U, NP, RSK)                                                                                      \
     {                                                                                                               \
         auto kfn = k_sweep_lean<DYN, PI_T, U, NP, RSK>;                                                                  \
+        set_kname(h, "k_sweep_lean", (int)DYN, tname<PI_T>(), (bool)U, (int)NP, (int)RSK);                              \
         if (!h->lean_lds_attr && h->lean_lds > 48 * 1024) {                                                         \
             HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PVI_LDS_MAX)); \
             h->lean_lds_attr = true;                                                                                \
@@ -4372,6 +4423,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             const float al = (float)alpha;
             sc.nblocks = gf;
 #define FAST(DYN)                                                                                                  \
+    set_kname(h, "k_sweep_fast", (int)DYN, tname<PI_T>(), h->F.lsplit == 0);                                       \
     if (h->F.lsplit == 0)                                                                                          \
         hipLaunchKernelGGL((k_sweep_fast<DYN, PI_T, true>), gf, 256, 0, st, h->P, h->F, Jin, Jout, pi, al, sc, h->F.act);                                                                                  \
     else                                                                                                           \
@@ -4394,11 +4446,13 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
 #define EXACT(DYN)                                                                                                     \
     if constexpr (Dyn<DYN>::DOF == 2 && sizeof(REAL) == 4) {                                                           \
         if (sparse_x) {                                                                                                \
+            set_kname(h, "k_sweep", (int)DYN, tname<REAL>(), tname<PI_T>(), true, true);                              \
             hipLaunchKernelGGL((k_sweep<DYN, REAL, PI_T, true, true>), g, 256, lev_bytes, st, h->P, Jin, Jout, pi,     \
                                alpha, sc, h->P.utab, h->P.gu, h->aok32, h->vmask);                                     \
             break;                                                                                                     \
         }                                                                                                              \
     }                                                                                                                  \
+    set_kname(h, "k_sweep", (int)DYN, tname<REAL>(), tname<PI_T>(), lev_in_lds, false);                               \
     if (lev_in_lds)                                                                                                    \
         hipLaunchKernelGGL((k_sweep<DYN, REAL, PI_T, true>), g, 256, lev_bytes, st, h->P, Jin, Jout, pi, alpha, sc,    \
                            h->P.utab, h->P.gu, h->aok32, (const uint4*)nullptr);                                       \
@@ -4421,6 +4475,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             sc.xcd_remap = (gp >= 64u && !(ovr("XCD64") && !atoi(ovr("XCD64")))) ? 1 : 0;
             const size_t lds64 = h->levr_bytes + (sparse == 1 ? (size_t)h->P.A * sizeof(Act64) : 0);
 #define S64Q(DYN, PT, SP)                                                                                             \
+    set_kname(h, "k_sweep64", (int)DYN, tname<PI_T>(), off32, (bool)PT, (bool)SP);                                    \
     if (off32)                                                                                                        \
         hipLaunchKernelGGL((k_sweep64<DYN, PI_T, true, PT, SP>), gp, 256, lds64, st, h->P, Jin, Jout, pi, alpha, sc,  \
                            h->act64, h->levr, h->vmask);                                                              \
@@ -4465,6 +4520,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     if constexpr (sizeof(REAL) == 4) {
         if (h->okmask3 && !h->force_exact) {
 #define FAST3(DYN)                                                                                                  \
+    set_kname(h, "k_sweep3_fast", (int)DYN, tname<PI_T>());                                                         \
     hipLaunchKernelGGL((k_sweep3_fast<DYN, PI_T>), g, 256, 0, st, h->P, Jin, Jout, pi, (float)alpha, sc, h->P.utab, h->P.gu, \
                        h->okmask3)
             switch (h->d.dynamics_id) {
@@ -4480,6 +4536,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         }
     }
 #define SWEEP3(DYN)                                                                                                  \
+    set_kname(h, "k_sweep3", (int)DYN, tname<REAL>(), tname<PI_T>());                                                \
     hipLaunchKernelGGL((k_sweep3<DYN, REAL, PI_T>), g, 256, 0, st, h->P, Jin, Jout, pi, alpha, sc, h->P.utab, h->P.gu, \
                        h->aok32)
     switch (h->d.dynamics_id) {
@@ -4506,6 +4563,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
                 if (h->packed) {
                     const unsigned gp = (unsigned)((h->owned + 255) / 256);
                     sc.nblocks = gp;
+                    set_kname(h, "k_sweep_tablep", h->P.n, tname<REAL>(), tname<PI_T>());
                     switch (h->P.n) {
                         case 2:
                             hipLaunchKernelGGL((k_sweep_tablep<2, REAL, PI_T>), gp, 256, 0, st, h->P,
@@ -4533,6 +4591,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
                 int lpn_t = 0;
                 while ((npb << (lpn_t + 1)) <= 256 && (2 << lpn_t) <= 16 && (4 << lpn_t) <= achunk) ++lpn_t;
 #define TABLE(NN, LL)                                                                                                   \
+    set_kname(h, "k_sweep_table", (int)NN, tname<REAL>(), tname<PI_T>(), (bool)LL);                                     \
     hipLaunchKernelGGL((k_sweep_table<NN, REAL, PI_T, LL>), gt, 256, lds, st, h->P, h->d_xnext, h->d_G, h->d_ok, Jin, Jout, \
                        pi, alpha, sc, npb, achunk, qs_doubles, lpn_t)
                 switch (h->P.n * 2 + lev_lds) {

@@ -37,7 +37,7 @@ def partition_rows(n_rows, world):
     return out
 
 
-def halo_rows(grid_sys, rows=None, xn=None):
+def halo_rows(grid_sys, rows=None, xn=None, device=0):
     """Rows of axis 0 a gather can reach beyond a node's own row (+1 for the upper corner).
 
     Mechanical systems: x_next_0 - x_0 = dq_0 dt exactly, so the bound is analytic and GLOBAL.  Any other system: the
@@ -54,7 +54,7 @@ def halo_rows(grid_sys, rows=None, xn=None):
     plane = int(np.prod(grid_sys.x_grid_dim[1:]))
     lo = 0 if rows is None else rows[0] * plane
     if xn is None:
-        xn = grid_sys.x_next_table if rows is None else _xnext_of_rows(grid_sys, rows)
+        xn = grid_sys.x_next_table if rows is None else _xnext_of_rows(grid_sys, rows, device)
     x0 = np.repeat(grid_sys.x_level[0], plane)[lo:lo + xn.shape[0]]
     inside = np.ones(xn.shape[:2], dtype=bool)
     for d in range(s.n):
@@ -64,13 +64,14 @@ def halo_rows(grid_sys, rows=None, xn=None):
     return int(math.ceil(r / float(grid_sys.x_step_size[0]))) + 1
 
 
-def _xnext_of_rows(grid_sys, rows):
-    """x_next of the nodes of axis-0 rows [rows[0], rows[1]): from the GPU for systems with in-kernel dynamics (only those
-    rows are built), from the reference's loop over sys.f otherwise."""
+def _xnext_of_rows(grid_sys, rows, device=0):
+    """x_next of the nodes of axis-0 rows [rows[0], rows[1]): from the GPU for systems with in-kernel dynamics, from the
+    reference's loop over sys.f otherwise.  The GPU handle owns and stores THOSE rows only, on the rank's own device (a
+    whole-grid handle on device 0 per rank would defeat sharding for memory and serialise set-up on one GPU)."""
     from pyro_amd.planning.discretizer import device_dynamics_of
     plane = int(np.prod(grid_sys.x_grid_dim[1:]))
     if device_dynamics_of(grid_sys.sys) is not None:
-        p = grid_sys._device_problem()
+        p = grid_sys._device_problem(rows=(int(rows[0]), int(rows[1])), halo=(0, 0), device=device)
         try:
             return p.build_tables(rows[0], rows[1] - rows[0], x_next_isok=False, action_isok=False, G=False)[0]
         finally:
@@ -85,7 +86,8 @@ class HipSlab:
     rows next to each neighbour ("boundary") and the rest ("interior") -- so that a sweep can run
     boundary kernels -> [halo exchange || interior kernel]: the rows the neighbours wait for are produced first."""
 
-    def __init__(self, grid_sys, cost, dtype, rows, halo, device, split=False, has_lower=False, has_upper=False):
+    def __init__(self, grid_sys, cost, dtype, rows, halo, device, split=False, has_lower=False, has_upper=False,
+                 hard_inf=False):
         import torch
         from pyro_amd import _native
         self.torch = torch
@@ -121,7 +123,7 @@ class HipSlab:
             return grid_sys._device_problem(
                 cost=cost, dtype=dtype, rows=(a, b), halo=(a - self.store_rows[0], self.store_rows[1] - b), device=device,
                 ext_J=[t.data_ptr() for t in self.J], ext_pi=self.pi.data_ptr() + (a - r0) * self.plane * self.pi.element_size(),
-                flags=_native.FLAG_EXT_J_SLACK)
+                flags=_native.FLAG_EXT_J_SLACK | (_native.FLAG_HARD_INF if hard_inf else 0))
         self.handles = [make(pc) for pc in pieces]
         self.n_boundary = len(self.boundary)
         self.p = self.handles[-1]
@@ -188,7 +190,7 @@ class ShardedValueIteration:
     """Drives one slab per rank; `dist` is torch.distributed (already initialised)."""
 
     def __init__(self, grid_sys, cost_function, dist, dtype="float32", device=0, slab_factory=None, halo=None,
-                 overlap=True):
+                 overlap=True, hard_inf=False):
         import torch
         self.torch, self.dist = torch, dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
@@ -199,11 +201,11 @@ class ShardedValueIteration:
         if halo is None:
             # mechanical systems: analytic.  Anything else: this rank's bound, then the largest over the ranks -- the
             # exchange needs ONE width (neighbours post matching send / recv counts)
-            halo = halo_rows(grid_sys, None if getattr(grid_sys.sys, "dof", None) is not None else self.rows)
+            halo = halo_rows(grid_sys, None if getattr(grid_sys.sys, "dof", None) is not None else self.rows, device=device)
             if self.world > 1 and getattr(grid_sys.sys, "dof", None) is None:
-                t = torch.tensor([halo], dtype=torch.int64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                halo = int(t.item())
+                bounds = [None] * self.world              # (all_gather_object: works on any backend, also a pure nccl group,
+                dist.all_gather_object(bounds, int(halo))  #  where an all_reduce of a CPU tensor raises)
+                halo = max(bounds)
         self.halo = int(halo)
         if self.rows[1] - self.rows[0] < 1:
             raise ValueError("more ranks than rows of axis 0")
@@ -216,9 +218,13 @@ class ShardedValueIteration:
         self.overlap = bool(overlap) and slab_factory is None and self.p2p and self.world > 1
         if slab_factory is None:
             self.slab = HipSlab(grid_sys, cost, dtype, self.rows, store_halo, device, split=self.overlap,
-                                has_lower=self.rank > 0, has_upper=self.rank < self.world - 1)
+                                has_lower=self.rank > 0, has_upper=self.rank < self.world - 1, hard_inf=hard_inf)
         else:
-            self.slab = slab_factory(grid_sys, cost, dtype, self.rows, store_halo, device)
+            import inspect
+            kw = {"hard_inf": True} if hard_inf else {}
+            if hard_inf and "hard_inf" not in inspect.signature(slab_factory).parameters:
+                raise NotImplementedError("this slab back end has no base-class (exactly-INF) recursion")
+            self.slab = slab_factory(grid_sys, cost, dtype, self.rows, store_halo, device, **kw)
         self.k = 0
         self.slab.terminal_cost()
 
@@ -354,7 +360,7 @@ class RcclValueIteration:
                 # mechanical: analytic and global.  Explicit systems: the bound of THIS rank's rows (built on the GPU for
                 # those rows only), negative = "take the largest over the ranks" (pvi_shard_create)
                 mech = getattr(s, "dof", None) is not None
-                halo = halo_rows(grid_sys) if mech else -halo_rows(grid_sys, (r0, r1))
+                halo = halo_rows(grid_sys) if mech else -halo_rows(grid_sys, (r0, r1), device=device)
             self.shard = grid_sys._shard_problem(self.rank, self.world, int(halo), comm_id=comm_id, overlap=overlap,
                                                  cost=cost, dtype=dtype, device=device, transport=transport,
                                                  flags=_native.FLAG_HARD_INF if hard_inf else 0)
@@ -541,8 +547,14 @@ class _TorchEngine:
     sharded = True
 
     def __init__(self, dp, comm):
+        from pyro_amd.planning.discretizer import device_cost_of, device_dynamics_of
+        if comm.slab_factory is None and (device_dynamics_of(dp.grid_sys.sys) is None
+                                          or device_cost_of(dp.cf, dp.grid_sys.sys) is None):
+            # (the Python-driven schedule has no table tier: RcclComm / TransportComm shard the look-up tables)
+            raise NotImplementedError("TorchDistComm drives the fused tier only (in-kernel dynamics and cost); use RcclComm "
+                                      "or TransportComm for systems / costs that need look-up tables")
         self.vi = ShardedValueIteration(dp.grid_sys, dp.cf, comm.dist, dtype=dp.dtype, device=dp.device,
-                                        slab_factory=comm.slab_factory, overlap=comm.overlap)
+                                        slab_factory=comm.slab_factory, overlap=comm.overlap, hard_inf=bool(dp.HARD_INF))
         self.tier, self.rows, self.world = "fused", self.vi.rows, comm.world
         self.dynamics_id = None
 

@@ -257,6 +257,7 @@ def run(args):
                 frag["strong_scaling_speedup"] = frag["value"] / ref if ref else None
                 out["secondary"] = {"c4": frag}
     if rank == 0:
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        from pyro_amd import benchline
+        benchline.emit(out, fd=real_stdout)       # compact headline on stdout, the full record on stderr / gpurun_out
     _barrier(dist, torch)
     dist.destroy_process_group()

@@ -48,3 +48,64 @@ def test_usable_cpus_and_counter_sources():
     for name, rec in ctr.items():
         if isinstance(rec, dict):
             assert "source" in rec and "profiles/" in rec["source"], name      # counters are labelled, never anonymous
+
+
+def test_the_driver_parsed_line_is_compact():
+    """round 3's 26.5 KB line could not be parsed by the driver.  The headline built from the full records of
+    round 3 (N = 1 default run with every secondary, the N > 1 harness lines) must stay below 4 KB, load as JSON and carry
+    the contract keys, the roofline and the CPU baseline."""
+    import json
+    from pyro_amd import benchline
+    for name in ("r03_bench_default.json", "r03_bench_world1.json", "r03_bench_world1_c4.json"):
+        full = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert len(json.dumps(full)) > 8000 or "world1" in name
+        # fields this round adds to the full record
+        full["jstar_rel_err_vs_cpu_on"] = "c1 float64 618 sweeps from J0 (solved to tol 0.1): 1.00e-13; " * 3
+        full["jstar_ok"] = True
+        line = json.dumps(benchline.compact_line(full, "gpurun_out/bench_full.json"))
+        assert len(line) < 4096, (name, len(line))
+        rec = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in rec, (name, k)
+        assert rec["config"]["workload"] and "model" not in rec["config"]
+        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rec["roofline"])
+        assert "cands=" not in line
+        if name == "r03_bench_default.json":
+            assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["cores"] >= 1 and rec["cpu_baseline"]["sample"]
+            assert set(rec["secondary"]) >= {"c1", "c2", "c2p", "c4", "c5"}
+            assert all("ms_per_step" in v for v in rec["secondary"].values())
+
+
+def test_emit_prints_one_line_last_on_stdout(tmp_path, capfd):
+    import json
+    from pyro_amd import benchline
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_default.json")))
+    benchline.emit(full)
+    out, err = capfd.readouterr()
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    assert json.loads(lines[-1])["metric"] == full["metric"]
+    assert "bench.py full record: {" in err                      # everything else: stderr (and gpurun_out/bench_full.json)
+
+
+def test_counters_are_tied_to_the_kernel_name():
+    """the digest names the production kernel (the template instantiation pvi_describe reports), and
+    bench.py drops counters whose kernel is not the one the run launched."""
+    import json
+    bench = _bench()
+    assert bench.norm_kernel("void k_sweep64<3, unsigned char, true, true, true>(DevP, double const*)") == \
+        "k_sweep64<3,unsignedchar,true,true,true>"
+    assert bench.norm_kernel("k_sweep64<3,unsignedchar,true,true,true>") == "k_sweep64<3,unsignedchar,true,true,true>"
+    ctr = json.load(open(os.path.join(ROOT, "profiles", "counters.json")))
+    # C5 / C5d: the sparse patch walk and the dense patch walk, not set-up's slowest candidate
+    assert bench.norm_kernel(ctr["c5"]["kernel"]) == "k_sweep64<3,unsignedchar,true,true,true>"
+    assert bench.norm_kernel(ctr["c5d"]["kernel"]) == "k_sweep64<3,unsignedchar,true,true,false>"
+    c = dict(ctr["c5"], kernel_path="path=exact-f64v2 mapping=patch8x8 sparse=1")
+    good = "path=exact-f64v2 kernel=k_sweep64<3,unsignedchar,true,true,true> mapping=patch8x8 off32=1 sparse=1 inbox=0.1 note="
+    kept, err = bench.check_counters(c, good)
+    assert kept and err is None
+    kept, err = bench.check_counters(c, good.replace("true,true,true", "true,false,false"))
+    assert not kept and "kernel:" in err
+    kept, err = bench.check_counters(c, good.replace(" kernel=k_sweep64<3,unsignedchar,true,true,true>", ""))
+    assert not kept and "not reported" in err

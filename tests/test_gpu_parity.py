@@ -1174,6 +1174,73 @@ def test_two_ranks_share_one_gpu(tmp_path, case, world, overlap):
     assert pieces == ([1] * world if not overlap else [2] + [3] * (world - 2) + [2])
 
 
+_BASE2 = r"""
+import contextlib, io, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %r)
+from pyro_amd import parallel
+from pyro_amd.analysis import costfunction
+from pyro_amd.dynamic import vehicle_steering
+from pyro_amd.planning import discretizer, dynamicprogramming
+rank, out = int(sys.argv[1]), sys.argv[2]
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d", rank=rank, world_size=2)
+with contextlib.redirect_stdout(io.StringIO()):
+    s = vehicle_steering.HolonomicMobileRobotwithObstacles()
+    g = discretizer.GridDynamicSystem(s, [41, 41], [3, 3])
+    cf = costfunction.QuadraticCostFunction.from_sys(s)
+    cf.INF = 100.0
+    dp = dynamicprogramming.DynamicProgramming(g, cf, dtype="float64", device=0, comm=parallel.TorchDistComm(dist))
+    dp.save_time_history = False
+    assert dp.sharded and dp.HARD_INF
+    dp.compute_steps(6)
+    J, pi = dp.J.copy(), dp.pi.copy()
+if rank == 0:
+    np.savez(out, J=J, pi=pi)
+dist.destroy_process_group()
+print("BASE2-OK", rank)
+"""
+
+
+@pytest.mark.gpu
+def test_base_class_with_obstacles_over_torch_dist_comm(tmp_path):
+    """the base class (a rejected cell costs exactly INF, dynamicprogramming.py:225-233) over the
+    Python-driven sharded schedule used to run the look-up-table recursion (INF + alpha J) -- HipSlab never received
+    PVI_FLAG_HARD_INF.  Two ranks on GPU 0 (gloo, host-staged halo) on a system with obstacles must give the single-GPU
+    base class bit for bit, which differs from the look-up-table class."""
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import vehicle_steering
+    from pyro_amd.planning import discretizer, dynamicprogramming
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    out = str(tmp_path / "base.npz")
+    code = _BASE2 % (ROOT, port)
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    logs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all("BASE2-OK" in l for l in logs), "\n".join(l[-1500:] for l in logs)
+    r = np.load(out)
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = vehicle_steering.HolonomicMobileRobotwithObstacles()
+        g = discretizer.GridDynamicSystem(s, [41, 41], [3, 3])
+        cf = costfunction.QuadraticCostFunction.from_sys(s)
+        cf.INF = 100.0
+        one = dynamicprogramming.DynamicProgramming(g, cf, dtype="float64")
+        one.save_time_history = False
+        one.compute_steps(6)
+        lut = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, cf, dtype="float64")
+        lut.save_time_history = False
+        lut.compute_steps(6)
+    assert np.array_equal(r["J"], one.J) and np.array_equal(r["pi"], one.pi)
+    assert not np.array_equal(one.J, lut.J)                     # the two recursions really differ on this system
+
+
 # ------------------------------------------------------------------------------- bicubic-spline class
 def _spline_case(g, tag, xd, ud, dt):
     lv = O.make_levels(g["x_lb"], g["x_ub"], xd)

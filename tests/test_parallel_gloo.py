@@ -365,3 +365,59 @@ def test_python_driver_agrees_on_one_halo(tmp_path):
     r = np.load(out)
     assert len(set(r[:, 0])) == 1 and len(set(r[:, 1])) == 1          # one width, one exchange kind on every rank
     assert len(set(r[:, 2])) > 1 and r[0, 0] == r[:, 2].max()         # ... although the local bounds differ
+
+
+# ---- base class over the Python-driven schedule -----------------------------------------------------
+def _hardinf_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from pyro_amd import parallel
+    from pyro_amd.planning import dynamicprogramming
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        cfg = _build("pendulum:21,11:3:float64")
+        seen = {}
+
+        class Recording(OracleSlab):
+            def __init__(self, grid_sys, cost, dtype, rows, halo, device, hard_inf=False):
+                seen["hard_inf"] = hard_inf
+                super().__init__(grid_sys, cost, dtype, rows, halo, device)
+        with contextlib.redirect_stdout(io.StringIO()):
+            dp = dynamicprogramming.DynamicProgramming(cfg["grid_sys"], cfg["cf"], comm=parallel.TorchDistComm(dist, slab_factory=Recording))
+        base_flag = seen["hard_inf"]
+        refused = False
+        try:        # a back end without the keyword cannot run the base-class recursion: refused, not silently LUT semantics
+            with contextlib.redirect_stdout(io.StringIO()):
+                dynamicprogramming.DynamicProgramming(cfg["grid_sys"], cfg["cf"], comm=parallel.TorchDistComm(dist, slab_factory=OracleSlab))
+        except NotImplementedError:
+            refused = True
+        with contextlib.redirect_stdout(io.StringIO()):
+            lut = dynamicprogramming.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"],
+                                                                       comm=parallel.TorchDistComm(dist, slab_factory=Recording))
+        lut_flag = seen["hard_inf"]
+        np.save(out, np.array([bool(dp.HARD_INF), base_flag, refused, lut_flag], dtype=float))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_base_class_flag_reaches_the_python_driven_slabs(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "hi.npy")
+    mp.spawn(_hardinf_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    r = np.load(out)
+    assert r[0] == 1 and r[1] == 1 and r[2] == 1 and r[3] == 0
+
+
+def test_torch_dist_comm_refuses_the_table_tier():
+    """The Python-driven schedule has no table tier: a system without in-kernel dynamics must raise, not run 'fused'."""
+    from pyro_amd import parallel
+
+    class FakeDist:
+        def get_rank(self): return 0
+        def get_world_size(self): return 1
+
+    class DP:
+        grid_sys = _contracting_grid()
+        cf = None
+        dtype, device, HARD_INF = "float64", 0, False
+    with pytest.raises(NotImplementedError):
+        parallel._TorchEngine(DP(), parallel.TorchDistComm(FakeDist()))

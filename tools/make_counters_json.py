@@ -1,6 +1,7 @@
 """Merge gpurun_out/counters_<w>.json (tools_counters.sh) into profiles/counters.json (read by bench.py)."""
 import json, os, subprocess, sys
-ROUND = os.environ.get("PVI_ROUND", "r03")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROUND = os.environ.get("PVI_ROUND", "r04")
 HEAD = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("PVI_HEAD", "?")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(ROOT, "profiles", "counters.json")
@@ -8,10 +9,23 @@ out = json.load(open(dst)) if os.path.exists(dst) else {}
 for w in sys.argv[1:]:
     raw = json.load(open(os.path.join(ROOT, "gpurun_out", "counters_%s.json" % w)))
     src = raw["kernels"]
-    # the production sweep kernel: the k_sweep* with the most vector work (k_sweep_finish, launched as often, folds 64 values;
-    # k_sweep_lean4_probe are set-up's timed candidate tilings)
-    kname, sweep = max(((k, v) for k, v in src.items() if "k_sweep" in k and "finish" not in k and "_probe" not in k),
-                       key=lambda kv: kv[1].get("SQ_INSTS_VALU", 0.0))
+    # The production sweep kernel: the one pvi_describe names (`kernel=` in the kernel path the counter pass logged: the
+    # template instantiation of the handle's last launch).  pvi_create also launches slower candidates of the same family
+    # once or twice each (mappings, dense / sparse walks, tile shapes): "the k_sweep* with the most vector work" picked one
+    # of THOSE for C5 / C5d in round 3.  Without a `kernel=` token: the sweep kernel with the most calls.
+    from bench import norm_kernel
+    want = norm_kernel(dict(t.split("=", 1) for t in raw.get("kernel_path", "").split() if "=" in t).get("kernel"))
+    sweeps = {k: v for k, v in src.items() if "k_sweep" in k and "finish" not in k and "_probe" not in k}
+    named = [(k, v) for k, v in sweeps.items() if want and want != "-" and norm_kernel(k) == want]
+    if want and want != "-" and not named:
+        # (the counter script truncates kernel names at 64 characters)
+        named = [(k, v) for k, v in sweeps.items() if want.startswith(norm_kernel(k)) or norm_kernel(k).startswith(want[:40])]
+    if len(named) == 1:
+        kname, sweep = named[0]
+    else:
+        if want and want != "-":
+            print("make_counters_json: %s: %d kernels match %s -- taking the one with the most calls" % (w, len(named), want))
+        kname, sweep = max((named or list(sweeps.items())), key=lambda kv: kv[1].get("calls", 0))
     cal = next((v for k, v in src.items() if "to_f64" in k), {})
     out[w] = {
         "hbm_bytes_per_launch": (2.0 * sweep["FETCH_SIZE"] + sweep["WRITE_SIZE"]) * 1024.0,
@@ -23,7 +37,7 @@ for w in sys.argv[1:]:
         "calibration_k_to_f64": {k: cal[k] for k in ("FETCH_SIZE", "WRITE_SIZE") if k in cal},
         "wave_cycles_quad": sweep.get("SQ_WAVE_CYCLES"), "wait_any_quad": sweep.get("SQ_WAIT_ANY"),
         "wait_inst_any_quad": sweep.get("SQ_WAIT_INST_ANY"), "active_inst_any_quad": sweep.get("SQ_ACTIVE_INST_ANY"),
-        "kernel": kname, "kernel_path": raw.get("kernel_path", ""),
+        "kernel": kname, "kernel_calls": sweep.get("calls"), "kernel_path": raw.get("kernel_path", ""),
         "source": "profiles/%s_counters_%s.json (rocprofv3 --pmc passes of tools/tools_counters.sh), kernel %s as of commit %s"
                   % (ROUND, w, kname.split("<")[0], HEAD),
     }

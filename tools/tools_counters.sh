@@ -31,10 +31,10 @@ for i in (1, 2, 3, 4):
     geom = lambda r: (r.get('Grid_Size'), r.get('Workgroup_Size'), r.get('LDS_Block_Size'))
     last = {}
     for r in rows:
-        last[r['Kernel_Name'].split('(')[0][:64]] = geom(r)
+        last[r['Kernel_Name'].split('(')[0][:96]] = geom(r)
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
-        k = r['Kernel_Name'].split('(')[0][:64]
+        k = r['Kernel_Name'].split('(')[0][:96]
         if geom(r) == last[k]:
             acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
     for k, d in acc.items():
