@@ -2666,6 +2666,8 @@ static const char* const OVERRIDE_KEYS[] = {
     "SPLINE_CHUNK",            // spline mode: rows per chunk of the substitution passes
     "WIN",         // 4-D lean sweep window layout: 0 single floats + ds_read2_b32, 1 position-paired + ds_read_b64
     "TABLES",      // lean sweep per-node coefficient tables: 0 per-node arrays, 1 factorised where the dynamics allow
+    "PERSIST",     // 4-D lean sweep: 1 persistent workgroups over strided tile lists, 0 one workgroup per tile
+    "PERSIST_WGS", // ... at most this many of them per CU
 };
 static std::vector<std::pair<std::string, std::string>> g_overrides;
 static std::mutex g_override_mu;
@@ -2724,6 +2726,10 @@ struct pvi_problem {
     int lean4_block = 512, lean4_rsk = 0, lean4_bands = 1, lean4_tables = 0;
     void* lean4_tiles = nullptr;  // [grid] Lean4Tile, launch order
     int lean4_stage = 2;          // actions whose gathers are in flight together (sweep_lean4.inc)
+    int lean4_persist = 0;        // 1: persistent workgroups (k_sweep_lean4p), each sweeping a strided list of tiles
+    unsigned lean4_pgrid = 0;     // ... and how many of them are launched (resident workgroups, a multiple of 8)
+    void* lean4_dblocks = nullptr;     // DevP + Lean4P in device memory for the persistent kernel
+    bool lean4_dblocks_stale = true;
     int lean4_ptab_inv = 0;       // bit 0 / 1: the (position node, action) table does not depend on axis 0 / 1
     long long lean4_ptab_groups = 0;
     char lean4_cands[960] = "";  // the timed tile shapes of set-up: rows x columns : ms
@@ -2943,8 +2949,42 @@ static int launch_lean4_t(pvi_problem* h, const float* Jin, float* Jout, float a
         hipLaunchKernelGGL(kfn, dim3(h->lean4_grid), dim3(h->lean4_block), h->lean4_lds, st, h->P, L, Jin, Jout, pi, alpha, \
                            sc, (const float*)L.ptab, (const Lean4Tile*)h->lean4_tiles);                                \
     }
+    // persistent form: as many workgroups as are resident (occupancy of THIS kernel with this block size and window), a
+    // multiple of 8 so that workgroup b and the tiles b + k grid it sweeps stay on XCD b % 8
+#define L4P(KFN)                                                                                                       \
+    {                                                                                                                  \
+        auto kfn = KFN;                                                                                                \
+        if (h->lean4_lds > 48 * 1024)                                                                                  \
+            HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PVI_LDS_MAX));    \
+        if (!h->lean4_pgrid) {                                                                                         \
+            int per_cu = 0, ncu = 0;                                                                                   \
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfn, h->lean4_block, h->lean4_lds)); \
+            HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device));                     \
+            if (ovr("PERSIST_WGS") && atoi(ovr("PERSIST_WGS")) > 0) per_cu = std::min(per_cu, atoi(ovr("PERSIST_WGS"))); \
+            unsigned g = (unsigned)std::max(1, per_cu) * (unsigned)std::max(8, ncu);                                   \
+            g = std::min(g & ~7u, (h->lean4_grid + 7u) & ~7u);                                                         \
+            h->lean4_pgrid = std::max(8u, g);                                                                          \
+        }                                                                                                              \
+        if (!h->lean4_dblocks) {  /* the two parameter blocks in device memory (read through the constant cache) */  \
+            HIPCHK(hipMalloc(&h->lean4_dblocks, sizeof(DevP) + sizeof(Lean4P)));                                       \
+            h->dev_allocs.push_back(h->lean4_dblocks);                                                                 \
+            h->lean4_dblocks_stale = true;                                                                             \
+        }                                                                                                              \
+        if (h->lean4_dblocks_stale) {                                                                                  \
+            HIPCHK(hipMemcpyAsync(h->lean4_dblocks, &h->P, sizeof(DevP), hipMemcpyHostToDevice, st));                  \
+            HIPCHK(hipMemcpyAsync((char*)h->lean4_dblocks + sizeof(DevP), &L, sizeof(Lean4P), hipMemcpyHostToDevice, st)); \
+            HIPCHK(hipStreamSynchronize(st));  /* (the sources are host structures that change with the next candidate) */ \
+            h->lean4_dblocks_stale = false;                                                                            \
+        }                                                                                                              \
+        hipLaunchKernelGGL(kfn, dim3(h->lean4_pgrid), dim3(h->lean4_block), h->lean4_lds, st,                          \
+                           (const DevP*)h->lean4_dblocks, (const Lean4P*)((char*)h->lean4_dblocks + sizeof(DevP)), Jin, Jout, pi, \
+                           alpha, sc, (const float*)L.ptab, (const Lean4Tile*)h->lean4_tiles, h->lean4_grid);          \
+    }
 #define L4(DYN)                                   \
-    if (probe)                                    \
+    if (h->lean4_persist) {                       \
+        if (!probe) set_kname(h, "k_sweep_lean4p", (int)DYN, tname<PI_T>()); \
+        L4P((k_sweep_lean4p<DYN, PI_T>))          \
+    } else if (probe)                             \
         L4K((k_sweep_lean4_probe<DYN, PI_T>))     \
     else {                                        \
         set_kname(h, "k_sweep_lean4", (int)DYN, tname<PI_T>()); \
@@ -2958,6 +2998,7 @@ static int launch_lean4_t(pvi_problem* h, const float* Jin, float* Jout, float a
     }
 #undef L4
 #undef L4K
+#undef L4P
     hipLaunchKernelGGL(k_sweep_finish, 1, STAT_SHARDS, 0, st, sc);
     HIPCHK(hipGetLastError());
     return PVI_OK;
@@ -3099,6 +3140,8 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
     h->lean4_rsk = 0;
     h->lean4_lds = lds;
     h->lean4_block = threads;
+    h->lean4_pgrid = 0;
+    h->lean4_dblocks_stale = true;
     hipLaunchKernelGGL(k_lean4_off, grid_for(h->lean4_ptab_groups * 4), 256, 0, h->stream, L, h->lean4_ptab_groups);
     // bands of the tile list: three axis-0 rows x (chunk of axis 1 + position reach) x band rows x V1 floats within ~1.5 MB of L2
     const int n1c = (P.dim[1] + 7) / 8 + 3;
@@ -3168,6 +3211,7 @@ static int lean4_setup(pvi_problem* h) {
     int rc;
     L.owned = h->owned;
     h->lean4_stage = 2;
+    h->lean4_persist = ovr_is("PERSIST", 1) ? 1 : 0;
     L.ngroups = (P.A + 3) / 4;
     float2* tsp_node = nullptr;
     float* gx_node = nullptr;
@@ -4177,9 +4221,9 @@ static int describe_impl(pvi_handle h, char* buf, int32_t n) {
         // win=1: position-paired window + ds_read_b64 (sweep_lean4.inc); tables: bit d set = the displacement table does
         // not span axis d; rowpieces / bands: the step-aligned row pieces of axis 2 and their grouping in the launch order
         snprintf(buf, (size_t)n, "path=lean tile=%dx%d grid=%ux1x1 block=%d pw1=%d lds_bytes=%zu lsplit=0 tb_tile=1 dma16=0 npt=1 "
-                 "reach=0 opmag=0 sparse=0 win=1 tables=%d ptab=%d gx=%s stage=%d tiles_per_plane=%d bands=%d cands=%s note=%s", h->L4.TV0, h->L4.TV1,
+                 "reach=0 opmag=0 sparse=0 win=1 tables=%d ptab=%d gx=%s stage=%d persist=%d pgrid=%u tiles_per_plane=%d bands=%d cands=%s note=%s", h->L4.TV0, h->L4.TV1,
                  h->lean4_grid, h->lean4_block, h->L4.RS, h->lean4_lds, h->lean4_tables, h->lean4_ptab_inv, h->L4.gx ? "node" : "axes", h->lean4_stage,
-                 h->L4.ntr, h->lean4_bands, h->lean4_cands[0] ? h->lean4_cands : "-", h->lean_why);
+                 h->lean4_persist, h->lean4_pgrid, h->L4.ntr, h->lean4_bands, h->lean4_cands[0] ? h->lean4_cands : "-", h->lean_why);
         return PVI_OK;
     }
     snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d npt=%d reach=%d opmag=%d sparse=%d win=0 tables=0 note=%s",
