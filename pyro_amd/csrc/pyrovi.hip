@@ -3241,8 +3241,12 @@ static int lean4_setup(pvi_problem* h) {
             }
             if ((rc = dev_upload(h, t.data(), t.size(), &L.gt[d]))) return rc;
         }
-    } else if ((rc = dev_alloc(h, (size_t)h->owned, &gx_node))) {
-        return rc;
+    } else {
+        if ((rc = dev_alloc(h, (size_t)h->owned, &gx_node))) return rc;
+        // (the sweep loads both forms of g_x without a branch and keeps the one that applies: one-word zero tables to read)
+        const double zero = 0.0;
+        for (int d = 0; d < 4; ++d)
+            if ((rc = dev_upload(h, &zero, 1, &L.gt[d]))) return rc;
     }
     L.gx = gx_node;
     HIPCHK(hipMemsetAsync(L.summary, 0, 8 * sizeof(int), h->stream));

@@ -413,9 +413,9 @@ def test_f32_kernel_variants_agree(name, variants):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         h = native_problem(p, dtype="float32")
-        desc = h.describe()
         h.terminal_cost()
         h.sweep(nsw, alpha, -1.0)
+        desc = h.describe()                              # (after the sweeps: `kernel=` names the kernel of the last launch)
         outs[tag] = (h.get_J(), h.get_pi(), desc)
         h.close()
     for tag, (J, pi, desc) in outs.items():
