@@ -2664,7 +2664,8 @@ static const char* const OVERRIDE_KEYS[] = {
     "SPARSE", "PATCH",         // 4-D float64 / exact-float32 sweeps: walk over validity masks, 8x8 patch mapping
     "NO_PACK",     // table tier: sweep the raw tables instead of the packed records
     "SPLINE_CHUNK",            // spline mode: rows per chunk of the substitution passes
-    "WIN",         // 4-D lean sweep window layout: 0 single floats + ds_read2_b32, 1 position-paired + ds_read_b64
+    "WIN",         // 4-D lean sweep window layout: 0 single floats + ds_read2_b32, 1 position-paired + ds_read_b64, 2 position quads + ds_read_b128
+    "RSMOD",       // quad window: residue of the row pitch modulo 16 slots
     "TABLES",      // lean sweep per-node coefficient tables: 0 per-node arrays, 1 factorised where the dynamics allow
     "PERSIST",     // 4-D lean sweep: 1 persistent workgroups over strided tile lists, 0 one workgroup per tile
     "PERSIST_WGS", // ... at most this many of them per CU
@@ -2726,6 +2727,7 @@ struct pvi_problem {
     int lean4_block = 512, lean4_rsk = 0, lean4_bands = 1, lean4_tables = 0;
     void* lean4_tiles = nullptr;  // [grid] Lean4Tile, launch order
     int lean4_stage = 2;          // actions whose gathers are in flight together (sweep_lean4.inc)
+    int lean4_quad = 0;           // 1: quad window (k_sweep_lean4q): tiles cut where either position corner steps
     int lean4_persist = 0;        // 1: persistent workgroups (k_sweep_lean4p), each sweeping a strided list of tiles
     unsigned lean4_pgrid = 0;     // ... and how many of them are launched (resident workgroups, a multiple of 8)
     void* lean4_dblocks = nullptr;     // DevP + Lean4P in device memory for the persistent kernel
@@ -2981,7 +2983,10 @@ static int launch_lean4_t(pvi_problem* h, const float* Jin, float* Jout, float a
                            alpha, sc, (const float*)L.ptab, (const Lean4Tile*)h->lean4_tiles, h->lean4_grid);          \
     }
 #define L4(DYN)                                   \
-    if (h->lean4_persist) {                       \
+    if (h->lean4_quad) { /* (opt-in experiment family: its timed candidates launch the kernel itself) */ \
+        if (!probe) set_kname(h, "k_sweep_lean4q", (int)DYN, tname<PI_T>()); \
+        L4K((k_sweep_lean4q<DYN, PI_T>))          \
+    } else if (h->lean4_persist) {                \
         if (!probe) set_kname(h, "k_sweep_lean4p", (int)DYN, tname<PI_T>()); \
         L4P((k_sweep_lean4p<DYN, PI_T>))          \
     } else if (probe)                             \
@@ -3067,27 +3072,65 @@ static void lean4_schedule(int R, int N1, int ntr, int nbands, std::vector<unsig
 
 struct Lean4Cand {
     int cap, w, wmax;  // rows cap, workgroup threads, widest tile
+    int quad = 0;      // 1: quad window (wmax = columns cap of the step-aligned column pieces)
 };
 
-// one candidate tiling: tile lists, window boxes, row pitch, schedule.  rc 0 = usable, 1 = does not fit, < 0 error
-static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int threads, int wmax, size_t lds_budget, int* narrower = nullptr) {
+// one candidate tiling: tile lists, window boxes, row pitch, schedule.  rc 0 = usable, 1 = does not fit, < 0 error.
+// quad: the quad-window kernel -- tiles are row piece x COLUMN piece (both cut where the position corner of their axis steps,
+// the column pieces from pt1 per index of axis 1, at most `wmax` columns), the tile list is per position node.
+static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int threads, int wmax, size_t lds_budget, int* narrower = nullptr,
+                     bool quad = false, const std::vector<int2>* pt1 = nullptr) {
     const DevP& P = h->P;
     Lean4P& L = h->L4;
     const int rows = P.row_end - P.row_begin;
     if (threads > 512 || threads < 64 || (threads & 63)) return 1;
-    std::vector<std::vector<int4>> per((size_t)rows);
+    std::vector<std::vector<int4>> per;
     int ntr = 1, tv0 = 1, tv1 = 1;
-    for (int r = 0; r < rows; ++r) {
-        lean4_row_tiles(pt0, P.row_begin + r, P.dim[2], P.dim[3], cap, threads, wmax, per[(size_t)r]);
-        ntr = std::max(ntr, (int)per[(size_t)r].size());
-        for (auto& t : per[(size_t)r]) {
+    if (!quad) {
+        per.resize((size_t)rows);
+        for (int r = 0; r < rows; ++r) {
+            lean4_row_tiles(pt0, P.row_begin + r, P.dim[2], P.dim[3], cap, threads, wmax, per[(size_t)r]);
+            ntr = std::max(ntr, (int)per[(size_t)r].size());
+        }
+    } else {
+        if (!pt1) return 1;
+        // row pieces per owned row of axis 0, column pieces per index of axis 1; a tile = (row piece, column piece)
+        std::vector<std::vector<int2>> rp((size_t)rows), cp((size_t)P.dim[1]);
+        int nr = 1, nc = 1;
+        for (int r = 0; r < rows; ++r) {
+            lean4_row_pieces(pt0, P.row_begin + r, P.dim[2], cap, rp[(size_t)r]);
+            nr = std::max(nr, (int)rp[(size_t)r].size());
+        }
+        for (int i1 = 0; i1 < P.dim[1]; ++i1) {
+            lean4_row_pieces(*pt1, i1, P.dim[3], wmax, cp[(size_t)i1]);
+            nc = std::max(nc, (int)cp[(size_t)i1].size());
+        }
+        ntr = nr * nc;
+        per.resize((size_t)rows * P.dim[1]);
+        for (int r = 0; r < rows; ++r)
+            for (int i1 = 0; i1 < P.dim[1]; ++i1) {
+                auto& out = per[(size_t)r * P.dim[1] + i1];
+                out.assign((size_t)ntr, make_int4(0, 0, 0, 0));
+                for (size_t a = 0; a < rp[(size_t)r].size(); ++a)
+                    for (size_t b = 0; b < cp[(size_t)i1].size(); ++b) {
+                        const int2 rr = rp[(size_t)r][a], cc = cp[(size_t)i1][b];
+                        if (rr.y * cc.y > threads) return 1;  // (the caps of this candidate do not fit the workgroup)
+                        out[a * (size_t)nc + b] = make_int4(rr.x, rr.y, cc.x, cc.y);
+                    }
+            }
+    }
+    for (auto& v : per)
+        for (auto& t : v) {
             tv0 = std::max(tv0, t.y);
             tv1 = std::max(tv1, t.w);
         }
-    }
-    std::vector<int4> tlist((size_t)rows * ntr, make_int4(0, 0, 0, 0));
-    for (int r = 0; r < rows; ++r)
-        for (size_t k = 0; k < per[(size_t)r].size(); ++k) tlist[(size_t)r * ntr + k] = per[(size_t)r][k];
+    const size_t nlists = per.size();
+    std::vector<int4> tlist(nlists * ntr, make_int4(0, 0, 0, 0));
+    for (size_t r = 0; r < nlists; ++r)
+        for (size_t k = 0; k < per[r].size(); ++k) tlist[r * ntr + k] = per[r][k];
+    L.tl_by = quad ? 1 : 0;
+    L.quad = quad ? 1 : 0;
+    h->lean4_quad = quad ? 1 : 0;
     L.V0 = P.dim[2];
     L.V1 = P.dim[3];
     L.TV0 = tv0;
@@ -3121,15 +3164,20 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
     // Row pitch in slots: the fill writes whole groups of four columns.  (Tiles differ in width, so no pitch is congruent to
     // all of them; tools/ldsgather.hip: a row wrap or a displacement step inside a wave costs a ds_read_b64 4.3 -> 5.0 clk at
     // worst, whatever the pitch -- the 4.4 clk of the conflict-free read is what counts.)
-    const int rs = std::max(4, (summary[1] + 3) & ~3);
-    const size_t lds = (size_t)std::max(summary[0], 1) * (size_t)rs * 8 + 256;
-    if (narrower) {  // the widest tile whose window lets as many workgroups onto a CU as the register budget does (24 waves)
-        *narrower = 0;
-        const size_t room = (size_t)160 * 1024 / (size_t)std::max(1, 1536 / threads) - 512;
-        if (lds > room && summary[0] > 0) {
-            const int rs_fit = (int)((room - 256) / 8 / (size_t)summary[0]) & ~3, w_fit = tv1 - (rs - rs_fit);
-            if (w_fit >= 12 && w_fit < tv1) *narrower = w_fit;
+    int rs = std::max(4, (summary[1] + 3) & ~3);
+    size_t lds = (size_t)std::max(summary[0], 1) * (size_t)rs * 8 + 256;
+    if (quad) {
+        // one plane of 16-byte slots; every non-empty tile must see ONE corner pair on either position axis
+        if (summary[4] > 1 || summary[2] > 2) {
+            snprintf(h->lean_why, sizeof(h->lean_why), "quad window: a tile spans %d pair planes x %d position rows", summary[4], summary[2]);
+            return 1;
         }
+        // Pitch congruent to the widest tile modulo 16 slots: a 16-lane group (one LDS pass of a ds_read_b128) that wraps from
+        // one tile row to the next then keeps walking consecutive bank groups.  RSMOD overrides the residue (experiments).
+        const int m = ovr("RSMOD") ? (atoi(ovr("RSMOD")) & 15) : (tv1 & 15);
+        rs = std::max(1, summary[1]);
+        while ((rs & 15) != m) ++rs;
+        lds = (size_t)std::max(summary[5], 1) * (size_t)rs * 16 + 256;
     }
     if (lds > lds_budget) {
         snprintf(h->lean_why, sizeof(h->lean_why), "tiles of %d threads, <= %d rows need %zu LDS bytes (%d window rows x %d pairs; budget %zu)",
@@ -3206,6 +3254,7 @@ static int lean4_setup(pvi_problem* h) {
     h->lean4_ok = false;
     if (!h->fast_ok || P.dof != 2 || ovr("NO_LEAN") || ovr_is("WIN", 0) || h->stored >= 0x7fffffffLL) return PVI_OK;
     if (!(h->own_J || (h->d.flags & PVI_FLAG_EXT_J_SLACK))) return PVI_OK;  // the 16-byte window loads may run 12 bytes past a row
+    if (P.strd[0] * 16 >= (1LL << 31)) return PVI_OK;  // the window fill addresses planes by 32-bit byte offsets from the window origin
     const int rows = P.row_end - P.row_begin;
     const long long npos = (long long)rows * P.dim[1];
     int rc;
@@ -3417,12 +3466,44 @@ static int lean4_setup(pvi_problem* h) {
             if (!cands.empty()) break;
         }
     }
+    // ---- quad-window family (round 4): tiles of one (p0, p1) corner pair each.  Opt-in (WIN=2): measured on C3 / C4 it does
+    // not beat the pair window (3.4 against 3.14 ms, 19.5 against 19.7 ms), so a default create does not spend
+    // set-up time on its candidates.
+    const bool want_quad = ovr_is("WIN", 2);
+    std::vector<int2> hpt1;
+    if (want_quad) {
+        hpt1.resize((size_t)P.dim[1] * P.dim[3]);
+        HIPCHK(hipMemcpy(hpt1.data(), pt1, hpt1.size() * sizeof(int2), hipMemcpyDeviceToHost));
+        if (ovr_is("WIN", 2)) cands.clear();
+        if (ovr("TV0") && ovr("TV1")) {
+            const int c0 = atoi(ovr("TV0")), c1 = atoi(ovr("TV1"));
+            if (ovr_is("WIN", 2)) cands.push_back({c0, std::min(512, ((c0 * c1 + 63) / 64) * 64), c1, 1});
+        } else {
+            // the longest row piece / column piece of a middle position node: the natural tile; then a few caps below it
+            std::vector<int2> pc;
+            lean4_row_pieces(hpt0, P.row_begin + rows / 2, P.dim[2], P.dim[2], pc);
+            int lr = 1, lc = 1;
+            for (auto& q : pc) lr = std::max(lr, q.y);
+            lean4_row_pieces(hpt1, P.dim[1] / 2, P.dim[3], P.dim[3], pc);
+            for (auto& q : pc) lc = std::max(lc, q.y);
+            for (int threads : {512, 448, 384, 320, 256, 192, 128, 64}) {
+                for (int cc : {lc, (lc + 1) / 2}) {
+                    const int cap_c = std::max(1, std::min(cc, threads));
+                    const int cap_r = std::max(1, std::min(lr, threads / cap_c));
+                    if (cap_r * cap_c <= threads - 64 && threads > 64) continue;  // (a smaller workgroup holds these tiles)
+                    bool dup = false;
+                    for (auto& c : cands) dup = dup || (c.quad && c.cap == cap_r && c.wmax == cap_c && c.w == threads);
+                    if (!dup && cands.size() < 40) cands.push_back({cap_r, threads, cap_c, 1});
+                }
+            }
+        }
+    }
     const bool tune = !ovr_is("TUNE", 0) && cands.size() > 1;
     float best_ms = 1e30f;
     int best = -1;
     for (size_t ci = 0; ci < cands.size(); ++ci) {
         int narrower = 0;
-        rc = lean4_try(h, hpt0, cands[ci].cap, cands[ci].w, cands[ci].wmax, budget, &narrower);
+        rc = lean4_try(h, hpt0, cands[ci].cap, cands[ci].w, cands[ci].wmax, budget, &narrower, cands[ci].quad != 0, &hpt1);
         if (rc < 0) return rc;
         if (rc) continue;
         if (!tune) {
@@ -3463,13 +3544,16 @@ static int lean4_setup(pvi_problem* h) {
         }
         {
             const size_t at = strlen(h->lean4_cands);
-            if (cands[ci].wmax < V1)
+            if (cands[ci].quad)
+                snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, "%sq%dx%d/%d:%.2f", at ? "," : "", cands[ci].cap, cands[ci].wmax, cands[ci].w, ms / 2.f);
+            else if (cands[ci].wmax < V1)
                 snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, ",%d/%d/%d:%.2f", cands[ci].cap, cands[ci].w, cands[ci].wmax, ms / 2.f);
             else
                 snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, "%s%d/%d:%.2f", at ? "," : "", cands[ci].cap, cands[ci].w, ms / 2.f);
         }
         // (a narrower twin of a shape that is in the running: one more workgroup per CU may pay for the extra window halo)
-        if (narrower && cands[ci].wmax == V1 && ms < 1.1f * best_ms && cands.size() < 48) cands.push_back({cands[ci].cap, cands[ci].w, narrower});
+        if (narrower && !cands[ci].quad && cands[ci].wmax == V1 && ms < 1.1f * best_ms && cands.size() < 48)
+            cands.push_back({cands[ci].cap, cands[ci].w, narrower, 0});
         if (ms < 0.98f * best_ms) {  // a later candidate must win by 2 %: within the timing noise the choice stays put, so the
             best_ms = ms;            // shape (and with it the committed counter passes) is the same from run to run
             best = (int)ci;
@@ -3477,7 +3561,9 @@ static int lean4_setup(pvi_problem* h) {
     }
     if (best < 0) return give_up(h->lean_why[0] ? h->lean_why : "no tile shape fits the LDS budget");
     if (tune) {
-        if ((rc = lean4_try(h, hpt0, cands[(size_t)best].cap, cands[(size_t)best].w, cands[(size_t)best].wmax, budget))) return rc < 0 ? rc : give_up("tile shape lost");
+        if ((rc = lean4_try(h, hpt0, cands[(size_t)best].cap, cands[(size_t)best].w, cands[(size_t)best].wmax, budget, nullptr,
+                            cands[(size_t)best].quad != 0, &hpt1)))
+            return rc < 0 ? rc : give_up("tile shape lost");
         // the timed sweeps wrote into the second J buffer, pi and the control block
         HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream));
         HIPCHK(hipMemsetAsync(h->pi, 0, (size_t)h->owned * h->pi_size, h->stream));
@@ -4225,8 +4311,8 @@ static int describe_impl(pvi_handle h, char* buf, int32_t n) {
         // win=1: position-paired window + ds_read_b64 (sweep_lean4.inc); tables: bit d set = the displacement table does
         // not span axis d; rowpieces / bands: the step-aligned row pieces of axis 2 and their grouping in the launch order
         snprintf(buf, (size_t)n, "path=lean tile=%dx%d grid=%ux1x1 block=%d pw1=%d lds_bytes=%zu lsplit=0 tb_tile=1 dma16=0 npt=1 "
-                 "reach=0 opmag=0 sparse=0 win=1 tables=%d ptab=%d gx=%s stage=%d persist=%d pgrid=%u tiles_per_plane=%d bands=%d cands=%s note=%s", h->L4.TV0, h->L4.TV1,
-                 h->lean4_grid, h->lean4_block, h->L4.RS, h->lean4_lds, h->lean4_tables, h->lean4_ptab_inv, h->L4.gx ? "node" : "axes", h->lean4_stage,
+                 "reach=0 opmag=0 sparse=0 win=%d tables=%d ptab=%d gx=%s stage=%d persist=%d pgrid=%u tiles_per_plane=%d bands=%d cands=%s note=%s", h->L4.TV0, h->L4.TV1,
+                 h->lean4_grid, h->lean4_block, h->L4.RS, h->lean4_lds, h->lean4_quad ? 2 : 1, h->lean4_tables, h->lean4_ptab_inv, h->L4.gx ? "node" : "axes", h->lean4_stage,
                  h->lean4_persist, h->lean4_pgrid, h->L4.ntr, h->lean4_bands, h->lean4_cands[0] ? h->lean4_cands : "-", h->lean_why);
         return PVI_OK;
     }

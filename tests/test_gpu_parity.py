@@ -201,8 +201,16 @@ def test_cartpole_21p4_f32_golden():
         assert n == 20
         J, pi = h.get_J(), h.get_pi()
         assert relerr(J, g["J"].astype(np.float64)) <= tol
-        bad = pi != g["pi"]
-        assert bad.mean() < (1e-4 if dtype == "float64" else 2e-2)
+        # the policy by its float64 Q-regret on the GPU's own previous cost-to-go (no mismatch allowance --
+        # an action is right when no other is better by more than the tolerance, whatever ties rounding flips)
+        from oracle import c_oracle as CO
+        nodes = np.arange(pi.size, dtype=np.int64)
+        q, qmin = CO.CProblem(p).q_at(h.get_J(prev=True), nodes, pi.astype(np.int64))
+        ok = np.isfinite(q) & np.isfinite(qmin)
+        assert np.array_equal(np.isfinite(q), np.isfinite(qmin))
+        assert (q[ok] - qmin[ok]).max() <= (1e-9 if dtype == "float64" else 1e-5) * np.abs(g["J"]).max(), (dtype, (q[ok] - qmin[ok]).max())
+        if dtype == "float64":
+            assert (pi != g["pi"]).mean() < 1e-4          # (ties at the last bit of LAPACK's inverse in the reference's own run)
         h.close()
 
 
@@ -405,10 +413,13 @@ def test_f32_kernel_variants_agree(name, variants):
                      ("lean_persist", {"PVI_WIN": "1", "PVI_PERSIST": "1"}), ("lean_persist1", {"PVI_WIN": "1", "PVI_PERSIST": "1", "PVI_PERSIST_WGS": "1"}),
                      ("lean_persist_shape", {"PVI_WIN": "1", "PVI_PERSIST": "1", "PVI_TV0": "3", "PVI_TV1": "7"}),
                      ("lean_nopersist", {"PVI_WIN": "1", "PVI_PERSIST": "0"}),
+                     # round 4: quad window (tiles of one position-corner quad, ds_read_b128), two tile shapes, another pitch residue
+                     ("lean_quad", {"PVI_WIN": "2"}), ("lean_quad_shape", {"PVI_WIN": "2", "PVI_TV0": "3", "PVI_TV1": "4"}),
+                     ("lean_quad_rsmod", {"PVI_WIN": "2", "PVI_RSMOD": "1", "PVI_NO_XCD": "1"}),
                      ("fast", {"PVI_NO_LEAN": "1"}),
                      ("exact32", {"PVI_NO_FAST": "1"})]:
         for k in ("PVI_LSPLIT", "PVI_NO_LEAN", "PVI_NO_FAST", "PVI_NPT", "PVI_WIN", "PVI_TABLES", "PVI_NO_XCD", "PVI_TV0", "PVI_TV1",
-                  "PVI_PERSIST", "PVI_PERSIST_WGS"):
+                  "PVI_PERSIST", "PVI_PERSIST_WGS", "PVI_RSMOD"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -447,6 +458,9 @@ def test_f32_kernel_variants_agree(name, variants):
             assert np.array_equal(outs[tag][0], outs["lean_win1"][0]) and np.array_equal(outs[tag][1], outs["lean_win1"][1]), (tag, outs[tag][2])
         assert "tables=0" in outs["lean_tab0"][2] and "gx=node" in outs["lean_tab0"][2], outs["lean_tab0"][2]
         assert "tile=3x" in outs["lean_shape"][2], outs["lean_shape"][2]       # (columns are evened out over the tiles)
+        for tag in ("lean_quad", "lean_quad_shape", "lean_quad_rsmod"):     # the same arithmetic per cell: the same bits
+            assert path_of(outs[tag][2]) == "path=lean" and "win=2" in outs[tag][2] and "kernel=k_sweep_lean4q<" in outs[tag][2], (tag, outs[tag][2])
+            assert np.array_equal(outs[tag][0], outs["lean_win1"][0]) and np.array_equal(outs[tag][1], outs["lean_win1"][1]), (tag, outs[tag][2])
         assert "persist=1" in outs["lean_persist"][2] and "kernel=k_sweep_lean4p<" in outs["lean_persist"][2], outs["lean_persist"][2]
         assert "persist=0" in outs["lean_nopersist"][2] and "kernel=k_sweep_lean4<" in outs["lean_nopersist"][2], outs["lean_nopersist"][2]
         # its split displacement is the more accurate float32 form: at least as close to the float64 oracle as the others
@@ -566,15 +580,30 @@ def test_full_size_c2_against_c_oracle():
     J = c.terminal_cost()
     for _ in range(3):
         J, pi = c.sweep(J)
-    for dtype, tol in (("float32", REL_F32), ("float64", 1e-12)):
-        h = native_problem(p, dtype=dtype)
+    from pyro_amd import _native
+    nodes = np.arange(0, pi.size, 7, dtype=np.int64)
+    outs = {}
+    # look-up-table class and base class (PVI_FLAG_HARD_INF: a rejected cell costs exactly INF, dynamicprogramming.py:225-233)
+    for dtype, tol, flags in (("float32", REL_F32, 0), ("float64", 1e-12, 0), ("float32", REL_F32, _native.FLAG_HARD_INF),
+                              ("float64", 1e-12, _native.FLAG_HARD_INF)):
+        h = native_problem(p, dtype=dtype, flags=flags)
         h.terminal_cost()
         stats, n = h.sweep(3, 1.0, -1.0)
         Jg, pig = h.get_J(), h.get_pi()
         assert relerr(Jg, J) <= tol
-        assert (pig != pi).mean() < (1e-9 if dtype == "float64" else 5e-3)
+        if dtype == "float64":
+            assert np.array_equal(pig, pi)
+        else:   # float32: the float64 Q-regret of the GPU's action on the GPU's own previous J (no mismatch allowance)
+            q, qmin = c.q_at(h.get_J(prev=True), nodes, pig[nodes].astype(np.int64))
+            assert (q - qmin).max() <= 1e-5 * np.abs(J).max(), (q - qmin).max()
         assert abs(stats[-1, 0] - J.max()) <= 1e-5 * J.max()
+        outs[(dtype, flags)] = (Jg, pig)
         h.close()
+    # the pendulum's box IS its grid and every input is valid: a rejected cell lands outside the grid, where the interpolant
+    # fills 0 -- the two classes must agree bit for bit
+    for dtype in ("float32", "float64"):
+        a, b = outs[(dtype, 0)], outs[(dtype, _native.FLAG_HARD_INF)]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), dtype
 
 
 def test_full_size_north_star_grid_against_c_oracle():
