@@ -25,6 +25,7 @@
 #include <limits>
 #include <new>
 #include <algorithm>
+#include <map>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -3052,13 +3053,13 @@ static void lean4_row_tiles(const std::vector<int2>& pt0, int i0, int V0, int V1
 // XCD x sweeps ITS chunk of axis 1 for every owned row of axis 0 in turn (bands of the row's tile list outermost, so that
 // the planes of three consecutive axis-0 rows over the chunk fit its L2): the axis-0 planes a tile gathers from were
 // fetched for the previous row a moment ago.  Lists are interleaved into physical order and padded to equal length.
-static void lean4_schedule(int R, int N1, int ntr, int nbands, std::vector<unsigned>& out) {
+static void lean4_schedule(int R, int N1, int ntr, int nbands, std::vector<unsigned>& out, int r0 = 0) {
     std::vector<std::vector<unsigned>> lists(8);
     for (int x = 0; x < 8; ++x) {
         const int c0 = (int)((long long)N1 * x / 8), c1 = (int)((long long)N1 * (x + 1) / 8);
         for (int b = 0; b < nbands; ++b) {
             const int k0 = (int)((long long)ntr * b / nbands), k1 = (int)((long long)ntr * (b + 1) / nbands);
-            for (int r = 0; r < R; ++r)
+            for (int r = r0; r < r0 + R; ++r)  // (r0, R: the rows of a timed candidate; the whole slab otherwise)
                 for (int i1 = c0; i1 < c1; ++i1)
                     for (int k = k0; k < k1; ++k) lists[x].push_back((unsigned)((long long)(r * N1 + i1) * ntr + k));
         }
@@ -3074,12 +3075,17 @@ struct Lean4Cand {
     int cap, w, wmax;  // rows cap, workgroup threads, widest tile
     int quad = 0;      // 1: quad window (wmax = columns cap of the step-aligned column pieces)
 };
+// the tiling a create of this process chose for a problem shape (device, dynamics, dims, actions, rows, dt, velocity box):
+// a second handle of the same shape -- the float32 / float64 pair of a convergence check, the pieces of a shard, a bench
+// that builds its workload twice -- takes it without timing anything (pvi_override("TUNE", "2") times again)
+static std::map<std::string, Lean4Cand> g_lean4_choice;
+static std::mutex g_lean4_choice_mu;
 
 // one candidate tiling: tile lists, window boxes, row pitch, schedule.  rc 0 = usable, 1 = does not fit, < 0 error.
 // quad: the quad-window kernel -- tiles are row piece x COLUMN piece (both cut where the position corner of their axis steps,
 // the column pieces from pt1 per index of axis 1, at most `wmax` columns), the tile list is per position node.
 static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int threads, int wmax, size_t lds_budget, int* narrower = nullptr,
-                     bool quad = false, const std::vector<int2>* pt1 = nullptr) {
+                     bool quad = false, const std::vector<int2>* pt1 = nullptr, int sub_r0 = 0, int sub_rows = -1) {
     const DevP& P = h->P;
     Lean4P& L = h->L4;
     const int rows = P.row_end - P.row_begin;
@@ -3179,6 +3185,14 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
         while ((rs & 15) != m) ++rs;
         lds = (size_t)std::max(summary[5], 1) * (size_t)rs * 16 + 256;
     }
+    if (narrower) {  // the widest tile whose window lets as many workgroups onto a CU as the register budget does (24 waves)
+        *narrower = 0;
+        const size_t room = (size_t)160 * 1024 / (size_t)std::max(1, 1536 / threads) - 512;
+        if (!quad && lds > room && summary[0] > 0) {
+            const int rs_fit = (int)((room - 256) / 8 / (size_t)summary[0]) & ~3, w_fit = tv1 - (rs - rs_fit);
+            if (w_fit >= 12 && w_fit < tv1) *narrower = w_fit;
+        }
+    }
     if (lds > lds_budget) {
         snprintf(h->lean_why, sizeof(h->lean_why), "tiles of %d threads, <= %d rows need %zu LDS bytes (%d window rows x %d pairs; budget %zu)",
                  threads, cap, lds, summary[0], rs, lds_budget);
@@ -3198,7 +3212,12 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
     const int nbands = std::max(1, std::min(ntr, (L.V0 + band_rows - 1) / band_rows));
     h->lean4_bands = nbands;
     std::vector<unsigned> sched;
-    lean4_schedule(rows, P.dim[1], ntr, ovr_is("NO_XCD", 1) ? 1 : nbands, sched);
+    // (sub_rows: a timed candidate sweeps a few rows of axis 0 from the middle of the slab -- the tiling is the same for every
+    //  row, so a tenth of the grid ranks the candidates at a tenth of the cost; window boxes and pitch are those of the slab)
+    if (sub_rows > 0 && sub_rows < rows && !ovr_is("NO_XCD", 1))
+        lean4_schedule(sub_rows, P.dim[1], ntr, nbands, sched, sub_r0);
+    else
+        lean4_schedule(rows, P.dim[1], ntr, ovr_is("NO_XCD", 1) ? 1 : nbands, sched);
     if (ovr_is("NO_XCD", 1)) {  // plain order (experiments, tests): tile ids ascending
         sched.resize((size_t)ntiles);
         for (long long t = 0; t < ntiles; ++t) sched[(size_t)t] = (unsigned)t;
@@ -3498,12 +3517,41 @@ static int lean4_setup(pvi_problem* h) {
             }
         }
     }
+    // ---- the choice of an earlier create of the same problem shape in this process -------------------------------------------
+    char key[256];
+    snprintf(key, sizeof(key), "%d/%d:%dx%dx%dx%d:A%d:rows%d:dt%.17g:lb%.17g,%.17g:ub%.17g,%.17g:lds%zu:win%d:p%d", h->device, h->d.dynamics_id,
+             P.dim[0], P.dim[1], P.dim[2], P.dim[3], P.A, rows, P.dt, P.lb[2], P.lb[3], P.ub[2], P.ub[3], budget, want_quad ? 2 : 1, h->lean4_persist);
+    bool from_cache = false;
+    if (!ovr_is("TUNE", 0) && !(ovr("TV0") && ovr("TV1")) && !ovr_is("TUNE", 2)) {
+        std::lock_guard<std::mutex> lk(g_lean4_choice_mu);
+        auto it = g_lean4_choice.find(key);
+        if (it != g_lean4_choice.end()) {
+            cands.assign(1, it->second);
+            from_cache = true;
+        }
+    }
     const bool tune = !ovr_is("TUNE", 0) && cands.size() > 1;
+    // Timed candidates (round 4): every candidate sweeps the SAME few rows of axis 0 from the middle of the slab -- one warm-up
+    // and five timed sweeps, each between its own pair of events -- and is judged by the MEDIAN; a later candidate displaces
+    // the best so far only by 5 %.  Round 3 timed two whole-grid sweeps per candidate (C4: 52 x 25 ms) and a 2 % margin: the
+    // choice flipped between runs (55x26 / 55x22, a 9 % swing of the bench line) and set-up took 3.5-6 s.
+    const int sub_rows = std::min(rows, 12), sub_r0 = (rows - sub_rows) / 2;
+    hipEvent_t tev[7] = {};
+    struct EvGuard {
+        hipEvent_t* e;
+        ~EvGuard() {
+            for (int i = 0; i < 7; ++i)
+                if (e[i]) (void)hipEventDestroy(e[i]);
+        }
+    } ev_guard{tev};
+    if (tune)
+        for (auto& e : tev) HIPCHK(hipEventCreate(&e));
     float best_ms = 1e30f;
     int best = -1;
     for (size_t ci = 0; ci < cands.size(); ++ci) {
         int narrower = 0;
-        rc = lean4_try(h, hpt0, cands[ci].cap, cands[ci].w, cands[ci].wmax, budget, &narrower, cands[ci].quad != 0, &hpt1);
+        rc = lean4_try(h, hpt0, cands[ci].cap, cands[ci].w, cands[ci].wmax, budget, &narrower, cands[ci].quad != 0, &hpt1, tune ? sub_r0 : 0,
+                       tune ? sub_rows : -1);
         if (rc < 0) return rc;
         if (rc) continue;
         if (!tune) {
@@ -3518,43 +3566,48 @@ static int lean4_setup(pvi_problem* h) {
         sc.result = h->results;
         sc.tol = -1.0;
         bool hopeless = false;
-        for (int rep = 0; rep < 3 && rc == 0 && !hopeless; ++rep) {  // one warm-up, two timed
-            if (rep <= 1) HIPCHK(hipEventRecord(h->ev0, h->stream));
+        for (int rep = 0; rep < 6 && rc == 0 && !hopeless; ++rep) {  // one warm-up, five timed
+            HIPCHK(hipEventRecord(tev[rep], h->stream));
             hipLaunchKernelGGL(k_reset_stats, 1, STAT_WORDS, 0, h->stream, h->slots, STAT_WORDS);
             hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, h->stream, h->ctrl);
             rc = h->pi_size == 1 ? launch_lean4_t<unsigned char>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc, true)
                                  : launch_lean4_t<unsigned short>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc, true);
             if (rc) return rc;
-            if (rep == 0) {  // (the warm-up sweep of a shape far off the best: not worth two more)
+            if (rep == 0) {  // (the warm-up sweep of a shape far off the best: not worth five more)
                 float warm = 0.f;
-                HIPCHK(hipEventRecord(h->ev1, h->stream));
+                HIPCHK(hipEventRecord(tev[6], h->stream));
                 HIPCHK(hipStreamSynchronize(h->stream));
-                HIPCHK(hipEventElapsedTime(&warm, h->ev0, h->ev1));
-                if (best >= 0 && warm > 1.5f * best_ms / 2.f) {
+                HIPCHK(hipEventElapsedTime(&warm, tev[0], tev[6]));
+                if (best >= 0 && warm > 1.6f * best_ms) {
                     hopeless = true;
-                    ms = 2.f * warm;
+                    ms = warm;
                 }
             }
         }
         if (rc) return rc;
         if (!hopeless) {
-            HIPCHK(hipEventRecord(h->ev1, h->stream));
+            HIPCHK(hipEventRecord(tev[6], h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
-            HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+            float t[5];
+            for (int i = 0; i < 5; ++i) HIPCHK(hipEventElapsedTime(&t[i], tev[1 + i], tev[i + 2 <= 5 ? i + 2 : 6]));
+            std::sort(t, t + 5);
+            ms = t[2];
         }
         {
+            // (milliseconds of the timed rows scaled to the slab: comparable with a whole sweep)
+            const float full = ms * (float)rows / (float)sub_rows;
             const size_t at = strlen(h->lean4_cands);
             if (cands[ci].quad)
-                snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, "%sq%dx%d/%d:%.2f", at ? "," : "", cands[ci].cap, cands[ci].wmax, cands[ci].w, ms / 2.f);
+                snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, "%sq%dx%d/%d:%.2f", at ? "," : "", cands[ci].cap, cands[ci].wmax, cands[ci].w, full);
             else if (cands[ci].wmax < V1)
-                snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, ",%d/%d/%d:%.2f", cands[ci].cap, cands[ci].w, cands[ci].wmax, ms / 2.f);
+                snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, ",%d/%d/%d:%.2f", cands[ci].cap, cands[ci].w, cands[ci].wmax, full);
             else
-                snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, "%s%d/%d:%.2f", at ? "," : "", cands[ci].cap, cands[ci].w, ms / 2.f);
+                snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, "%s%d/%d:%.2f", at ? "," : "", cands[ci].cap, cands[ci].w, full);
         }
         // (a narrower twin of a shape that is in the running: one more workgroup per CU may pay for the extra window halo)
         if (narrower && !cands[ci].quad && cands[ci].wmax == V1 && ms < 1.1f * best_ms && cands.size() < 48)
             cands.push_back({cands[ci].cap, cands[ci].w, narrower, 0});
-        if (ms < 0.98f * best_ms) {  // a later candidate must win by 2 %: within the timing noise the choice stays put, so the
+        if (ms < 0.95f * best_ms) {  // a later candidate must win by 5 %: within the timing noise the choice stays put, so the
             best_ms = ms;            // shape (and with it the committed counter passes) is the same from run to run
             best = (int)ci;
         }
@@ -3570,6 +3623,11 @@ static int lean4_setup(pvi_problem* h) {
         HIPCHK(hipMemsetAsync(h->J[h->cur ^ 1], 0, (size_t)h->stored * 4, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
+    if (best >= 0 && !from_cache && tune) {
+        std::lock_guard<std::mutex> lk(g_lean4_choice_mu);
+        g_lean4_choice[key] = cands[(size_t)best];
+    }
+    if (from_cache) snprintf(h->lean4_cands, sizeof(h->lean4_cands), "cached");
     h->lean_why[0] = 0;
     h->lean4_ok = true;
     return PVI_OK;
