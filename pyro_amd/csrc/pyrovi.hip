@@ -519,6 +519,26 @@ __device__ inline void block_stats_f32_at(int* red, float j, float dmax, float n
     }
 }
 
+// the workgroup's three maxima -> out[0..2] (plain stores by threads 0..2; the multi-sweep kernel's barrier publishes them)
+__device__ inline void block_max3_store(double j, double dmax, double ndmin, double* out) {
+    __shared__ double red3[3][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    j = wave_max(j);
+    dmax = wave_max(dmax);
+    ndmin = wave_max(ndmin);
+    if (lane == 0) {
+        red3[0][wave] = j;
+        red3[1][wave] = dmax;
+        red3[2][wave] = ndmin;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double v = red3[threadIdx.x][0];
+        for (int w = 1; w < nw; ++w) v = fmax(v, red3[threadIdx.x][w]);
+        out[threadIdx.x] = v;
+    }
+}
+
 __device__ inline void block_stats(double j, double dmax, double ndmin, unsigned long long* slot) {
     __shared__ double red[3][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -925,15 +945,37 @@ __device__ __forceinline__ int interval_frac64(const double2* __restrict__ tab, 
 //     the cells outside the box, whose Q is INF + alpha*0 = INF exactly, enter the argmin as one candidate (INF, first
 //     clear bit).  A wave runs as many trips as its busiest lane has cells in the box instead of A (two-link 101^4 x
 //     121: 7 % of the cells are in the box).
-template <int DYN, typename PI_T, bool OFF32, bool PATCH, bool SPARSE = false>
-__global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restrict__ Jin, double* __restrict__ Jout,
-                                                 PI_T* __restrict__ pi, double alpha, SweepCtl sc,
-                                                 const Act64* __restrict__ act64, const double2* __restrict__ levr,
-                                                 const uint4* __restrict__ vmask) {
+// Grid-wide barrier of the multi-sweep kernels (every workgroup of the launch is resident: cooperative launch).  `counter`
+// counts arrivals monotonically over the sweeps of the launch (k_begin_batch zeroes it); `target` = arrivals after this
+// sweep.  Thread 0 publishes the workgroup's stores device-wide (release: the L2s of the 8 XCDs are not coherent with each
+// other -- the fence writes this XCD's dirty lines back), arrives, spins, and invalidates stale lines (acquire) before
+// the workgroup reads the other workgroups' J.
+__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target) {
+    __syncthreads();  // (every wave's stores have been issued and acknowledged: s_waitcnt vmcnt(0) ahead of the barrier)
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+// MULTI (round 4): the device form of the driver loops dynamicprogramming.py:265-314 for grids whose
+// workgroups are all resident.  ONE launch runs up to `nsweeps` backups: everything of a node that does not change between
+// sweeps (coordinates, position row, weights, dynamics prologue) stays in its thread's registers, J ping-pongs between the
+// two buffers, the three statistics of sweep k go to slot k, a grid barrier separates the sweeps, and every workgroup folds
+// the statistics itself and takes the same stop decision (delta <= tol).  Same arithmetic per cell as one launch per sweep:
+// J, pi, the statistics and the stop sweep are bit-identical.
+template <int DYN, typename PI_T, bool OFF32, bool PATCH, bool SPARSE, bool MULTI>
+__device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, double* Jout, PI_T* __restrict__ pi, double alpha, SweepCtl sc,
+                                             const Act64* __restrict__ act64, const double2* __restrict__ levr,
+                                             const uint4* __restrict__ vmask, int nsweeps) {
     using D = Dyn<DYN>;
     constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M;
     static_assert(!PATCH || DOF == 2, "patches tile the velocity plane of 4-D grids");
     static_assert(!SPARSE || DOF == 2, "validity masks are kept for 4-D grids");
+    static_assert(!MULTI || (!PATCH && !SPARSE), "the multi-sweep form is the dense walk over consecutive nodes");
     typedef typename JOff<OFF32>::T off_t;
     typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
     if (sc.ctrl->done) return;
@@ -950,6 +992,11 @@ __global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restric
     long long o = (long long)lb * blockDim.x + threadIdx.x;
     const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
     bool live = o < owned;
+    const bool store_ok = live;
+    if constexpr (MULTI) {  // every thread walks the sweep loop (barriers inside): threads past the grid stand in for its last node
+        if (!live) o = owned - 1;
+        live = true;
+    }
     int idx[N];
     if constexpr (PATCH) {
         const int np2 = (P.dim[2] + 7) >> 3, np3 = (P.dim[3] + 7) >> 3;
@@ -1046,6 +1093,7 @@ __global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restric
 #pragma unroll
             for (int i = 0; i < DOF; ++i) y[i] = (xn[i] - l0[i]) / (l1[i] - l0[i]);
         }
+      for (int ks = 0;; ++ks) {  // (one trip unless MULTI)
         double best = P.INF;  // position row outside the box: every action costs INF + alpha*0, the first one wins
         int arg = 0;
         if (pos_in) {
@@ -1321,15 +1369,80 @@ __global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restric
             }
         }
         if (halo_bad) atomicOr(&sc.ctrl->halo_err, 1);
-        Jout[self] = best;
-        pi[o] = (PI_T)arg;
-        const double d = best - Jin[self];
-        st_j = best;
-        st_dmax = d;
-        st_ndmin = -d;
+        if (store_ok) {
+            Jout[self] = best;
+            pi[o] = (PI_T)arg;
+            const double d = best - Jin[self];
+            st_j = best;
+            st_dmax = d;
+            st_ndmin = -d;
+        }
+        if constexpr (!MULTI) {
+            break;
+        } else {
+            __shared__ double folded[4];
+            // The statistics ride on the barrier: every workgroup stores its three maxima (plain stores, published by the
+            // barrier's release), and behind the barrier every workgroup reads all of them (lane = workgroup: at most 64,
+            // see multi64_applies) -- no atomics, no second round trip.  Two sets, alternating: a workgroup can run at most
+            // one barrier ahead of the slowest reader.
+            double* part = (double*)sc.slot + (size_t)(ks & 1) * 64 * 4;
+            block_max3_store(st_j, st_dmax, st_ndmin, part + 4 * blockIdx.x);
+            grid_barrier(&sc.ctrl->ticket, (unsigned)(ks + 1) * gridDim.x);
+            if (threadIdx.x < 64) {
+                const int l = threadIdx.x;
+                const bool has = l < (int)gridDim.x;
+                double v0 = has ? __builtin_nontemporal_load(part + 4 * l + 0) : -INFINITY;
+                double v1 = has ? __builtin_nontemporal_load(part + 4 * l + 1) : -INFINITY;
+                double v2 = has ? __builtin_nontemporal_load(part + 4 * l + 2) : -INFINITY;
+                v0 = wave_max(v0);
+                v1 = wave_max(v1);
+                v2 = wave_max(v2);
+                if (l == 0) {
+                    folded[0] = v0;
+                    folded[1] = v1;
+                    folded[2] = -v2;
+                    folded[3] = fmax(fabs(v1), fabs(-v2));
+                }
+            }
+            __syncthreads();
+            const double delta = folded[3];
+            const bool stop = sc.tol >= 0.0 && delta <= sc.tol;
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                double* res = sc.result + 4 * ks;
+                res[0] = folded[0];
+                res[1] = folded[1];
+                res[2] = folded[2];
+                res[3] = delta;
+                sc.ctrl->k_done = ks + 1;
+                if (stop) sc.ctrl->done = 1;
+            }
+            if (stop || ks + 1 >= nsweeps) break;
+            const double* t = Jin;  // ping-pong
+            Jin = Jout;
+            Jout = const_cast<double*>(t);
+            st_j = st_dmax = st_ndmin = -INFINITY;
+            __syncthreads();  // (`folded` is rewritten by the next sweep)
+        }
+      }
     }
-    block_stats(st_j, st_dmax, st_ndmin, sc.slot);
-    sweep_finish(sc);
+    if constexpr (!MULTI) {
+        block_stats(st_j, st_dmax, st_ndmin, sc.slot);
+        sweep_finish(sc);
+    }
+}
+
+template <int DYN, typename PI_T, bool OFF32, bool PATCH, bool SPARSE = false>
+__global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restrict__ Jin, double* __restrict__ Jout,
+                                                 PI_T* __restrict__ pi, double alpha, SweepCtl sc,
+                                                 const Act64* __restrict__ act64, const double2* __restrict__ levr,
+                                                 const uint4* __restrict__ vmask) {
+    sweep64_body<DYN, PI_T, OFF32, PATCH, SPARSE, false>(P, Jin, Jout, pi, alpha, sc, act64, levr, vmask, 1);
+}
+// (Jin / Jout without __restrict__: the kernel swaps them between its sweeps)
+template <int DYN, typename PI_T>
+__global__ __launch_bounds__(256) void k_sweep64m(DevP P, const double* Jin, double* Jout, PI_T* __restrict__ pi, double alpha, SweepCtl sc,
+                                                  const Act64* __restrict__ act64, const double2* __restrict__ levr, int nsweeps) {
+    sweep64_body<DYN, PI_T, true, false, false, true>(P, Jin, Jout, pi, alpha, sc, act64, levr, nullptr, nsweeps);
 }
 
 // Validity masks of the SPARSE float64 sweep: bit a of a node's 128-bit word is set when the position row and the cell of
@@ -2668,6 +2781,7 @@ static const char* const OVERRIDE_KEYS[] = {
     "WIN",         // 4-D lean sweep window layout: 0 single floats + ds_read2_b32, 1 position-paired + ds_read_b64, 2 position quads + ds_read_b128
     "RSMOD",       // quad window: residue of the row pitch modulo 16 slots
     "TABLES",      // lean sweep per-node coefficient tables: 0 per-node arrays, 1 factorised where the dynamics allow
+    "MULTI",       // 0: one launch per sweep also where a batch could run as ONE multi-sweep launch (k_sweep64m)
     "PERSIST",     // 4-D lean sweep: 1 persistent workgroups over strided tile lists, 0 one workgroup per tile
     "PERSIST_WGS", // ... at most this many of them per CU
 };
@@ -2761,6 +2875,8 @@ struct pvi_problem {
     const double* roll_params = nullptr;  // constants of the continuous closed form (pvi_set_rollout_params)
     SplineP SP;               // bicubic-spline interpolation mode (sweep_spline.inc)
     bool spline = false;
+    int multi64 = -1;         // multi-sweep launch of the float64 sweep (k_sweep64m): -1 not decided, 0 no, 1 yes
+    char multi_why[96] = "";
     char kname[128] = "";     // the sweep kernel of the last launch, as a kernel trace prints it (spaces removed): pvi_describe `kernel=`
 };
 
@@ -4360,9 +4476,9 @@ static int describe_impl(pvi_handle h, char* buf, int32_t n) {
                        : h->okmask3 ? "fast3"
                        : (h->d.dynamics_id == PVI_DYN_TABLE ? (h->packed ? "table-packed" : "table") : "exact-f32");
     if (h->d.dtype == PVI_F64 && h->use64 && h->d.dynamics_id != PVI_DYN_TABLE) {
-        snprintf(buf, (size_t)n, "path=exact-f64v2 mapping=%s off32=%d sparse=%d inbox=%.4f note=",
+        snprintf(buf, (size_t)n, "path=exact-f64v2 mapping=%s off32=%d sparse=%d inbox=%.4f multi=%d note=%s",
                  h->P.n == 4 ? (h->patch64 ? "patch8x8" : "line64") : "line64",
-                 (int)((unsigned long long)h->stored * 8ull < (1ull << 32)), h->sparse64, h->infrac64);
+                 (int)((unsigned long long)h->stored * 8ull < (1ull << 32)), h->sparse64, h->infrac64, h->multi64, h->multi_why);
         return PVI_OK;
     }
     if (h->lean4_ok) {
@@ -4823,6 +4939,71 @@ static int launch_sweep(pvi_problem* h, int src, double alpha, hipStream_t st, i
                            : launch_sweep_t<float, unsigned short>(h, src, alpha, st, sc);
 }
 
+// ---- multi-sweep launch (k_sweep64m): one cooperative launch for a whole batch of sweeps -------------------------------------
+// Applies to float64 handles on the second-form kernel with the dense walk over consecutive nodes (2-D grids; 4-D ones when
+// set-up kept neither patches nor validity masks), whole grid, every workgroup resident.  pvi_override("MULTI", "0") keeps
+// one launch per sweep.
+template <typename PI_T>
+static const void* multi64_kernel(int dyn) {
+    switch (dyn) {
+        case PVI_DYN_PENDULUM: return (const void*)k_sweep64m<PVI_DYN_PENDULUM, PI_T>;
+        case PVI_DYN_CARTPOLE: return (const void*)k_sweep64m<PVI_DYN_CARTPOLE, PI_T>;
+        case PVI_DYN_TWOLINK: return (const void*)k_sweep64m<PVI_DYN_TWOLINK, PI_T>;
+        case PVI_DYN_NODE_1x1: return (const void*)k_sweep64m<PVI_DYN_NODE_1x1, PI_T>;
+        case PVI_DYN_NODE_2x1: return (const void*)k_sweep64m<PVI_DYN_NODE_2x1, PI_T>;
+        case PVI_DYN_NODE_2x2: return (const void*)k_sweep64m<PVI_DYN_NODE_2x2, PI_T>;
+        default: return nullptr;
+    }
+}
+static bool multi64_applies(pvi_problem* h) {
+    if (h->multi64 >= 0) return h->multi64 == 1;
+    h->multi64 = 0;
+    auto no = [&](const char* why) {
+        snprintf(h->multi_why, sizeof(h->multi_why), "%s", why);
+        return false;
+    };
+    if (ovr_is("MULTI", 0)) return no("MULTI=0");
+    if (h->d.dtype != PVI_F64 || !h->use64 || h->spline || h->d.dynamics_id == PVI_DYN_TABLE) return no("not the float64 second-form sweep");
+    if (h->P.n == 4 && (h->patch64 != 0 || h->sparse64 != 0)) return no("patch mapping / sparse walk");
+    if ((unsigned long long)h->stored * 8ull >= (1ull << 32)) return no("64-bit offsets");
+    const void* kfn = h->pi_size == 1 ? multi64_kernel<unsigned char>(h->d.dynamics_id) : multi64_kernel<unsigned short>(h->d.dynamics_id);
+    if (!kfn) return no("dynamics");
+    int coop = 0, per_cu = 0, ncu = 0;
+    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, h->device) != hipSuccess || !coop) return no("no cooperative launch");
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, h->levr_bytes) != hipSuccess) return no("occupancy query");
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) return no("device query");
+    const unsigned g = grid_for(h->owned);
+    if ((long long)g > (long long)per_cu * ncu) return no("more workgroups than are resident");
+    // Small grids only: a sweep of 40 workgroups is a latency chain that one launch per sweep dominates (C1: 9.9 -> 7.6 us with
+    // the first version of the kernel); with hundreds of workgroups every one of them runs the barrier's L2 write-back and
+    // invalidate and the sweep gets SLOWER (401 x 401 x 51: 27 -> 62 us, profiles/r04_multi_first.log).
+    if (g > 64u) return no("more than 64 workgroups: one launch per sweep is faster");
+    h->multi64 = 1;
+    return true;
+}
+static int launch_multi64(pvi_problem* h, int src, double alpha, double tol, int nsweeps) {
+    SweepCtl sc;
+    sc.ctrl = h->ctrl;
+    sc.slot = h->slots;
+    sc.result = h->results;
+    sc.tol = tol;
+    sc.k = 0;
+    sc.nblocks = grid_for(h->owned);
+    sc.split_finish = 0;
+    sc.xcd_remap = (sc.nblocks >= 64u && !(ovr("XCD64") && !atoi(ovr("XCD64")))) ? 1 : 0;
+    const void* kfn = h->pi_size == 1 ? multi64_kernel<unsigned char>(h->d.dynamics_id) : multi64_kernel<unsigned short>(h->d.dynamics_id);
+    DevP P = h->P;
+    const double* Jin = (const double*)h->J[src];
+    double* Jout = (double*)h->J[src ^ 1];
+    void* pi = h->pi;
+    const Act64* act64 = h->act64;
+    const double2* levr = h->levr;
+    void* args[] = {&P, &Jin, &Jout, &pi, &alpha, &sc, &act64, &levr, &nsweeps};
+    set_kname(h, "k_sweep64m", (int)h->d.dynamics_id, h->pi_size == 1 ? tname<unsigned char>() : tname<unsigned short>());
+    HIPCHK(hipLaunchCooperativeKernel(kfn, dim3(sc.nblocks), dim3(256), args, (unsigned)h->levr_bytes, h->stream));
+    return PVI_OK;
+}
+
 extern "C" int pvi_sweep(pvi_handle h, int32_t max_sweeps, double alpha, double tol, double* stats,
                          int32_t* sweeps_done) {
     if (!h) return fail(PVI_EINVAL, "NULL handle");
@@ -4840,10 +5021,15 @@ extern "C" int pvi_sweep(pvi_handle h, int32_t max_sweeps, double alpha, double 
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(h->ev0, h->stream));
         int src = h->cur;
-        for (int k = 0; k < nb; ++k) {
-            int rc = launch_sweep(h, src, alpha, h->stream, k, tol);
+        if (multi64_applies(h)) {  // ONE launch for the batch: grid barriers between the sweeps, the stop test on the device
+            int rc = launch_multi64(h, src, alpha, tol, nb);
             if (rc) return rc;
-            src ^= 1;
+        } else {
+            for (int k = 0; k < nb; ++k) {
+                int rc = launch_sweep(h, src, alpha, h->stream, k, tol);
+                if (rc) return rc;
+                src ^= 1;
+            }
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(h->ev1, h->stream));

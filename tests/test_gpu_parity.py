@@ -1278,6 +1278,37 @@ def test_base_class_with_obstacles_over_torch_dist_comm(tmp_path):
     assert not np.array_equal(one.J, lut.J)                     # the two recursions really differ on this system
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,tol,extra", [("config1_pendulum_101x101x11", 0.1, {}),
+                                            ("pendulum_demo_51x51x9", -1.0, {}),
+                                            ("cartpole_11p4x5", -1.0, {"PVI_PATCH": "0", "PVI_SPARSE": "0"})])
+def test_multi_sweep_launch_is_bit_identical(name, tol, extra, variants):
+    """a batch of sweeps as ONE cooperative launch (k_sweep64m: per-node state in registers, ping-pong J, grid
+    barrier, device-side stop) against one launch per sweep (MULTI=0): J, pi, every sweep's statistics and the stop sweep
+    are the same bits -- BASELINE config 1 stops after the reference's 618 sweeps either way."""
+    g = load(name)
+    case = CASES.get(name, (O.DYN_PENDULUM, O.pendulum_consts()))
+    p = oracle_problem(g, *case)
+    alpha = float(g["alpha"]) if "alpha" in g.files else 1.0
+    outs = {}
+    for tag, env in (("multi", {}), ("single", {"PVI_MULTI": "0"})):
+        for k in ("PVI_MULTI", "PVI_PATCH", "PVI_SPARSE"):
+            variants.delenv(k)
+        for k, v in {**extra, **env}.items():
+            variants.setenv(k, v)
+        h = native_problem(p, dtype="float64")
+        h.terminal_cost()
+        stats, n = h.sweep(700 if tol > 0 else 9, alpha, tol)
+        outs[tag] = (h.get_J(), h.get_pi(), stats, n, h.describe(), h.get_J(prev=True))
+        h.close()
+    assert "multi=1" in outs["multi"][4] and "kernel=k_sweep64m<" in outs["multi"][4], outs["multi"][4]
+    assert "multi=0" in outs["single"][4] and "kernel=k_sweep64<" in outs["single"][4], outs["single"][4]
+    assert outs["multi"][3] == outs["single"][3] == (618 if tol > 0 else 9)
+    for i in (0, 1, 5):
+        assert np.array_equal(outs["multi"][i], outs["single"][i]), i
+    assert np.array_equal(outs["multi"][2], outs["single"][2])          # the statistics of every sweep
+
+
 # ------------------------------------------------------------------------------- bicubic-spline class
 def _spline_case(g, tag, xd, ud, dt):
     lv = O.make_levels(g["x_lb"], g["x_ub"], xd)
