@@ -992,7 +992,7 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
     long long o = (long long)lb * blockDim.x + threadIdx.x;
     const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
     bool live = o < owned;
-    const bool store_ok = live;
+    bool store_ok = live;
     if constexpr (MULTI) {  // every thread walks the sweep loop (barriers inside): threads past the grid stand in for its last node
         if (!live) o = owned - 1;
         live = true;
@@ -1009,6 +1009,7 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
         idx[2] = p2 * 8 + (lane >> 3);
         idx[3] = p3 * 8 + (lane & 7);
         live = row < (P.row_end - P.row_begin) && idx[2] < P.dim[2] && idx[3] < P.dim[3];
+        store_ok = live;
         o = pl * ((long long)P.dim[2] * P.dim[3]) + (long long)idx[2] * P.dim[3] + idx[3];
     } else if (live) {
         decode_node<N>(P, o, idx);
