@@ -110,6 +110,39 @@ class _Driver:
                 self.vi.slab.close()
 
 
+def _selftest(dist, torch, rank, world, local, via_torch, name="cartpole:41,13,17,15:7:float32", sweeps=6):
+    """`sweeps` backups of a small cart-pole over all ranks against the same backups on rank 0 alone: J, pi and the
+    statistics of the last sweep must be the same bits (same kernels, same arithmetic per node; only the rows a rank does
+    not own travel).  Returns {"ok": bool, ...}; every rank takes part, rank 0 holds the verdict."""
+    cfg = _quiet_build(name, world=world)
+    drv = _Driver(cfg, dist, torch, rank, world, local, via_torch)
+    st = drv.run(sweeps - 1)                 # (the driver's constructor ran one sweep already when it used the library's RCCL path)
+    if drv.fallback_reason is None and hasattr(drv.vi, "shard"):
+        J, pi = drv.vi.shard.gather_J(False), drv.vi.shard.gather_pi()
+        done = sweeps
+    else:                                    # the Python-driven schedule starts from J0
+        st = drv.run(1)
+        J, pi = drv.vi.gather()
+        done = sweeps
+    drv.close()
+    res = {"ok": True, "grid": name, "sweeps": done, "ranks": world}
+    if rank == 0:
+        from pyro_amd.planning import dynamicprogramming
+        with contextlib.redirect_stdout(io.StringIO()):
+            dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype=cfg["dtype"], device=local)
+        stats, _ = dp._p.sweep(done, 1.0, -1.0)
+        J1, pi1 = dp._p.get_J(), dp._p.get_pi()
+        dp._p.close()
+        res["ok"] = bool(np.array_equal(J, J1) and np.array_equal(pi, pi1) and np.allclose(st[:3], stats[-1][:3], rtol=1e-12, atol=0))
+        if not res["ok"]:
+            res["max_abs_diff_J"] = float(np.abs(np.asarray(J) - J1).max())
+            res["pi_mismatches"] = int((np.asarray(pi) != pi1).sum())
+    flag = [res["ok"] if rank == 0 else None]
+    dist.broadcast_object_list(flag, src=0)
+    res["ok"] = bool(flag[0])
+    return res
+
+
 def _timed(drv, dist, torch, steps, warmup):
     """W warm-up sweeps, then batches of exactly K sweeps, each bracketed by barrier + synchronize on both sides and
     reduced with max over the ranks, until the region reaches MIN_REGION_S (every rank takes the same decisions: they
@@ -224,6 +257,20 @@ def run(args):
         drv.close()
         return frag, ref
 
+    # ---- self-test before anything is timed: a small grid through the SAME sharded path (slabs, halo exchange, statistics
+    # all-reduce, gathers) must equal one rank's result bit for bit.  Until an 8-GPU node has run this, it is the first real
+    # RCCL send / recv between ranks the library ever executes -- a wrong exchange should say so, not print a fast number.
+    selftest = None
+    if not getattr(args, "no_selftest", False):
+        err = None
+        try:
+            selftest = _selftest(dist, torch, rank, world, local, via_torch)
+        except Exception as e:                            # noqa: BLE001
+            err = "%s: %s" % (type(e).__name__, e)
+        errs = [None] * world
+        dist.all_gather_object(errs, err)
+        if any(errs):
+            selftest = {"ok": False, "error": "; ".join("rank %d: %s" % (r, e) for r, e in enumerate(errs) if e)}
     frag, ref = one(headline, steps, warmup, max(3, steps // 4))
     if rank == 0:
         weak = headline == "c3w"
@@ -233,6 +280,7 @@ def run(args):
                "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": frag.pop("dtype"),
                "data": "synthetic", "config": frag.pop("config")}
         out.update(frag)
+        out["selftest"] = selftest
         if weak:
             out["value_1gpu_c3"] = ref                # one rank's share of the work, alone on one GPU (N = 1 line)
         else:

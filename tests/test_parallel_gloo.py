@@ -151,8 +151,10 @@ def test_partition_and_halo():
     assert parallel.partition_rows(151, 8) == [(0, 19), (19, 38), (38, 57), (57, 76), (76, 95), (95, 114), (114, 133), (133, 151)]
     assert parallel.partition_rows(10, 3) == [(0, 4), (4, 7), (7, 10)]
     cfg = _build("cartpole:151,5,5,5:3:float32")
-    # C4 halo = ceil(2*pi*0.05 / (4*pi/150)) + 1 = ceil(3.75) + 1 = 5
-    assert parallel.halo_rows(cfg["grid_sys"]) == 5
+    # C4: the largest displacement along axis 0 is 2*pi*0.05 / (4*pi/150) = 3.75 cells: lower corner 3 rows away, upper 4.
+    # (SURVEY 8(e) counted ceil(3.75) + 1 = 5: one row more than the interpolation reads)
+    assert parallel.halo_rows(cfg["grid_sys"]) == 4
+    assert parallel._rows_for_reach(3.0) == 4 and parallel._rows_for_reach(2.9999999999999996) == 4 and parallel._rows_for_reach(0.2) == 1
 
 
 def _harness_worker(rank, world, port, out):
