@@ -266,6 +266,8 @@ int pvi_policy_tables(pvi_handle h, int32_t controller_id, const double* ctl_par
 #define PVI_INTERP_LINEAR 0          /* RegularGridInterpolator('linear', fill 0), discretizer.py:570-587 (default) */
 #define PVI_INTERP_BICUBIC_SPLINE 1  /* RectBivariateSpline(kx=ky=3, s=0), discretizer.py:590-612: refit every sweep,
                                         x_next clamped to the grid box, no zero fill */
+#define PVI_INTERP_NEAREST 2         /* RegularGridInterpolator('nearest', fill 0): per axis the nearer level, ties to the lower one
+                                        (scipy _evaluate_nearest).  Table tier (PVI_DYN_TABLE) only; before pvi_set_tables. */
 /* PVI_INTERP_BICUBIC_SPLINE turns the handle into DynamicProgramming2DRectBivariateSpline
    (dynamicprogramming.py:578-614): n == 2, whole-grid handles only, >= 4 levels per axis; works with the
    pendulum-family in-kernel dynamics (look-up-table semantics) and with tier-B tables.  On a tier-B handle call it

@@ -20,7 +20,7 @@ CLOSED_FORM_IDS = (DYN_PENDULUM, DYN_CARTPOLE, DYN_TWOLINK)    # dynamics pvi_ev
 # ... and pvi_rollout: the explicit systems have continuous closed forms too (their sweeps read host tables at the nodes)
 ROLLOUT_IDS = CLOSED_FORM_IDS + (DYN_HELICOPTER, DYN_KINCAR, DYN_QUARTERCAR, DYN_HOLONOMIC, DYN_LONGCAR)
 COST_TABLE, COST_QUADRATIC, COST_TIME, COST_QUADRATIC_DOMAIN, COST_REACHABILITY = 0, 1, 2, 3, 4
-INTERP_LINEAR, INTERP_BICUBIC_SPLINE = 0, 1
+INTERP_LINEAR, INTERP_BICUBIC_SPLINE, INTERP_NEAREST = 0, 1, 2
 CTL_TABLE, CTL_COMPUTED_TORQUE = 0, 1
 PVI_EHALO = -5
 FLAG_EXT_J_SLACK = 1
@@ -440,8 +440,9 @@ class Problem:
         check(lib().pvi_set_tables(self._h, _ptr(x_next), _ptr(G), okp))
 
     def set_interpolation(self, kind):
-        """'linear' (RegularGridInterpolator, default) or 'bicubic' (RectBivariateSpline kx=ky=3, 2-D grids)."""
-        code = {"linear": INTERP_LINEAR, "bicubic": INTERP_BICUBIC_SPLINE}.get(kind, kind)
+        """'linear' (RegularGridInterpolator, default), 'nearest' (the same with method='nearest'; table tier, before the
+        tables are set) or 'bicubic' (RectBivariateSpline kx=ky=3, 2-D grids)."""
+        code = {"linear": INTERP_LINEAR, "bicubic": INTERP_BICUBIC_SPLINE, "nearest": INTERP_NEAREST}.get(kind, kind)
         check(lib().pvi_set_interpolation(self._h, int(code)))
 
     def spline_coefficients(self):

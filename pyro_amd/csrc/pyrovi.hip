@@ -65,6 +65,7 @@ struct DevP {
     double obs[PVI_MAX_OBS][4];
     const double* aux;          // [A] per-action constants of the dynamics (PVI_DYN_KINCAR)
     int all_aok;                // every action passes isavalidinput (the rule for box-bounded systems)
+    int nearest;                // table tier: RegularGridInterpolator(method='nearest') -- the fraction of every axis snaps to 0 / 1
 };
 
 struct Ctrl {
@@ -2190,6 +2191,7 @@ __global__ __launch_bounds__(256) void k_sweep_table(DevP P, const double* __res
                 double l0, l1;
                 ci[d] = find_interval_lv(lev[d], P.dim[d], P.glo[d], P.inv_step[d], v, l0, l1);
                 y[d] = (v - l0) / (l1 - l0);
+                if (P.nearest) y[d] = y[d] <= 0.5 ? 0.0 : 1.0;  // method='nearest' (see k_table_pack)
                 int c = ci[d];
                 if (d == 0) {
                     if (inb && (c < P.store_begin || c + 1 >= P.store_end)) atomicOr(&sc.ctrl->halo_err, 1);
@@ -2288,7 +2290,10 @@ __global__ __launch_bounds__(256) void k_table_pack(DevP P, const double* __rest
         inb = inb && !(v < P.glo[d]) && !(v > P.ghi[d]);
         double l0, l1;
         const int ci = find_interval_lv(P.lev[d], P.dim[d], P.glo[d], P.inv_step[d], v, l0, l1);
-        r.y[d] = (REAL)((v - l0) / (l1 - l0));
+        double yd = (v - l0) / (l1 - l0);
+        // scipy _evaluate_nearest: idx = where(y <= .5, i, i + 1) per axis -- as weights 1 / 0 of the linear form (exact)
+        if (P.nearest) yd = yd <= 0.5 ? 0.0 : 1.0;
+        r.y[d] = (REAL)yd;
         int c = ci;
         if (d == 0) {
             if (inb && (c < P.store_begin || c + 1 >= P.store_end)) atomicOr(halo_err, 1);
@@ -4170,6 +4175,7 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
     if ((rc = dev_upload(h, utab.data(), utab.size(), &P.utab))) return bail(rc);
     if ((rc = dev_upload(h, gu.data(), gu.size(), &P.gu))) return bail(rc);
     if ((rc = dev_upload(h, aok.data(), aok.size(), &P.aok))) return bail(rc);
+    P.nearest = 0;
     P.all_aok = 1;
     for (long long a = 0; a < A; ++a) P.all_aok = P.all_aok && aok[a];
     {
@@ -5259,7 +5265,14 @@ static int spline_warmup(double rho, int limit) {
 
 extern "C" int pvi_set_interpolation(pvi_handle h, int32_t kind) {
     if (!h) return fail(PVI_EINVAL, "NULL handle");
-    if (kind == PVI_INTERP_LINEAR) {
+    if (kind == PVI_INTERP_LINEAR || kind == PVI_INTERP_NEAREST) {
+        // 'nearest' (RegularGridInterpolator(method='nearest'), discretizer.py:570-587): table tier only -- the interval and
+        // fraction of every cell are fixed when the tables are packed, so the kind must be chosen before pvi_set_tables
+        const int want = kind == PVI_INTERP_NEAREST ? 1 : 0;
+        if (want && h->d.dynamics_id != PVI_DYN_TABLE) return fail(PVI_EINVAL, "nearest-neighbour interpolation is implemented for the table tier");
+        if (want != h->P.nearest && (h->packed || h->d_xnext))
+            return fail(PVI_ESTATE, "the tables have been packed with another interpolation kind: call pvi_set_interpolation before pvi_set_tables");
+        h->P.nearest = want;
         h->spline = false;
         return PVI_OK;
     }

@@ -64,6 +64,19 @@ def halo_rows(grid_sys, rows=None, xn=None, device=0):
     return _rows_for_reach(r / float(grid_sys.x_step_size[0]))
 
 
+def _halo_of_table(grid_sys, rows, xn):
+    """halo_rows for an x_next table [nodes, A, n] of axis-0 rows `rows` whatever the system: the largest in-box
+    |x_next_0 - x_0| of the table (policy-evaluation tables of a mechanical system move by the CONTROLLED dq_0 dt too, but the
+    table is at hand and exact)."""
+    plane = int(np.prod(grid_sys.x_grid_dim[1:]))
+    x0 = np.repeat(grid_sys.x_level[0], plane)[rows[0] * plane:rows[0] * plane + xn.shape[0]]
+    inside = np.ones(xn.shape[:2], dtype=bool)
+    for d in range(grid_sys.sys.n):
+        inside &= (xn[:, :, d] >= grid_sys.x_level[d][0]) & (xn[:, :, d] <= grid_sys.x_level[d][-1])
+    reach = np.abs(xn[:, :, 0] - x0[:, None])[inside]
+    return _rows_for_reach((float(reach.max()) if reach.size else 0.0) / float(grid_sys.x_step_size[0]))
+
+
 def _rows_for_reach(d):
     """Halo rows for a largest displacement of `d` cells along axis 0.  A node sits ON a level, so x_next lies in the cell
     whose lower corner is floor(d) rows away and the interpolation reads that row and the next: floor(d) + 1 rows (also when
@@ -352,7 +365,10 @@ class RcclValueIteration:
     Construction is collective (pvi_shard_create: the ranks agree on the halo width and on success)."""
 
     def __init__(self, grid_sys, cost_function, rank, world, comm_id=None, dtype="float32", device=0, halo=None,
-                 overlap=True, transport=None, hard_inf=False):
+                 overlap=True, transport=None, hard_inf=False, tables=None):
+        """`tables`: dict(u_levels, u_lb, u_ub, build) for table-tier problems whose tables are NOT the reference's
+        x_next / G look-up tables of the grid's own action set -- policy evaluation: one action per node, the controller's
+        (PolicyEvaluator*).  build(lo, hi) -> (x_next [nodes, A, n], G [nodes, A], ok [nodes, A] | None) of this rank's nodes."""
         from pyro_amd import _native
         from pyro_amd.planning.discretizer import device_cost_of, device_dynamics_of
         self.rank, self.world = int(rank), int(world)
@@ -361,7 +377,7 @@ class RcclValueIteration:
         # the same tier decision as DynamicProgramming._make_engine: a cost that tests validity against another system
         # (or a wrapped test) is arbitrary Python -> look-up tables
         cost = device_cost_of(cost_function, s)
-        self.tier = "fused" if (device_dynamics_of(s) is not None and cost is not None) else "table"
+        self.tier = "fused" if (device_dynamics_of(s) is not None and cost is not None and tables is None) else "table"
         n0 = int(grid_sys.x_grid_dim[0])
         r0, r1 = partition_rows(n0, self.world)[self.rank]
         plane = int(np.prod(grid_sys.x_grid_dim[1:]))
@@ -382,16 +398,27 @@ class RcclValueIteration:
         # (the O(N*A) host loops of discretizer.py:342-376 and dynamicprogramming.py:517-553, split over the ranks) and
         # the sweeps run sharded like the fused ones
         lo, hi = r0 * plane, r1 * plane
-        xn, xok = grid_sys._xnext_rows(lo, hi)
-        if halo is None:
-            halo = -halo_rows(grid_sys, (r0, r1), xn=xn)       # local bound; the library takes the largest
-        X, U = grid_sys.state_from_node_id, grid_sys.input_from_action_id
-        aok = np.array([[s.isavalidinput(X[i], U[a]) for a in range(grid_sys.actions_n)] for i in range(lo, hi)], dtype=bool)
-        ok = aok & xok
-        G = np.full(ok.shape, float(cost_function.INF))
-        for i, a in zip(*np.nonzero(ok)):
-            G[i, a] = cost_function.g(X[lo + i], U[a], 0) * grid_sys.dt
-        kw = dict(x_levels=grid_sys.x_level, u_levels=grid_sys.u_level, x_lb=s.x_lb, x_ub=s.x_ub, u_lb=s.u_lb, u_ub=s.u_ub,
+        X = grid_sys.state_from_node_id
+        if tables is not None:
+            xn, G, ok = tables["build"](lo, hi)
+            if halo is None:
+                halo = -_halo_of_table(grid_sys, (r0, r1), xn)
+            u_levels, u_lb, u_ub = tables["u_levels"], tables["u_lb"], tables["u_ub"]
+            if ok is None:
+                ok = np.ones(G.shape, dtype=bool)
+                hard_inf = False
+        else:
+            xn, xok = grid_sys._xnext_rows(lo, hi)
+            if halo is None:
+                halo = -halo_rows(grid_sys, (r0, r1), xn=xn)       # local bound; the library takes the largest
+            U = grid_sys.input_from_action_id
+            aok = np.array([[s.isavalidinput(X[i], U[a]) for a in range(grid_sys.actions_n)] for i in range(lo, hi)], dtype=bool)
+            ok = aok & xok
+            G = np.full(ok.shape, float(cost_function.INF))
+            for i, a in zip(*np.nonzero(ok)):
+                G[i, a] = cost_function.g(X[lo + i], U[a], 0) * grid_sys.dt
+            u_levels, u_lb, u_ub = grid_sys.u_level, s.u_lb, s.u_ub
+        kw = dict(x_levels=grid_sys.x_level, u_levels=u_levels, x_lb=s.x_lb, x_ub=s.x_ub, u_lb=u_lb, u_ub=u_ub,
                   dt=grid_sys.dt, dtype=dtype, dynamics_id=0, table_inf=float(cost_function.INF), device=device)
         self.shard = _native.ShardedProblem(self.rank, self.world, int(halo), comm_id=comm_id, overlap=overlap,
                                             transport=transport, **kw)
@@ -513,7 +540,7 @@ class _LibraryEngine:
     def __init__(self, dp, comm, transport, allgather):
         self.vi = RcclValueIteration(dp.grid_sys, dp.cf, comm.rank, comm.world, comm_id=getattr(comm, "comm_id", None),
                                      dtype=dp.dtype, device=dp.device, overlap=comm.overlap, transport=transport,
-                                     hard_inf=dp.HARD_INF)
+                                     hard_inf=dp.HARD_INF, tables=dp.__dict__.get("_shard_tables"))
         self.shard, self.tier, self.rows = self.vi.shard, self.vi.tier, self.vi.rows
         self.world, self._allgather = comm.world, allgather
         self.plane = self.shard.plane

@@ -86,7 +86,7 @@ class DynamicProgramming:
     # ------------------------------------------------------------------ device engine
     # interpolants of J_k the sweeps implement (discretizer.py:570-587 hands dp.interpol_method to RegularGridInterpolator
     # every sweep; 'bicubic' is this build's name for the RectBivariateSpline subclass, dynamicprogramming.py:578-614)
-    _INTERPOLATIONS = ("linear", "bicubic")
+    _INTERPOLATIONS = ("linear", "nearest", "bicubic")
 
     @property
     def interpol_method(self):
@@ -94,16 +94,32 @@ class DynamicProgramming:
 
     @interpol_method.setter
     def interpol_method(self, value):
-        """The reference passes dp.interpol_method to the interpolant of every sweep; here the interpolation is compiled
-        into the kernel the engine was built with, so a value that engine does not implement ('nearest', 'cubic', ...,
-        or switching kind after construction) raises instead of silently computing with another interpolant."""
+        """The reference passes dp.interpol_method to the interpolant of every sweep (dynamicprogramming.py:186-189,
+        discretizer.py:570-587); here the interpolation is compiled into the engine, so:
+          'linear'  -- every tier (default);
+          'nearest' -- RegularGridInterpolator(method='nearest'): the TABLE tier implements it (the interval and fraction of
+                       every cell are fixed when the tables are packed).  Assigning it rebuilds the engine on the table
+                       tier from the reference's look-up tables and restarts from the terminal cost, as setting it before
+                       the first sweep does in the reference; a sharded engine raises;
+          'bicubic' -- only as the class DynamicProgramming2DRectBivariateSpline;
+        anything else ('cubic', 'slinear', 'quintic', 'pchip') raises instead of silently computing with another interpolant."""
         if value not in self._INTERPOLATIONS:
             raise NotImplementedError("interpol_method %r: the GPU sweeps implement %s" % (value, ", ".join(self._INTERPOLATIONS)))
-        if "_p" in self.__dict__ and value != self.INTERPOLATION:
-            raise NotImplementedError("interpol_method %r on a %s engine: use %s" % (
-                value, self.INTERPOLATION, "DynamicProgramming2DRectBivariateSpline" if value == "bicubic"
-                else "DynamicProgrammingWithLookUpTable"))
+        if value == "bicubic" or self.INTERPOLATION == "bicubic":
+            if "_p" in self.__dict__ and value != self.INTERPOLATION:
+                raise NotImplementedError("interpol_method %r on a %s engine: use %s" % (
+                    value, self.INTERPOLATION, "DynamicProgramming2DRectBivariateSpline" if value == "bicubic"
+                    else "DynamicProgrammingWithLookUpTable"))
+            self.__dict__["_interpol_method"] = value
+            return
+        old = self.__dict__.get("_interpol_method", "linear")
         self.__dict__["_interpol_method"] = value
+        if "_p" in self.__dict__ and value != old:
+            if self.comm is not None or not hasattr(self, "_rebuild_engine"):
+                self.__dict__["_interpol_method"] = old
+                raise NotImplementedError("interpol_method %r on this engine (sharded grids and policy evaluation keep the "
+                                          "interpolant they were built with)" % value)
+            self._rebuild_engine()
 
     def _make_engine(self):
         self._host = {}             # cached downloads: 'J', 'pi', 'J_next'
@@ -119,6 +135,9 @@ class DynamicProgramming:
         self.tier = "fused" if (dd is not None and cost is not None) else "table"
         if self.INTERPOLATION != "linear" and dd is not None and dd[0] != _native.DYN_PENDULUM:
             self.tier = "table"         # the spline sweep has in-kernel dynamics for the pendulum family only
+        nearest = self.__dict__.get("_interpol_method", "linear") == "nearest"
+        if nearest:
+            self.tier = "table"         # nearest-neighbour interpolation: packed into the table tier's records
         if self.tier == "fused":
             # (base class: an invalid cell costs exactly INF; the same as INF + alpha*0 unless the system rejects
             #  states inside the grid box, i.e. obstacles)
@@ -131,6 +150,8 @@ class DynamicProgramming:
                                       table_inf=float(self.cf.INF))
             if self.INTERPOLATION != "linear":
                 self._p.set_interpolation(self.INTERPOLATION)       # before the tables: the spline sweep reads them raw
+            elif nearest:
+                self._p.set_interpolation("nearest")                # before the tables: fractions are snapped when they are packed
             ok = (g.action_isok & g.x_next_isok) if self.HARD_INF else None
             self._p.set_tables(g.x_next_table, self._host_cost_table(), ok)
         if self.tier == "fused" and self.INTERPOLATION != "linear":
@@ -200,6 +221,16 @@ class DynamicProgramming:
     def _invalidate(self):
         self._host.clear()
         self._dirty = False
+
+    def _rebuild_engine(self):
+        """A new engine for the current interpol_method, carrying the current cost-to-go over: the reference builds its
+        interpolant from J_next with the CURRENT method at the start of every sweep (dynamicprogramming.py:186-189), so a
+        change of method between sweeps applies from the next sweep on."""
+        J = self.J.copy()
+        self._p.close()
+        self.__dict__.pop("_G", None)
+        self._make_engine()
+        self.J = J
 
     # ------------------------------------------------------------------ reference API
     def evaluate_terminal_cost(self):
@@ -502,15 +533,48 @@ class PolicyEvaluator(DynamicProgramming):
 
     HARD_INF = True
 
-    def __init__(self, ctl, grid_sys, cost_function, final_time=0, dtype="float64", device=0):
+    def __init__(self, ctl, grid_sys, cost_function, final_time=0, dtype="float64", device=0, comm=None):
         self.ctl = ctl
-        super().__init__(grid_sys, cost_function, final_time, dtype=dtype, device=device)
+        super().__init__(grid_sys, cost_function, final_time, dtype=dtype, device=device, comm=comm)
+
+    def _node_tables(self, lo, hi):
+        """(x_next [hi-lo, n], G [hi-lo], ok [hi-lo]) of the nodes lo..hi-1 by the reference's loop (dynamicprogramming.py:
+        704-735): u = ctl.c(x), x_next = f dt + x, ok = isavalidinput and isavalidstate, G = g dt or INF."""
+        g, s = self.grid_sys, self.sys
+        X, r = g.state_from_node_id, self.ctl.rbar
+        xn, G, ok = np.zeros((hi - lo, s.n)), np.zeros(hi - lo), np.zeros(hi - lo, dtype=bool)
+        for k, i in enumerate(range(lo, hi)):
+            x = X[i]
+            u = self.ctl.c(x, r, self.t)
+            x_next = s.f(x, u, self.t) * g.dt + x
+            xn[k] = x_next
+            ok[k] = s.isavalidinput(x, u) and s.isavalidstate(x_next)
+            G[k] = self.cf.g(x, u, self.t) * g.dt if ok[k] else self.cf.INF
+        return xn, G, ok
 
     def _make_engine(self):
         g, s = self.grid_sys, self.sys
         N = g.nodes_n
         if self.comm is not None:
-            raise NotImplementedError("policy evaluation over a sharded grid")
+            # Sharded (round 4): every rank evaluates the control law, f and g on ITS rows of axis 0 only -- the reference's
+            # O(N) Python loop split over the ranks -- and the one-action tables go to the library's sharded table tier
+            # (halo width from the table itself, agreed between the ranks).  x_next_table / G hold this rank's rows.
+            if not hasattr(self.comm, "comm_id") and not hasattr(self.comm, "sendrecv"):
+                raise NotImplementedError("policy evaluation over a sharded grid: RcclComm or TransportComm (the library's "
+                                          "sharded table tier)")
+            self.tables_on = "host (this rank's rows)"
+            one = [np.zeros(1) for _ in range(s.m)]
+
+            def build(lo, hi):
+                xn, G, ok = self._node_tables(lo, hi)
+                self.x_next_table, self.G = xn, G
+                return xn[:, None, :], G[:, None], (ok[:, None] if self.HARD_INF else None)
+            self._shard_tables = dict(u_levels=one, u_lb=np.zeros(s.m), u_ub=np.zeros(s.m), build=build)
+            self._p = self.comm.engine(self)
+            self.tier = "table"
+            self._host = {}
+            self._dirty = False
+            return
         self.tables_on = "host"
         dd = device_dynamics_of(s)
         cost = device_cost_of(self.cf, s)
@@ -536,23 +600,14 @@ class PolicyEvaluator(DynamicProgramming):
                 p.close()
             self.U, self.x_next_table, self.G = U, xn, G
         else:
-            X = g.state_from_node_id
-            self.x_next_table = np.zeros((N, s.n))
-            self.G = np.zeros(N)
-            ok = np.zeros(N, dtype=bool)
-            r = self.ctl.rbar
-            for i in range(N):
-                x = X[i]
-                u = self.ctl.c(x, r, self.t)
-                x_next = s.f(x, u, self.t) * g.dt + x
-                self.x_next_table[i] = x_next
-                ok[i] = s.isavalidinput(x, u) and s.isavalidstate(x_next)
-                self.G[i] = self.cf.g(x, u, self.t) * g.dt if ok[i] else self.cf.INF
+            self.x_next_table, self.G, ok = self._node_tables(0, N)
         one = [np.zeros(1) for _ in range(s.m)]                     # a single placeholder action
         self.tier = "table"
         self._p = _native.Problem(g.x_level, one, s.x_lb, s.x_ub, np.zeros(s.m), np.zeros(s.m), g.dt, dtype=self.dtype,
                                   dynamics_id=_native.DYN_TABLE, cost=None, device=self.device,
                                   table_inf=float(self.cf.INF))
+        if self.__dict__.get("_interpol_method", "linear") == "nearest":
+            self._p.set_interpolation("nearest")
         self._p.set_tables(self.x_next_table[:, None, :], self.G[:, None], ok[:, None] if self.HARD_INF else None)
         self._host = {}
         self._dirty = False

@@ -660,7 +660,43 @@ def case_floatmass():
     save("floatmass_51x51x21", **out)
 
 
-CASES = dict(longcar=case_longcar, car=case_car, suspension=case_suspension, floatmass=case_floatmass, acrobot=case_acrobot, mintime=case_mintime, mountaincar=case_mountaincar, spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
+def case_nearest():
+    """interpol_method = 'nearest' (discretizer.py:570-587 hands it to RegularGridInterpolator every sweep): the LUT class on
+    a 2-D pendulum, and on the 4-D cart-pole for a few sweeps; plus a switch linear -> nearest between sweeps."""
+    s, g, q = _pendulum_problem((31, 21), (5,))
+    out = _meta(s, g, q)
+    with quiet():
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, q)
+        dp.save_time_history = False
+        dp.interpol_method = "nearest"
+        out.update(x_next_table=g.x_next_table, G=dp.G, J0=dp.J.copy())
+        for k in range(1, 9):
+            dp.initialize_backward_step(); dp.compute_backward_step(); dp.finalize_backward_step()
+            if k in (1, 3, 8):
+                out["J_%d" % k] = dp.J.copy(); out["pi_%d" % k] = dp.pi.copy()
+        # three linear sweeps, then nearest from the fourth on
+        dm = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, q)
+        dm.save_time_history = False
+        dm.compute_steps(3)
+        dm.interpol_method = "nearest"
+        dm.compute_steps(2)
+        out["Jmix_5"] = dm.J.copy(); out["pimix_5"] = dm.pi.copy()
+    save("nearest_pendulum_31x21x5", **out)
+    with quiet():
+        c = cartpole.CartPole()
+        g4 = discretizer.GridDynamicSystem(c, [7, 9, 7, 9], [3])
+        q4 = costfunction.QuadraticCostFunction.from_sys(c)
+        q4.INF = 1000.0
+        d4 = dynamicprogramming.DynamicProgrammingWithLookUpTable(g4, q4)
+        d4.save_time_history = False
+        d4.interpol_method = "nearest"
+        d4.compute_steps(4)
+    out4 = _meta(c, g4, q4)
+    out4.update(J_4=d4.J.copy(), pi_4=d4.pi.copy())
+    save("nearest_cartpole_7x9x7x9x3", **out4)
+
+
+CASES = dict(nearest=case_nearest, longcar=case_longcar, car=case_car, suspension=case_suspension, floatmass=case_floatmass, acrobot=case_acrobot, mintime=case_mintime, mountaincar=case_mountaincar, spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
              policy_eval=case_policy_eval, cost_kat=case_cost_kat, grid_kat=case_grid_kat,
              pendulum_small=case_pendulum_small, config1=case_config1, lowdef=case_lowdef,
              pendulum_demo=case_pendulum_demo, cartpole_small=case_cartpole_small,

@@ -393,3 +393,20 @@ def test_reachability_cost_restatement_matches_reference():
         J, pi = O.sweep(p, J)
         if k in (1, 20):
             np.testing.assert_allclose(J, g["J_%d" % k], rtol=1e-12, atol=1e-12)
+
+
+def test_nearest_interpolation_matches_reference_golden():
+    """dp.interpol_method = 'nearest' (RegularGridInterpolator method='nearest', discretizer.py:570-587): the oracle's
+    restatement against the reference's own runs -- a 2-D pendulum for 1, 3 and 8 sweeps, a switch from linear to nearest
+    between sweeps, and a 4-D cart-pole (scipy's generic path)."""
+    g = load("nearest_pendulum_31x21x5")
+    lv = O.make_levels(g["x_lb"], g["x_ub"], g["dims"])
+    J = g["J0"].copy()
+    for k in range(1, 9):
+        J, pi, _ = O.sweep_lut(lv, g["x_next_table"], g["G"], J, method="nearest")
+        if k in (1, 3, 8):
+            assert np.array_equal(J, g["J_%d" % k]) and np.array_equal(pi, g["pi_%d" % k]), k
+    J = g["J0"].copy()
+    for k in range(5):
+        J, pi, _ = O.sweep_lut(lv, g["x_next_table"], g["G"], J, method="linear" if k < 3 else "nearest")
+    assert np.abs(J - g["Jmix_5"]).max() <= 1e-13 * np.abs(g["Jmix_5"]).max() and np.array_equal(pi, g["pimix_5"])

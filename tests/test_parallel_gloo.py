@@ -298,11 +298,17 @@ def test_interpol_method_is_not_silently_ignored():
     dp = Probe(cfg["grid_sys"], cfg["cf"])
     assert dp.interpol_method == "linear"
     dp.interpol_method = "linear"
-    for kind in ("nearest", "cubic", "slinear", "quintic", "pchip"):
+    for kind in ("cubic", "slinear", "quintic", "pchip"):
         with pytest.raises(NotImplementedError):
             dp.interpol_method = kind
     with pytest.raises(NotImplementedError):        # a linear engine cannot turn into the spline class by assignment
         dp.interpol_method = "bicubic"
+    assert dp.interpol_method == "linear"
+    # 'nearest' is implemented by the table tier (round 4; the GPU test runs it against the reference's own results): on one
+    # device the engine is rebuilt there, a sharded engine keeps the interpolant it was built with and says so
+    dp.comm = object()
+    with pytest.raises(NotImplementedError):
+        dp.interpol_method = "nearest"
     assert dp.interpol_method == "linear"
 
 
