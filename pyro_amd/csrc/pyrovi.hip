@@ -3207,14 +3207,17 @@ static std::mutex g_lean4_choice_mu;
 // quad: the quad-window kernel -- tiles are row piece x COLUMN piece (both cut where the position corner of their axis steps,
 // the column pieces from pt1 per index of axis 1, at most `wmax` columns), the tile list is per position node.
 static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int threads, int wmax, size_t lds_budget, int* narrower = nullptr,
-                     bool quad = false, const std::vector<int2>* pt1 = nullptr, int sub_r0 = 0, int sub_rows = -1) {
+                     int quad = 0, const std::vector<int2>* pt1 = nullptr, int sub_r0 = 0, int sub_rows = -1) {
+    // quad: 0 pair window, 1 quad window with step-aligned column pieces (one plane), 2 quad window over the pair window's
+    // tiles (free column splits: up to three planes)
+    const bool quad_cols = quad == 1;
     const DevP& P = h->P;
     Lean4P& L = h->L4;
     const int rows = P.row_end - P.row_begin;
     if (threads > 512 || threads < 64 || (threads & 63)) return 1;
     std::vector<std::vector<int4>> per;
     int ntr = 1, tv0 = 1, tv1 = 1;
-    if (!quad) {
+    if (!quad_cols) {
         per.resize((size_t)rows);
         for (int r = 0; r < rows; ++r) {
             lean4_row_tiles(pt0, P.row_begin + r, P.dim[2], P.dim[3], cap, threads, wmax, per[(size_t)r]);
@@ -3256,9 +3259,9 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
     std::vector<int4> tlist(nlists * ntr, make_int4(0, 0, 0, 0));
     for (size_t r = 0; r < nlists; ++r)
         for (size_t k = 0; k < per[r].size(); ++k) tlist[r * ntr + k] = per[r][k];
-    L.tl_by = quad ? 1 : 0;
+    L.tl_by = quad_cols ? 1 : 0;
     L.quad = quad ? 1 : 0;
-    h->lean4_quad = quad ? 1 : 0;
+    h->lean4_quad = quad;
     L.V0 = P.dim[2];
     L.V1 = P.dim[3];
     L.TV0 = tv0;
@@ -3296,7 +3299,7 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
     size_t lds = (size_t)std::max(summary[0], 1) * (size_t)rs * 8 + 256;
     if (quad) {
         // one plane of 16-byte slots; every non-empty tile must see ONE corner pair on either position axis
-        if (summary[4] > 1 || summary[2] > 2) {
+        if (summary[4] > 1 || summary[2] > (quad_cols ? 2 : 4)) {
             snprintf(h->lean_why, sizeof(h->lean_why), "quad window: a tile spans %d pair planes x %d position rows", summary[4], summary[2]);
             return 1;
         }
@@ -3305,13 +3308,14 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
         const int m = ovr("RSMOD") ? (atoi(ovr("RSMOD")) & 15) : (tv1 & 15);
         rs = std::max(1, summary[1]);
         while ((rs & 15) != m) ++rs;
-        lds = (size_t)std::max(summary[5], 1) * (size_t)rs * 16 + 256;
+        lds = (size_t)std::max(summary[2] - 1, 1) * (size_t)std::max(summary[5], 1) * (size_t)rs * 16 + 256;  // (planes x rows: an upper bound)
     }
     if (narrower) {  // the widest tile whose window lets as many workgroups onto a CU as the register budget does (24 waves)
         *narrower = 0;
         const size_t room = (size_t)160 * 1024 / (size_t)std::max(1, 1536 / threads) - 512;
-        if (!quad && lds > room && summary[0] > 0) {
-            const int rs_fit = (int)((room - 256) / 8 / (size_t)summary[0]) & ~3, w_fit = tv1 - (rs - rs_fit);
+        if (quad != 1 && lds > room && summary[0] > 0) {
+            const size_t rows_w = quad ? (size_t)std::max(summary[2] - 1, 1) * (size_t)std::max(summary[5], 1) : (size_t)summary[0];
+            const int rs_fit = (int)((room - 256) / (quad ? 16 : 8) / rows_w) & ~3, w_fit = tv1 - (rs - rs_fit);
             if (w_fit >= 12 && w_fit < tv1) *narrower = w_fit;
         }
     }
@@ -3611,6 +3615,8 @@ static int lean4_setup(pvi_problem* h) {
     // not beat the pair window (3.4 against 3.14 ms, 19.5 against 19.7 ms), so a default create does not spend
     // set-up time on its candidates.
     const bool want_quad = ovr_is("WIN", 2);
+    if (ovr_is("WIN", 3))  // quad planes over the pair window's own tile candidates (free column splits)
+        for (auto& c : cands) c.quad = 2;
     std::vector<int2> hpt1;
     if (want_quad) {
         hpt1.resize((size_t)P.dim[1] * P.dim[3]);
@@ -3642,7 +3648,7 @@ static int lean4_setup(pvi_problem* h) {
     // ---- the choice of an earlier create of the same problem shape in this process -------------------------------------------
     char key[256];
     snprintf(key, sizeof(key), "%d/%d:%dx%dx%dx%d:A%d:rows%d:dt%.17g:lb%.17g,%.17g:ub%.17g,%.17g:lds%zu:win%d:p%d", h->device, h->d.dynamics_id,
-             P.dim[0], P.dim[1], P.dim[2], P.dim[3], P.A, rows, P.dt, P.lb[2], P.lb[3], P.ub[2], P.ub[3], budget, want_quad ? 2 : 1, h->lean4_persist);
+             P.dim[0], P.dim[1], P.dim[2], P.dim[3], P.A, rows, P.dt, P.lb[2], P.lb[3], P.ub[2], P.ub[3], budget, want_quad ? 2 : (ovr_is("WIN", 3) ? 3 : 1), h->lean4_persist);
     bool from_cache = false;
     if (!ovr_is("TUNE", 0) && !(ovr("TV0") && ovr("TV1")) && !ovr_is("TUNE", 2)) {
         std::lock_guard<std::mutex> lk(g_lean4_choice_mu);
@@ -3672,7 +3678,7 @@ static int lean4_setup(pvi_problem* h) {
     int best = -1;
     for (size_t ci = 0; ci < cands.size(); ++ci) {
         int narrower = 0;
-        rc = lean4_try(h, hpt0, cands[ci].cap, cands[ci].w, cands[ci].wmax, budget, &narrower, cands[ci].quad != 0, &hpt1, tune ? sub_r0 : 0,
+        rc = lean4_try(h, hpt0, cands[ci].cap, cands[ci].w, cands[ci].wmax, budget, &narrower, cands[ci].quad, &hpt1, tune ? sub_r0 : 0,
                        tune ? sub_rows : -1);
         if (rc < 0) return rc;
         if (rc) continue;
@@ -3719,7 +3725,7 @@ static int lean4_setup(pvi_problem* h) {
             // (milliseconds of the timed rows scaled to the slab: comparable with a whole sweep)
             const float full = ms * (float)rows / (float)sub_rows;
             const size_t at = strlen(h->lean4_cands);
-            if (cands[ci].quad)
+            if (cands[ci].quad == 1)
                 snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, "%sq%dx%d/%d:%.2f", at ? "," : "", cands[ci].cap, cands[ci].wmax, cands[ci].w, full);
             else if (cands[ci].wmax < V1)
                 snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, ",%d/%d/%d:%.2f", cands[ci].cap, cands[ci].w, cands[ci].wmax, full);
@@ -3727,8 +3733,8 @@ static int lean4_setup(pvi_problem* h) {
                 snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, "%s%d/%d:%.2f", at ? "," : "", cands[ci].cap, cands[ci].w, full);
         }
         // (a narrower twin of a shape that is in the running: one more workgroup per CU may pay for the extra window halo)
-        if (narrower && !cands[ci].quad && cands[ci].wmax == V1 && ms < 1.1f * best_ms && cands.size() < 48)
-            cands.push_back({cands[ci].cap, cands[ci].w, narrower, 0});
+        if (narrower && cands[ci].quad != 1 && cands[ci].wmax == V1 && ms < 1.1f * best_ms && cands.size() < 48)
+            cands.push_back({cands[ci].cap, cands[ci].w, narrower, cands[ci].quad});
         if (ms < 0.95f * best_ms) {  // a later candidate must win by 5 %: within the timing noise the choice stays put, so the
             best_ms = ms;            // shape (and with it the committed counter passes) is the same from run to run
             best = (int)ci;
@@ -3737,7 +3743,7 @@ static int lean4_setup(pvi_problem* h) {
     if (best < 0) return give_up(h->lean_why[0] ? h->lean_why : "no tile shape fits the LDS budget");
     if (tune) {
         if ((rc = lean4_try(h, hpt0, cands[(size_t)best].cap, cands[(size_t)best].w, cands[(size_t)best].wmax, budget, nullptr,
-                            cands[(size_t)best].quad != 0, &hpt1)))
+                            cands[(size_t)best].quad, &hpt1)))
             return rc < 0 ? rc : give_up("tile shape lost");
         // the timed sweeps wrote into the second J buffer, pi and the control block
         HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream));
@@ -4493,7 +4499,7 @@ static int describe_impl(pvi_handle h, char* buf, int32_t n) {
         // not span axis d; rowpieces / bands: the step-aligned row pieces of axis 2 and their grouping in the launch order
         snprintf(buf, (size_t)n, "path=lean tile=%dx%d grid=%ux1x1 block=%d pw1=%d lds_bytes=%zu lsplit=0 tb_tile=1 dma16=0 npt=1 "
                  "reach=0 opmag=0 sparse=0 win=%d tables=%d ptab=%d gx=%s stage=%d persist=%d pgrid=%u tiles_per_plane=%d bands=%d cands=%s note=%s", h->L4.TV0, h->L4.TV1,
-                 h->lean4_grid, h->lean4_block, h->L4.RS, h->lean4_lds, h->lean4_quad ? 2 : 1, h->lean4_tables, h->lean4_ptab_inv, h->L4.gx ? "node" : "axes", h->lean4_stage,
+                 h->lean4_grid, h->lean4_block, h->L4.RS, h->lean4_lds, h->lean4_quad ? 1 + h->lean4_quad : 1, h->lean4_tables, h->lean4_ptab_inv, h->L4.gx ? "node" : "axes", h->lean4_stage,
                  h->lean4_persist, h->lean4_pgrid, h->L4.ntr, h->lean4_bands, h->lean4_cands[0] ? h->lean4_cands : "-", h->lean_why);
         return PVI_OK;
     }

@@ -416,6 +416,8 @@ def test_f32_kernel_variants_agree(name, variants):
                      # round 4: quad window (tiles of one position-corner quad, ds_read_b128), two tile shapes, another pitch residue
                      ("lean_quad", {"PVI_WIN": "2"}), ("lean_quad_shape", {"PVI_WIN": "2", "PVI_TV0": "3", "PVI_TV1": "4"}),
                      ("lean_quad_rsmod", {"PVI_WIN": "2", "PVI_RSMOD": "1", "PVI_NO_XCD": "1"}),
+                     # ... and quad planes over the pair window's own tiles (free column splits: several planes per window)
+                     ("lean_quad3", {"PVI_WIN": "3"}), ("lean_quad3_shape", {"PVI_WIN": "3", "PVI_TV0": "3", "PVI_TV1": "7"}),
                      ("fast", {"PVI_NO_LEAN": "1"}),
                      ("exact32", {"PVI_NO_FAST": "1"})]:
         for k in ("PVI_LSPLIT", "PVI_NO_LEAN", "PVI_NO_FAST", "PVI_NPT", "PVI_WIN", "PVI_TABLES", "PVI_NO_XCD", "PVI_TV0", "PVI_TV1",
@@ -458,8 +460,9 @@ def test_f32_kernel_variants_agree(name, variants):
             assert np.array_equal(outs[tag][0], outs["lean_win1"][0]) and np.array_equal(outs[tag][1], outs["lean_win1"][1]), (tag, outs[tag][2])
         assert "tables=0" in outs["lean_tab0"][2] and "gx=node" in outs["lean_tab0"][2], outs["lean_tab0"][2]
         assert "tile=3x" in outs["lean_shape"][2], outs["lean_shape"][2]       # (columns are evened out over the tiles)
-        for tag in ("lean_quad", "lean_quad_shape", "lean_quad_rsmod"):     # the same arithmetic per cell: the same bits
-            assert path_of(outs[tag][2]) == "path=lean" and "win=2" in outs[tag][2] and "kernel=k_sweep_lean4q<" in outs[tag][2], (tag, outs[tag][2])
+        for tag in ("lean_quad", "lean_quad_shape", "lean_quad_rsmod", "lean_quad3", "lean_quad3_shape"):     # the same arithmetic per cell: the same bits
+            assert path_of(outs[tag][2]) == "path=lean" and ("win=3" if "quad3" in tag else "win=2") in outs[tag][2], (tag, outs[tag][2])
+            assert "kernel=k_sweep_lean4q<" in outs[tag][2], (tag, outs[tag][2])
             assert np.array_equal(outs[tag][0], outs["lean_win1"][0]) and np.array_equal(outs[tag][1], outs["lean_win1"][1]), (tag, outs[tag][2])
         assert "persist=1" in outs["lean_persist"][2] and "kernel=k_sweep_lean4p<" in outs["lean_persist"][2], outs["lean_persist"][2]
         assert "persist=0" in outs["lean_nopersist"][2] and "kernel=k_sweep_lean4<" in outs["lean_nopersist"][2], outs["lean_nopersist"][2]
