@@ -2786,6 +2786,7 @@ static const char* const OVERRIDE_KEYS[] = {
     "SPLINE_CHUNK",            // spline mode: rows per chunk of the substitution passes
     "WIN",         // 4-D lean sweep window layout: 0 single floats + ds_read2_b32, 1 position-paired + ds_read_b64, 2 position quads + ds_read_b128
     "RSMOD",       // quad window: residue of the row pitch modulo 16 slots
+    "BANDS",       // 4-D lean sweep launch order: bands of the tile list per XCD pass (default: sized for the L2)
     "TABLES",      // lean sweep per-node coefficient tables: 0 per-node arrays, 1 factorised where the dynamics allow
     "MULTI",       // 0: one launch per sweep also where a batch could run as ONE multi-sweep launch (k_sweep64m)
     "PERSIST",     // 4-D lean sweep: 1 persistent workgroups over strided tile lists, 0 one workgroup per tile
@@ -3176,15 +3177,22 @@ static void lean4_row_tiles(const std::vector<int2>& pt0, int i0, int V0, int V1
 // the planes of three consecutive axis-0 rows over the chunk fit its L2): the axis-0 planes a tile gathers from were
 // fetched for the previous row a moment ago.  Lists are interleaved into physical order and padded to equal length.
 static void lean4_schedule(int R, int N1, int ntr, int nbands, std::vector<unsigned>& out, int r0 = 0) {
+    // Round 4: an XCD's share of a row is a contiguous EIGHTH of the row's (axis-1 index, tile) list -- not a whole number of
+    // axis-1 indices.  Splitting by index gave 13, 13, 12, 13, ... of C3's 101 to the XCDs: the lists were padded to the
+    // longest with empty workgroups and five XCDs idled 8 % of every row (the plain order, which balances by construction,
+    // ran 2.90 ms against 3.10 ms with the same tiles; profiles/r04_launch_order.log).
     std::vector<std::vector<unsigned>> lists(8);
-    for (int x = 0; x < 8; ++x) {
-        const int c0 = (int)((long long)N1 * x / 8), c1 = (int)((long long)N1 * (x + 1) / 8);
-        for (int b = 0; b < nbands; ++b) {
-            const int k0 = (int)((long long)ntr * b / nbands), k1 = (int)((long long)ntr * (b + 1) / nbands);
-            for (int r = r0; r < r0 + R; ++r)  // (r0, R: the rows of a timed candidate; the whole slab otherwise)
-                for (int i1 = c0; i1 < c1; ++i1)
-                    for (int k = k0; k < k1; ++k) lists[x].push_back((unsigned)((long long)(r * N1 + i1) * ntr + k));
-        }
+    for (int b = 0; b < nbands; ++b) {
+        const int k0 = (int)((long long)ntr * b / nbands), k1 = (int)((long long)ntr * (b + 1) / nbands), kb = k1 - k0;
+        const long long E = (long long)N1 * kb;  // entries of one row of axis 0 in this band: i1-major, tile-minor
+        for (int r = r0; r < r0 + R; ++r)  // (r0, R: the rows of a timed candidate; the whole slab otherwise)
+            for (int x = 0; x < 8; ++x) {
+                const long long e0 = E * x / 8, e1 = E * (x + 1) / 8;
+                for (long long e = e0; e < e1; ++e) {
+                    const int i1 = (int)(e / kb), k = k0 + (int)(e - (long long)i1 * kb);
+                    lists[x].push_back((unsigned)((long long)(r * N1 + i1) * ntr + k));
+                }
+            }
     }
     size_t mx = 0;
     for (auto& l : lists) mx = std::max(mx, l.size());
@@ -3331,11 +3339,15 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
     h->lean4_pgrid = 0;
     h->lean4_dblocks_stale = true;
     hipLaunchKernelGGL(k_lean4_off, grid_for(h->lean4_ptab_groups * 4), 256, 0, h->stream, L, h->lean4_ptab_groups);
-    // bands of the tile list: three axis-0 rows x (chunk of axis 1 + position reach) x band rows x V1 floats within ~1.5 MB of L2
+    // bands of the tile list: an XCD's working set is three axis-0 rows x (its share of axis 1 + position reach) x band rows x
+    // V1 floats.  Round 3 sized the bands for 1.5 MB of the 4 MB L2 (C3: 2 bands, C4: 3); measured on the balanced schedule
+    // of round 4, ONE band is fastest on both (C3 2.77 against 2.91 ms, C4 19.13 against 19.30 ms; profiles/r04_launch_order.log)
+    // -- the sweep is not bound by what the bands save -- so bands are only cut when the working set is several L2s.
     const int n1c = (P.dim[1] + 7) / 8 + 3;
     const double per_row = 3.0 * n1c * (double)L.V1 * 4.0;
-    const int band_rows = std::max(L.TV0, (int)(1.5e6 / per_row) - (summary[0] ? 12 : 0));
-    const int nbands = std::max(1, std::min(ntr, (L.V0 + band_rows - 1) / band_rows));
+    const int band_rows = std::max(L.TV0, (int)(12e6 / per_row) - (summary[0] ? 12 : 0));
+    int nbands = std::max(1, std::min(ntr, (L.V0 + band_rows - 1) / band_rows));
+    if (ovr("BANDS") && atoi(ovr("BANDS")) > 0) nbands = std::min(ntr, atoi(ovr("BANDS")));  // (experiments: the launch order only)
     h->lean4_bands = nbands;
     std::vector<unsigned> sched;
     // (sub_rows: a timed candidate sweeps a few rows of axis 0 from the middle of the slab -- the tiling is the same for every

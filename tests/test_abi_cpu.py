@@ -508,8 +508,10 @@ def test_plane_tilings_partition_the_plane_and_fit_the_workgroup():
 
 
 def test_launch_schedule_is_a_permutation_dealt_to_the_xcds():
-    """pvi_plan_schedule (lean4_schedule): every tile exactly once, padding only at the tails of the per-XCD lists, XCD x =
-    blocks k with k % 8 == x holds a contiguous chunk of axis 1 for every row, rows ascending inside a band."""
+    """pvi_plan_schedule (lean4_schedule): every tile exactly once, padding only at the tails of the per-XCD lists; XCD x =
+    blocks k with k % 8 == x holds, for every row and band, a CONTIGUOUS EIGHTH of the row's (axis-1 index, tile) list -- the
+    lists of the XCDs differ by at most one tile per (row, band), whatever the number of axis-1 indices (round 4: splitting by
+    whole indices left five of eight XCDs idle 8 % of the time on a 101-wide axis) -- rows ascending inside a band."""
     from pyro_amd import _native
     rng = np.random.default_rng(6)
     for case in range(40):
@@ -519,12 +521,26 @@ def test_launch_schedule_is_a_permutation_dealt_to_the_xcds():
         assert len(s) % 8 == 0
         live = s[s != 0xFFFFFFFF]
         assert len(live) == rows * n1 * tpp and len(np.unique(live)) == len(live) and live.max() == rows * n1 * tpp - 1
+        lens = []
         for x in range(8):
             lst = s[x::8]
             pad = lst == 0xFFFFFFFF
             assert not pad[:len(lst) - pad.sum()].any()                      # padding at the tail only
             ids = lst[~pad].astype(np.int64)
-            i1 = (ids // tpp) % n1
-            if len(ids):
-                assert i1.max() - i1.min() + 1 == len(np.unique(i1))         # a contiguous chunk of axis 1
-                assert i1.min() == n1 * x // 8 and i1.max() == n1 * (x + 1) // 8 - 1
+            lens.append(len(ids))
+            if not len(ids):
+                continue
+            r, i1, k = ids // (tpp * n1), (ids // tpp) % n1, ids % tpp
+            band = np.searchsorted([tpp * (b + 1) // bands for b in range(bands)], k, side="right")
+            # bands outermost, rows ascending inside a band, and inside (band, row) a contiguous run of the (i1, k) list
+            key = (band * rows + r)
+            assert (np.diff(key) >= 0).all(), (case, x)
+            for kk in np.unique(key):
+                sel = key == kk
+                b = int(band[sel][0])
+                k0, k1 = tpp * b // bands, tpp * (b + 1) // bands
+                e = i1[sel] * (k1 - k0) + (k[sel] - k0)
+                assert (np.diff(e) == 1).all(), (case, x, kk)
+                E = n1 * (k1 - k0)
+                assert e[0] == E * x // 8 and e[-1] == E * (x + 1) // 8 - 1, (case, x, kk)
+        assert max(lens) - min(lens) <= rows * bands                         # balanced to a tile per (row, band)
