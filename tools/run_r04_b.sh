@@ -1,7 +1,8 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out
-L=gpurun_out/r04_sched_default.log; : > $L
-timeout 900 python tools/tools_create_time.py c3 c4 repeats=3 2>&1 | grep -E "CREATE|rror" >> $L
-timeout 300 python tools/tools_time.py c3s 200 2>&1 | grep -E "TIME|rror" >> $L
-timeout 300 python tools/tools_time.py cartpole:61,61,61,61:21:float32 100 2>&1 | grep -E "TIME|rror" >> $L
+L=gpurun_out/r04_quad_resched.log; : > $L
+for a in "WIN=2" "WIN=3" "WIN=2 TV0=20 TV1=20" "PERSIST=1"; do
+  timeout 300 python tools/tools_time.py c3 30 $a 2>&1 | grep -E "TIME|rror" >> $L
+done
+timeout 300 python tools/tools_time.py c4 10 WIN=2 2>&1 | grep -E "TIME|rror" >> $L
 cat $L

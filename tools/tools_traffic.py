@@ -13,6 +13,7 @@ with _native.overrides(**ov), contextlib.redirect_stdout(io.StringIO()):
     dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype=cfg["dtype"])
 dp.save_time_history = False
 p = dp._p
-p.sweep(6, 1.0, -1.0)
+for _ in range(6):          # one sweep per batch: a multi-sweep launch (k_sweep64m) then is ONE sweep per launch too
+    p.sweep(1, 1.0, -1.0)
 J = p.get_J()
 print("nodes", cfg["grid_sys"].nodes_n, p.describe())
