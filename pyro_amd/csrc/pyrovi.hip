@@ -986,9 +986,19 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
     // a CONTIGUOUS range of logical blocks (physical block b = 8 j + x  ->  logical x * chunk + j) and a plane is fetched
     // into one L2 instead of eight.  (Placement only; sc.xcd_remap = 0 keeps the identity.)
     unsigned lb = blockIdx.x;
-    if (sc.xcd_remap) {
+    if (sc.xcd_remap == 1) {
         const unsigned nb = gridDim.x, xq = nb >> 3, xr = nb & 7u, xx = lb & 7u, jj = lb >> 3;
         lb = (xx < xr ? xx * (xq + 1u) : xr * (xq + 1u) + (xx - xr) * xq) + jj;
+    } else if (sc.xcd_remap > 1) {
+        // chunks of C consecutive logical blocks dealt round-robin to the XCDs (C = the blocks of a few rows of axis 0): an XCD
+        // still works on neighbouring position rows, but every XCD samples the WHOLE range of axis 0 -- the sparse walk's work
+        // per node depends on the position (rows near the faces of the grid leave the box), and an XCD that owns one
+        // contiguous eighth of the rows is done early or late
+        const unsigned C = (unsigned)sc.xcd_remap, nb = gridDim.x, full = nb / (8u * C) * (8u * C);
+        if (lb < full) {
+            const unsigned xx = lb & 7u, jj = lb >> 3;
+            lb = ((jj / C) * 8u + xx) * C + jj % C;
+        }
     }
     long long o = (long long)lb * blockDim.x + threadIdx.x;
     const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
@@ -1755,7 +1765,10 @@ __global__ __launch_bounds__(256) void k_sweep3_fast(DevP P, const float* __rest
     using D = Dyn3<DYN>;
     constexpr int N = D::N, M = D::M;
     if (sc.ctrl->done) return;
-    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // (Plain block order.  Contiguous block ranges per XCD, as in k_sweep64, were measured in round 4: 0.478 against 0.458 ms on
+    //  the 201 x 201 x 401 helicopter grid -- the 2.4 GB this sweep moves through the fabric per launch are not what it waits for.)
+    const unsigned lb = blockIdx.x;
+    const long long o = (long long)lb * blockDim.x + threadIdx.x;
     const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
     double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
     if (o < owned) {
@@ -2786,6 +2799,7 @@ static const char* const OVERRIDE_KEYS[] = {
     "SPLINE_CHUNK",            // spline mode: rows per chunk of the substitution passes
     "WIN",         // 4-D lean sweep window layout: 0 single floats + ds_read2_b32, 1 position-paired + ds_read_b64, 2 position quads + ds_read_b128
     "RSMOD",       // quad window: residue of the row pitch modulo 16 slots
+    "XCD_CHUNK",   // 4-D float64 sweep: rows of axis 0 per chunk dealt round-robin to the XCDs (0: one contiguous eighth per XCD)
     "BANDS",       // 4-D lean sweep launch order: bands of the tile list per XCD pass (default: sized for the L2)
     "TABLES",      // lean sweep per-node coefficient tables: 0 per-node arrays, 1 factorised where the dynamics allow
     "MULTI",       // 0: one launch per sweep also where a batch could run as ONE multi-sweep launch (k_sweep64m)
@@ -3342,10 +3356,12 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
     // bands of the tile list: an XCD's working set is three axis-0 rows x (its share of axis 1 + position reach) x band rows x
     // V1 floats.  Round 3 sized the bands for 1.5 MB of the 4 MB L2 (C3: 2 bands, C4: 3); measured on the balanced schedule
     // of round 4, ONE band is fastest on both (C3 2.77 against 2.91 ms, C4 19.13 against 19.30 ms; profiles/r04_launch_order.log)
-    // -- the sweep is not bound by what the bands save -- so bands are only cut when the working set is several L2s.
+    // -- the sweep is not bound by what the bands save -- but C4's single band moved 17.1 GB through the L2s instead of 9.8
+    // (3.6x instead of 2.1x the algorithmic bytes, for 1 % of time): bands are cut where the working set exceeds ~3.6 MB
+    // of the 4 MB L2 (C3: one band of 2 MB, C4: two of 3 MB).
     const int n1c = (P.dim[1] + 7) / 8 + 3;
     const double per_row = 3.0 * n1c * (double)L.V1 * 4.0;
-    const int band_rows = std::max(L.TV0, (int)(12e6 / per_row) - (summary[0] ? 12 : 0));
+    const int band_rows = std::max(L.TV0, (int)(3.6e6 / per_row) - (summary[0] ? 12 : 0));
     int nbands = std::max(1, std::min(ntr, (L.V0 + band_rows - 1) / band_rows));
     if (ovr("BANDS") && atoi(ovr("BANDS")) > 0) nbands = std::min(ntr, atoi(ovr("BANDS")));  // (experiments: the launch order only)
     h->lean4_bands = nbands;
@@ -4806,6 +4822,16 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             }
             const int sparse = h->sparse64;
             sc.xcd_remap = (gp >= 64u && !(ovr("XCD64") && !atoi(ovr("XCD64")))) ? 1 : 0;
+            if (sc.xcd_remap && h->P.n == 4 && !(ovr("XCD_CHUNK") && atoi(ovr("XCD_CHUNK")) == 0)) {
+                // 4-D: the blocks of ONE row of axis 0 per chunk, chunks dealt round-robin to the XCDs (round 4).  One contiguous
+                // eighth of the rows per XCD left the XCDs with unequal work -- what a node costs depends on its position (rows
+                // near the faces leave the box; the sparse walk's in-box share varies with the joint angles): C5 15.8 -> 14.65 ms
+                // with chunks of one row, 14.9 with two, 15.7 with four (profiles/r04_c5_chunks.log)
+                const int rows_c = ovr("XCD_CHUNK") ? atoi(ovr("XCD_CHUNK")) : 1;
+                const long long per_row = (long long)gp / std::max(1, h->P.row_end - h->P.row_begin);
+                const long long C = per_row * std::max(1, rows_c);
+                if (C >= 2 && C * 16 <= (long long)gp) sc.xcd_remap = (int)C;
+            }
             const size_t lds64 = h->levr_bytes + (sparse == 1 ? (size_t)h->P.A * sizeof(Act64) : 0);
 #define S64Q(DYN, PT, SP)                                                                                             \
     set_kname(h, "k_sweep64", (int)DYN, tname<PI_T>(), off32, (bool)PT, (bool)SP);                                    \
