@@ -3356,12 +3356,12 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
     // bands of the tile list: an XCD's working set is three axis-0 rows x (its share of axis 1 + position reach) x band rows x
     // V1 floats.  Round 3 sized the bands for 1.5 MB of the 4 MB L2 (C3: 2 bands, C4: 3); measured on the balanced schedule
     // of round 4, ONE band is fastest on both (C3 2.77 against 2.91 ms, C4 19.13 against 19.30 ms; profiles/r04_launch_order.log)
-    // -- the sweep is not bound by what the bands save -- but C4's single band moved 17.1 GB through the L2s instead of 9.8
-    // (3.6x instead of 2.1x the algorithmic bytes, for 1 % of time): bands are cut where the working set exceeds ~3.6 MB
-    // of the 4 MB L2 (C3: one band of 2 MB, C4: two of 3 MB).
+    // -- the sweep is not bound by what the bands save -- but the bytes it moves through the L2s are: C4 with 1 / 2 / 3 / 4 / 6
+    // bands: 17.1 / 15.3 / 14.3 / 11.6 / 13.3 GB per launch at 19.1 / 18.9 / 19.0 / 18.9 / 19.1 ms
+    // (profiles/r04_c4_bands_traffic.log).  2.2 MB of working set per band gives C3 its one band (2 MB) and C4 four.
     const int n1c = (P.dim[1] + 7) / 8 + 3;
     const double per_row = 3.0 * n1c * (double)L.V1 * 4.0;
-    const int band_rows = std::max(L.TV0, (int)(3.6e6 / per_row) - (summary[0] ? 12 : 0));
+    const int band_rows = std::max(L.TV0, (int)(2.2e6 / per_row) - (summary[0] ? 12 : 0));
     int nbands = std::max(1, std::min(ntr, (L.V0 + band_rows - 1) / band_rows));
     if (ovr("BANDS") && atoi(ovr("BANDS")) > 0) nbands = std::min(ntr, atoi(ovr("BANDS")));  // (experiments: the launch order only)
     h->lean4_bands = nbands;
