@@ -3361,7 +3361,7 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
     // (profiles/r04_c4_bands_traffic.log).  2.2 MB of working set per band gives C3 its one band (2 MB) and C4 four.
     const int n1c = (P.dim[1] + 7) / 8 + 3;
     const double per_row = 3.0 * n1c * (double)L.V1 * 4.0;
-    const int band_rows = std::max(L.TV0, (int)(2.2e6 / per_row) - (summary[0] ? 12 : 0));
+    const int band_rows = std::max(8, (int)(2.2e6 / per_row) - (summary[0] ? 12 : 0));  // (bands are ranges of the tile LIST: no need to hold a whole tile's rows)
     int nbands = std::max(1, std::min(ntr, (L.V0 + band_rows - 1) / band_rows));
     if (ovr("BANDS") && atoi(ovr("BANDS")) > 0) nbands = std::min(ntr, atoi(ovr("BANDS")));  // (experiments: the launch order only)
     h->lean4_bands = nbands;
