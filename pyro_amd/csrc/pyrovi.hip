@@ -2790,7 +2790,7 @@ static const char* const OVERRIDE_KEYS[] = {
     "TUNE",        // 0: no timed candidate sweeps at create (first candidate that fits)
     "LDS_KB",      // LDS budget of the lean window
     "DMA16",       // 0: 4-byte window DMA
-    "NO_RS64", "NO_TBTILE", "NO_XCD", "XCD64", "NO_SPLIT_FINISH",   // layout / launch details of the lean and float64 sweeps
+    "NO_RS64", "NO_TBTILE", "NO_XCD", "XCD64", "NO_SPLIT_FINISH", "SPLIT_FINISH",   // layout / launch details of the lean and float64 sweeps
     "NO_LEAN",     // float32: skip the LDS-window kernel (plain-gather k_sweep_fast)
     "NO_FAST",     // float32: float64 dynamics with float32 storage (k_sweep<float>)
     "NO_SWEEP64",  // float64: the operation-for-operation kernel k_sweep instead of k_sweep64
@@ -2802,6 +2802,7 @@ static const char* const OVERRIDE_KEYS[] = {
     "XCD_CHUNK",   // 4-D float64 sweep: rows of axis 0 per chunk dealt round-robin to the XCDs (0: one contiguous eighth per XCD)
     "BANDS",       // 4-D lean sweep launch order: bands of the tile list per XCD pass (default: sized for the L2)
     "TABLES",      // lean sweep per-node coefficient tables: 0 per-node arrays, 1 factorised where the dynamics allow
+    "DEFER",       // 0: the 2-D float32 sweep keeps its in-kernel ticket / k_sweep_finish per sweep instead of the deferred fold
     "MULTI",       // 0: one launch per sweep also where a batch could run as ONE multi-sweep launch (k_sweep64m)
     "PERSIST",     // 4-D lean sweep: 1 persistent workgroups over strided tile lists, 0 one workgroup per tile
     "PERSIST_WGS", // ... at most this many of them per CU
@@ -2964,7 +2965,7 @@ static void dev_release(pvi_problem* h, void* p) {
     (void)hipFree(p);
 }
 
-static int launch_sweep(pvi_problem* h, int src, double alpha, hipStream_t st, int k, double tol);
+static int launch_sweep(pvi_problem* h, int src, double alpha, hipStream_t st, int k, double tol, int deferred = 0);
 
 static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats) {
     const DevP& P = h->P;
@@ -4720,7 +4721,8 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         if (h->lean_ok && !h->force_exact) {
             const float al = (float)alpha;
             sc.nblocks = h->lean_grid.x;
-            sc.split_finish = (sc.nblocks >= 16384u && !ovr("NO_SPLIT_FINISH")) ? 1 : 0;
+            if (sc.split_finish != 2)
+                sc.split_finish = ((sc.nblocks >= 16384u || ovr_is("SPLIT_FINISH", 1)) && !ovr("NO_SPLIT_FINISH")) ? 1 : 0;
 #define LEAN3(DYN, U, NP) LEAN4(DYN, U, NP, 0)
 #define LEAN4(DYN, U, NP, RSK)                                                                                      \
     {                                                                                                               \
@@ -4732,7 +4734,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         }                                                                                                           \
         hipLaunchKernelGGL(kfn, h->lean_grid, h->lean_block, h->lean_lds, st, h->P, h->LP, h->F.act, h->LP.actc, Jin, Jout, pi, al, \
                            sc);                                                                                     \
-        if (sc.split_finish) hipLaunchKernelGGL(k_sweep_finish, 1, STAT_SHARDS, 0, st, sc);                         \
+        if (sc.split_finish == 1) hipLaunchKernelGGL(k_sweep_finish, 1, STAT_SHARDS, 0, st, sc);                    \
     }
 #define LEAN(DYN)                                                  \
     if (h->LP.lsplit == 0) {                                       \
@@ -4973,7 +4975,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     return PVI_OK;
 }
 
-static int launch_sweep(pvi_problem* h, int src, double alpha, hipStream_t st, int k, double tol) {
+static int launch_sweep(pvi_problem* h, int src, double alpha, hipStream_t st, int k, double tol, int deferred) {
     SweepCtl sc;
     sc.ctrl = h->ctrl;
     sc.slot = h->slots + (size_t)STAT_WORDS * k;
@@ -4981,7 +4983,7 @@ static int launch_sweep(pvi_problem* h, int src, double alpha, hipStream_t st, i
     sc.tol = tol;
     sc.k = k;
     sc.nblocks = 0;
-    sc.split_finish = 0;
+    sc.split_finish = deferred ? 2 : 0;  // (2: the 2-D lean sweep folds the previous sweep's statistics itself)
     sc.xcd_remap = 0;
     if (h->d.dtype == PVI_F64)
         return h->pi_size == 1 ? launch_sweep_t<double, unsigned char>(h, src, alpha, st, sc)
@@ -5076,10 +5078,23 @@ extern "C" int pvi_sweep(pvi_handle h, int32_t max_sweeps, double alpha, double 
             int rc = launch_multi64(h, src, alpha, tol, nb);
             if (rc) return rc;
         } else {
+            // 2-D float32 LDS-window sweep: deferred fold -- sweep k folds sweep k - 1, one k_sweep_finish for the batch's last
+            const bool deferred = h->d.dtype == PVI_F32 && h->lean_ok && !h->lean4_ok && !h->force_exact && !h->spline &&
+                                  !ovr_is("DEFER", 0);
             for (int k = 0; k < nb; ++k) {
-                int rc = launch_sweep(h, src, alpha, h->stream, k, tol);
+                int rc = launch_sweep(h, src, alpha, h->stream, k, tol, deferred ? 1 : 0);
                 if (rc) return rc;
                 src ^= 1;
+            }
+            if (deferred) {
+                SweepCtl sc;
+                memset(&sc, 0, sizeof(sc));
+                sc.ctrl = h->ctrl;
+                sc.slot = h->slots + (size_t)STAT_WORDS * (nb - 1);
+                sc.result = h->results + 4 * (nb - 1);
+                sc.tol = tol;
+                sc.k = nb - 1;
+                hipLaunchKernelGGL(k_sweep_finish, 1, STAT_SHARDS, 0, h->stream, sc);
             }
         }
         HIPCHK(hipGetLastError());

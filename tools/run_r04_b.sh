@@ -1,9 +1,4 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out
-L=gpurun_out/r04_final_check.log; : > $L
-timeout 300 python tools/tools_time.py c4 10 2>&1 | grep -E "TIME|nodes|rror" | cut -c1-400 >> $L
-timeout 300 python tools/tools_time.py c3 40 2>&1 | grep -E "TIME|rror" >> $L
-timeout 300 python tools/tools_time.py c4 10 2>&1 | grep -E "TIME|rror" >> $L
-timeout 300 python tools/tools_time.py c3 40 2>&1 | grep -E "TIME|rror" >> $L
-bash tools/tools_traffic_quick.sh c4 2>&1 | grep -E "TRAFFIC|rror" >> $L
-cat $L
+timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "config1 or c2_solve or variants_agree or full_size_c2 or north_star or edge_cases or class_surface or lowdef or demo or two_ranks or sharded_driver" > gpurun_out/r04_deferred_tests.log 2>&1
+grep -E "passed|failed|Error|assert" gpurun_out/r04_deferred_tests.log | tail -8
