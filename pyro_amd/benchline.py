@@ -65,7 +65,7 @@ def compact_line(full, full_path=None):
         out["converged"] = {k: _r(cv.get(k)) for k in ("tol", "sweeps_f32", "sweeps_f64", "rel_err", "max_transient_rel_err",
                                                        "seconds", "error") if k in cv}
     tok = dict(t.split("=", 1) for t in str(full.get("kernel_path", "")).split() if "=" in t)
-    out["kernel_path"] = " ".join("%s=%s" % (k, tok[k]) for k in ("path", "tile", "block", "lds_bytes", "mapping", "sparse", "persist")
+    out["kernel_path"] = " ".join("%s=%s" % (k, tok[k]) for k in ("path", "tile", "block", "lds_bytes", "mapping", "sparse")
                                   if k in tok)
     sec = {}
     for name, f in (full.get("secondary") or {}).items():

@@ -2797,15 +2797,12 @@ static const char* const OVERRIDE_KEYS[] = {
     "SPARSE", "PATCH",         // 4-D float64 / exact-float32 sweeps: walk over validity masks, 8x8 patch mapping
     "NO_PACK",     // table tier: sweep the raw tables instead of the packed records
     "SPLINE_CHUNK",            // spline mode: rows per chunk of the substitution passes
-    "WIN",         // 4-D lean sweep window layout: 0 single floats + ds_read2_b32, 1 position-paired + ds_read_b64, 2 position quads + ds_read_b128
-    "RSMOD",       // quad window: residue of the row pitch modulo 16 slots
+    "WIN",         // 0: no LDS-window kernel for 4-D float32 sweeps (plain-gather k_sweep_fast)
     "XCD_CHUNK",   // 4-D float64 sweep: rows of axis 0 per chunk dealt round-robin to the XCDs (0: one contiguous eighth per XCD)
     "BANDS",       // 4-D lean sweep launch order: bands of the tile list per XCD pass (default: sized for the L2)
     "TABLES",      // lean sweep per-node coefficient tables: 0 per-node arrays, 1 factorised where the dynamics allow
     "DEFER",       // 0: the 2-D float32 sweep keeps its in-kernel ticket / k_sweep_finish per sweep instead of the deferred fold
     "MULTI",       // 0: one launch per sweep also where a batch could run as ONE multi-sweep launch (k_sweep64m)
-    "PERSIST",     // 4-D lean sweep: 1 persistent workgroups over strided tile lists, 0 one workgroup per tile
-    "PERSIST_WGS", // ... at most this many of them per CU
 };
 static std::vector<std::pair<std::string, std::string>> g_overrides;
 static std::mutex g_override_mu;
@@ -2864,11 +2861,6 @@ struct pvi_problem {
     int lean4_block = 512, lean4_rsk = 0, lean4_bands = 1, lean4_tables = 0;
     void* lean4_tiles = nullptr;  // [grid] Lean4Tile, launch order
     int lean4_stage = 2;          // actions whose gathers are in flight together (sweep_lean4.inc)
-    int lean4_quad = 0;           // 1: quad window (k_sweep_lean4q): tiles cut where either position corner steps
-    int lean4_persist = 0;        // 1: persistent workgroups (k_sweep_lean4p), each sweeping a strided list of tiles
-    unsigned lean4_pgrid = 0;     // ... and how many of them are launched (resident workgroups, a multiple of 8)
-    void* lean4_dblocks = nullptr;     // DevP + Lean4P in device memory for the persistent kernel
-    bool lean4_dblocks_stale = true;
     int lean4_ptab_inv = 0;       // bit 0 / 1: the (position node, action) table does not depend on axis 0 / 1
     long long lean4_ptab_groups = 0;
     char lean4_cands[960] = "";  // the timed tile shapes of set-up: rows x columns : ms
@@ -3090,45 +3082,8 @@ static int launch_lean4_t(pvi_problem* h, const float* Jin, float* Jout, float a
         hipLaunchKernelGGL(kfn, dim3(h->lean4_grid), dim3(h->lean4_block), h->lean4_lds, st, h->P, L, Jin, Jout, pi, alpha, \
                            sc, (const float*)L.ptab, (const Lean4Tile*)h->lean4_tiles);                                \
     }
-    // persistent form: as many workgroups as are resident (occupancy of THIS kernel with this block size and window), a
-    // multiple of 8 so that workgroup b and the tiles b + k grid it sweeps stay on XCD b % 8
-#define L4P(KFN)                                                                                                       \
-    {                                                                                                                  \
-        auto kfn = KFN;                                                                                                \
-        if (h->lean4_lds > 48 * 1024)                                                                                  \
-            HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PVI_LDS_MAX));    \
-        if (!h->lean4_pgrid) {                                                                                         \
-            int per_cu = 0, ncu = 0;                                                                                   \
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kfn, h->lean4_block, h->lean4_lds)); \
-            HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device));                     \
-            if (ovr("PERSIST_WGS") && atoi(ovr("PERSIST_WGS")) > 0) per_cu = std::min(per_cu, atoi(ovr("PERSIST_WGS"))); \
-            unsigned g = (unsigned)std::max(1, per_cu) * (unsigned)std::max(8, ncu);                                   \
-            g = std::min(g & ~7u, (h->lean4_grid + 7u) & ~7u);                                                         \
-            h->lean4_pgrid = std::max(8u, g);                                                                          \
-        }                                                                                                              \
-        if (!h->lean4_dblocks) {  /* the two parameter blocks in device memory (read through the constant cache) */  \
-            HIPCHK(hipMalloc(&h->lean4_dblocks, sizeof(DevP) + sizeof(Lean4P)));                                       \
-            h->dev_allocs.push_back(h->lean4_dblocks);                                                                 \
-            h->lean4_dblocks_stale = true;                                                                             \
-        }                                                                                                              \
-        if (h->lean4_dblocks_stale) {                                                                                  \
-            HIPCHK(hipMemcpyAsync(h->lean4_dblocks, &h->P, sizeof(DevP), hipMemcpyHostToDevice, st));                  \
-            HIPCHK(hipMemcpyAsync((char*)h->lean4_dblocks + sizeof(DevP), &L, sizeof(Lean4P), hipMemcpyHostToDevice, st)); \
-            HIPCHK(hipStreamSynchronize(st));  /* (the sources are host structures that change with the next candidate) */ \
-            h->lean4_dblocks_stale = false;                                                                            \
-        }                                                                                                              \
-        hipLaunchKernelGGL(kfn, dim3(h->lean4_pgrid), dim3(h->lean4_block), h->lean4_lds, st,                          \
-                           (const DevP*)h->lean4_dblocks, (const Lean4P*)((char*)h->lean4_dblocks + sizeof(DevP)), Jin, Jout, pi, \
-                           alpha, sc, (const float*)L.ptab, (const Lean4Tile*)h->lean4_tiles, h->lean4_grid);          \
-    }
 #define L4(DYN)                                   \
-    if (h->lean4_quad) { /* (opt-in experiment family: its timed candidates launch the kernel itself) */ \
-        if (!probe) set_kname(h, "k_sweep_lean4q", (int)DYN, tname<PI_T>()); \
-        L4K((k_sweep_lean4q<DYN, PI_T>))          \
-    } else if (h->lean4_persist) {                \
-        if (!probe) set_kname(h, "k_sweep_lean4p", (int)DYN, tname<PI_T>()); \
-        L4P((k_sweep_lean4p<DYN, PI_T>))          \
-    } else if (probe)                             \
+    if (probe)                                    \
         L4K((k_sweep_lean4_probe<DYN, PI_T>))     \
     else {                                        \
         set_kname(h, "k_sweep_lean4", (int)DYN, tname<PI_T>()); \
@@ -3142,7 +3097,6 @@ static int launch_lean4_t(pvi_problem* h, const float* Jin, float* Jout, float a
     }
 #undef L4
 #undef L4K
-#undef L4P
     hipLaunchKernelGGL(k_sweep_finish, 1, STAT_SHARDS, 0, st, sc);
     HIPCHK(hipGetLastError());
     return PVI_OK;
@@ -3218,7 +3172,6 @@ static void lean4_schedule(int R, int N1, int ntr, int nbands, std::vector<unsig
 
 struct Lean4Cand {
     int cap, w, wmax;  // rows cap, workgroup threads, widest tile
-    int quad = 0;      // 1: quad window (wmax = columns cap of the step-aligned column pieces)
 };
 // the tiling a create of this process chose for a problem shape (device, dynamics, dims, actions, rows, dt, velocity box):
 // a second handle of the same shape -- the float32 / float64 pair of a convergence check, the pieces of a shard, a bench
@@ -3227,51 +3180,17 @@ static std::map<std::string, Lean4Cand> g_lean4_choice;
 static std::mutex g_lean4_choice_mu;
 
 // one candidate tiling: tile lists, window boxes, row pitch, schedule.  rc 0 = usable, 1 = does not fit, < 0 error.
-// quad: the quad-window kernel -- tiles are row piece x COLUMN piece (both cut where the position corner of their axis steps,
-// the column pieces from pt1 per index of axis 1, at most `wmax` columns), the tile list is per position node.
 static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int threads, int wmax, size_t lds_budget, int* narrower = nullptr,
-                     int quad = 0, const std::vector<int2>* pt1 = nullptr, int sub_r0 = 0, int sub_rows = -1) {
-    // quad: 0 pair window, 1 quad window with step-aligned column pieces (one plane), 2 quad window over the pair window's
-    // tiles (free column splits: up to three planes)
-    const bool quad_cols = quad == 1;
+                     int sub_r0 = 0, int sub_rows = -1) {
     const DevP& P = h->P;
     Lean4P& L = h->L4;
     const int rows = P.row_end - P.row_begin;
     if (threads > 512 || threads < 64 || (threads & 63)) return 1;
-    std::vector<std::vector<int4>> per;
+    std::vector<std::vector<int4>> per((size_t)rows);
     int ntr = 1, tv0 = 1, tv1 = 1;
-    if (!quad_cols) {
-        per.resize((size_t)rows);
-        for (int r = 0; r < rows; ++r) {
-            lean4_row_tiles(pt0, P.row_begin + r, P.dim[2], P.dim[3], cap, threads, wmax, per[(size_t)r]);
-            ntr = std::max(ntr, (int)per[(size_t)r].size());
-        }
-    } else {
-        if (!pt1) return 1;
-        // row pieces per owned row of axis 0, column pieces per index of axis 1; a tile = (row piece, column piece)
-        std::vector<std::vector<int2>> rp((size_t)rows), cp((size_t)P.dim[1]);
-        int nr = 1, nc = 1;
-        for (int r = 0; r < rows; ++r) {
-            lean4_row_pieces(pt0, P.row_begin + r, P.dim[2], cap, rp[(size_t)r]);
-            nr = std::max(nr, (int)rp[(size_t)r].size());
-        }
-        for (int i1 = 0; i1 < P.dim[1]; ++i1) {
-            lean4_row_pieces(*pt1, i1, P.dim[3], wmax, cp[(size_t)i1]);
-            nc = std::max(nc, (int)cp[(size_t)i1].size());
-        }
-        ntr = nr * nc;
-        per.resize((size_t)rows * P.dim[1]);
-        for (int r = 0; r < rows; ++r)
-            for (int i1 = 0; i1 < P.dim[1]; ++i1) {
-                auto& out = per[(size_t)r * P.dim[1] + i1];
-                out.assign((size_t)ntr, make_int4(0, 0, 0, 0));
-                for (size_t a = 0; a < rp[(size_t)r].size(); ++a)
-                    for (size_t b = 0; b < cp[(size_t)i1].size(); ++b) {
-                        const int2 rr = rp[(size_t)r][a], cc = cp[(size_t)i1][b];
-                        if (rr.y * cc.y > threads) return 1;  // (the caps of this candidate do not fit the workgroup)
-                        out[a * (size_t)nc + b] = make_int4(rr.x, rr.y, cc.x, cc.y);
-                    }
-            }
+    for (int r = 0; r < rows; ++r) {
+        lean4_row_tiles(pt0, P.row_begin + r, P.dim[2], P.dim[3], cap, threads, wmax, per[(size_t)r]);
+        ntr = std::max(ntr, (int)per[(size_t)r].size());
     }
     for (auto& v : per)
         for (auto& t : v) {
@@ -3282,9 +3201,6 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
     std::vector<int4> tlist(nlists * ntr, make_int4(0, 0, 0, 0));
     for (size_t r = 0; r < nlists; ++r)
         for (size_t k = 0; k < per[r].size(); ++k) tlist[r * ntr + k] = per[r][k];
-    L.tl_by = quad_cols ? 1 : 0;
-    L.quad = quad ? 1 : 0;
-    h->lean4_quad = quad;
     L.V0 = P.dim[2];
     L.V1 = P.dim[3];
     L.TV0 = tv0;
@@ -3320,25 +3236,11 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
     // worst, whatever the pitch -- the 4.4 clk of the conflict-free read is what counts.)
     int rs = std::max(4, (summary[1] + 3) & ~3);
     size_t lds = (size_t)std::max(summary[0], 1) * (size_t)rs * 8 + 256;
-    if (quad) {
-        // one plane of 16-byte slots; every non-empty tile must see ONE corner pair on either position axis
-        if (summary[4] > 1 || summary[2] > (quad_cols ? 2 : 4)) {
-            snprintf(h->lean_why, sizeof(h->lean_why), "quad window: a tile spans %d pair planes x %d position rows", summary[4], summary[2]);
-            return 1;
-        }
-        // Pitch congruent to the widest tile modulo 16 slots: a 16-lane group (one LDS pass of a ds_read_b128) that wraps from
-        // one tile row to the next then keeps walking consecutive bank groups.  RSMOD overrides the residue (experiments).
-        const int m = ovr("RSMOD") ? (atoi(ovr("RSMOD")) & 15) : (tv1 & 15);
-        rs = std::max(1, summary[1]);
-        while ((rs & 15) != m) ++rs;
-        lds = (size_t)std::max(summary[2] - 1, 1) * (size_t)std::max(summary[5], 1) * (size_t)rs * 16 + 256;  // (planes x rows: an upper bound)
-    }
     if (narrower) {  // the widest tile whose window lets as many workgroups onto a CU as the register budget does (24 waves)
         *narrower = 0;
         const size_t room = (size_t)160 * 1024 / (size_t)std::max(1, 1536 / threads) - 512;
-        if (quad != 1 && lds > room && summary[0] > 0) {
-            const size_t rows_w = quad ? (size_t)std::max(summary[2] - 1, 1) * (size_t)std::max(summary[5], 1) : (size_t)summary[0];
-            const int rs_fit = (int)((room - 256) / (quad ? 16 : 8) / rows_w) & ~3, w_fit = tv1 - (rs - rs_fit);
+        if (lds > room && summary[0] > 0) {
+            const int rs_fit = (int)((room - 256) / 8 / (size_t)summary[0]) & ~3, w_fit = tv1 - (rs - rs_fit);
             if (w_fit >= 12 && w_fit < tv1) *narrower = w_fit;
         }
     }
@@ -3351,8 +3253,6 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
     h->lean4_rsk = 0;
     h->lean4_lds = lds;
     h->lean4_block = threads;
-    h->lean4_pgrid = 0;
-    h->lean4_dblocks_stale = true;
     hipLaunchKernelGGL(k_lean4_off, grid_for(h->lean4_ptab_groups * 4), 256, 0, h->stream, L, h->lean4_ptab_groups);
     // bands of the tile list: an XCD's working set is three axis-0 rows x (its share of axis 1 + position reach) x band rows x
     // V1 floats.  Round 3 sized the bands for 1.5 MB of the 4 MB L2 (C3: 2 bands, C4: 3); measured on the balanced schedule
@@ -3434,7 +3334,6 @@ static int lean4_setup(pvi_problem* h) {
     int rc;
     L.owned = h->owned;
     h->lean4_stage = 2;
-    h->lean4_persist = ovr_is("PERSIST", 1) ? 1 : 0;
     L.ngroups = (P.A + 3) / 4;
     float2* tsp_node = nullptr;
     float* gx_node = nullptr;
@@ -3640,44 +3539,10 @@ static int lean4_setup(pvi_problem* h) {
             if (!cands.empty()) break;
         }
     }
-    // ---- quad-window family (round 4): tiles of one (p0, p1) corner pair each.  Opt-in (WIN=2): measured on C3 / C4 it does
-    // not beat the pair window (3.4 against 3.14 ms, 19.5 against 19.7 ms), so a default create does not spend
-    // set-up time on its candidates.
-    const bool want_quad = ovr_is("WIN", 2);
-    if (ovr_is("WIN", 3))  // quad planes over the pair window's own tile candidates (free column splits)
-        for (auto& c : cands) c.quad = 2;
-    std::vector<int2> hpt1;
-    if (want_quad) {
-        hpt1.resize((size_t)P.dim[1] * P.dim[3]);
-        HIPCHK(hipMemcpy(hpt1.data(), pt1, hpt1.size() * sizeof(int2), hipMemcpyDeviceToHost));
-        if (ovr_is("WIN", 2)) cands.clear();
-        if (ovr("TV0") && ovr("TV1")) {
-            const int c0 = atoi(ovr("TV0")), c1 = atoi(ovr("TV1"));
-            if (ovr_is("WIN", 2)) cands.push_back({c0, std::min(512, ((c0 * c1 + 63) / 64) * 64), c1, 1});
-        } else {
-            // the longest row piece / column piece of a middle position node: the natural tile; then a few caps below it
-            std::vector<int2> pc;
-            lean4_row_pieces(hpt0, P.row_begin + rows / 2, P.dim[2], P.dim[2], pc);
-            int lr = 1, lc = 1;
-            for (auto& q : pc) lr = std::max(lr, q.y);
-            lean4_row_pieces(hpt1, P.dim[1] / 2, P.dim[3], P.dim[3], pc);
-            for (auto& q : pc) lc = std::max(lc, q.y);
-            for (int threads : {512, 448, 384, 320, 256, 192, 128, 64}) {
-                for (int cc : {lc, (lc + 1) / 2}) {
-                    const int cap_c = std::max(1, std::min(cc, threads));
-                    const int cap_r = std::max(1, std::min(lr, threads / cap_c));
-                    if (cap_r * cap_c <= threads - 64 && threads > 64) continue;  // (a smaller workgroup holds these tiles)
-                    bool dup = false;
-                    for (auto& c : cands) dup = dup || (c.quad && c.cap == cap_r && c.wmax == cap_c && c.w == threads);
-                    if (!dup && cands.size() < 40) cands.push_back({cap_r, threads, cap_c, 1});
-                }
-            }
-        }
-    }
     // ---- the choice of an earlier create of the same problem shape in this process -------------------------------------------
     char key[256];
-    snprintf(key, sizeof(key), "%d/%d:%dx%dx%dx%d:A%d:rows%d:dt%.17g:lb%.17g,%.17g:ub%.17g,%.17g:lds%zu:win%d:p%d", h->device, h->d.dynamics_id,
-             P.dim[0], P.dim[1], P.dim[2], P.dim[3], P.A, rows, P.dt, P.lb[2], P.lb[3], P.ub[2], P.ub[3], budget, want_quad ? 2 : (ovr_is("WIN", 3) ? 3 : 1), h->lean4_persist);
+    snprintf(key, sizeof(key), "%d/%d:%dx%dx%dx%d:A%d:rows%d:dt%.17g:lb%.17g,%.17g:ub%.17g,%.17g:lds%zu", h->device, h->d.dynamics_id,
+             P.dim[0], P.dim[1], P.dim[2], P.dim[3], P.A, rows, P.dt, P.lb[2], P.lb[3], P.ub[2], P.ub[3], budget);
     bool from_cache = false;
     if (!ovr_is("TUNE", 0) && !(ovr("TV0") && ovr("TV1")) && !ovr_is("TUNE", 2)) {
         std::lock_guard<std::mutex> lk(g_lean4_choice_mu);
@@ -3707,7 +3572,7 @@ static int lean4_setup(pvi_problem* h) {
     int best = -1;
     for (size_t ci = 0; ci < cands.size(); ++ci) {
         int narrower = 0;
-        rc = lean4_try(h, hpt0, cands[ci].cap, cands[ci].w, cands[ci].wmax, budget, &narrower, cands[ci].quad, &hpt1, tune ? sub_r0 : 0,
+        rc = lean4_try(h, hpt0, cands[ci].cap, cands[ci].w, cands[ci].wmax, budget, &narrower, tune ? sub_r0 : 0,
                        tune ? sub_rows : -1);
         if (rc < 0) return rc;
         if (rc) continue;
@@ -3754,16 +3619,14 @@ static int lean4_setup(pvi_problem* h) {
             // (milliseconds of the timed rows scaled to the slab: comparable with a whole sweep)
             const float full = ms * (float)rows / (float)sub_rows;
             const size_t at = strlen(h->lean4_cands);
-            if (cands[ci].quad == 1)
-                snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, "%sq%dx%d/%d:%.2f", at ? "," : "", cands[ci].cap, cands[ci].wmax, cands[ci].w, full);
-            else if (cands[ci].wmax < V1)
+            if (cands[ci].wmax < V1)
                 snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, ",%d/%d/%d:%.2f", cands[ci].cap, cands[ci].w, cands[ci].wmax, full);
             else
                 snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, "%s%d/%d:%.2f", at ? "," : "", cands[ci].cap, cands[ci].w, full);
         }
         // (a narrower twin of a shape that is in the running: one more workgroup per CU may pay for the extra window halo)
-        if (narrower && cands[ci].quad != 1 && cands[ci].wmax == V1 && ms < 1.1f * best_ms && cands.size() < 48)
-            cands.push_back({cands[ci].cap, cands[ci].w, narrower, cands[ci].quad});
+        if (narrower && cands[ci].wmax == V1 && ms < 1.1f * best_ms && cands.size() < 48)
+            cands.push_back({cands[ci].cap, cands[ci].w, narrower});
         if (ms < 0.95f * best_ms) {  // a later candidate must win by 5 %: within the timing noise the choice stays put, so the
             best_ms = ms;            // shape (and with it the committed counter passes) is the same from run to run
             best = (int)ci;
@@ -3771,8 +3634,7 @@ static int lean4_setup(pvi_problem* h) {
     }
     if (best < 0) return give_up(h->lean_why[0] ? h->lean_why : "no tile shape fits the LDS budget");
     if (tune) {
-        if ((rc = lean4_try(h, hpt0, cands[(size_t)best].cap, cands[(size_t)best].w, cands[(size_t)best].wmax, budget, nullptr,
-                            cands[(size_t)best].quad, &hpt1)))
+        if ((rc = lean4_try(h, hpt0, cands[(size_t)best].cap, cands[(size_t)best].w, cands[(size_t)best].wmax, budget, nullptr)))
             return rc < 0 ? rc : give_up("tile shape lost");
         // the timed sweeps wrote into the second J buffer, pi and the control block
         HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream));
@@ -4527,9 +4389,9 @@ static int describe_impl(pvi_handle h, char* buf, int32_t n) {
         // win=1: position-paired window + ds_read_b64 (sweep_lean4.inc); tables: bit d set = the displacement table does
         // not span axis d; rowpieces / bands: the step-aligned row pieces of axis 2 and their grouping in the launch order
         snprintf(buf, (size_t)n, "path=lean tile=%dx%d grid=%ux1x1 block=%d pw1=%d lds_bytes=%zu lsplit=0 tb_tile=1 dma16=0 npt=1 "
-                 "reach=0 opmag=0 sparse=0 win=%d tables=%d ptab=%d gx=%s stage=%d persist=%d pgrid=%u tiles_per_plane=%d bands=%d cands=%s note=%s", h->L4.TV0, h->L4.TV1,
-                 h->lean4_grid, h->lean4_block, h->L4.RS, h->lean4_lds, h->lean4_quad ? 1 + h->lean4_quad : 1, h->lean4_tables, h->lean4_ptab_inv, h->L4.gx ? "node" : "axes", h->lean4_stage,
-                 h->lean4_persist, h->lean4_pgrid, h->L4.ntr, h->lean4_bands, h->lean4_cands[0] ? h->lean4_cands : "-", h->lean_why);
+                 "reach=0 opmag=0 sparse=0 win=1 tables=%d ptab=%d gx=%s stage=%d tiles_per_plane=%d bands=%d cands=%s note=%s", h->L4.TV0, h->L4.TV1,
+                 h->lean4_grid, h->lean4_block, h->L4.RS, h->lean4_lds, h->lean4_tables, h->lean4_ptab_inv, h->L4.gx ? "node" : "axes", h->lean4_stage,
+                 h->L4.ntr, h->lean4_bands, h->lean4_cands[0] ? h->lean4_cands : "-", h->lean_why);
         return PVI_OK;
     }
     snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d npt=%d reach=%d opmag=%d sparse=%d win=0 tables=0 note=%s",

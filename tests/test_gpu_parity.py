@@ -409,19 +409,13 @@ def test_f32_kernel_variants_agree(name, variants):
                      ("lean_win1", {"PVI_WIN": "1"}), ("lean_tab0", {"PVI_WIN": "1", "PVI_TABLES": "0"}),
                      ("lean_tab1", {"PVI_WIN": "1", "PVI_TABLES": "1"}), ("lean_noxcd", {"PVI_WIN": "1", "PVI_NO_XCD": "1"}),
                      ("lean_shape", {"PVI_WIN": "1", "PVI_TV0": "3", "PVI_TV1": "7"}),
-                     # round 4: persistent workgroups over strided tile lists, and one tile per workgroup
-                     ("lean_persist", {"PVI_WIN": "1", "PVI_PERSIST": "1"}), ("lean_persist1", {"PVI_WIN": "1", "PVI_PERSIST": "1", "PVI_PERSIST_WGS": "1"}),
-                     ("lean_persist_shape", {"PVI_WIN": "1", "PVI_PERSIST": "1", "PVI_TV0": "3", "PVI_TV1": "7"}),
-                     ("lean_nopersist", {"PVI_WIN": "1", "PVI_PERSIST": "0"}),
-                     # round 4: quad window (tiles of one position-corner quad, ds_read_b128), two tile shapes, another pitch residue
-                     ("lean_quad", {"PVI_WIN": "2"}), ("lean_quad_shape", {"PVI_WIN": "2", "PVI_TV0": "3", "PVI_TV1": "4"}),
-                     ("lean_quad_rsmod", {"PVI_WIN": "2", "PVI_RSMOD": "1", "PVI_NO_XCD": "1"}),
-                     # ... and quad planes over the pair window's own tiles (free column splits: several planes per window)
-                     ("lean_quad3", {"PVI_WIN": "3"}), ("lean_quad3_shape", {"PVI_WIN": "3", "PVI_TV0": "3", "PVI_TV1": "7"}),
+                     # round 4: other bands of the launch order (the persistent and quad-window kernels of this round were
+                     # measured, lost and removed: DESIGN.md 4.2b)
+                     ("lean_bands2", {"PVI_WIN": "1", "PVI_BANDS": "2"}),
                      ("fast", {"PVI_NO_LEAN": "1"}),
                      ("exact32", {"PVI_NO_FAST": "1"})]:
         for k in ("PVI_LSPLIT", "PVI_NO_LEAN", "PVI_NO_FAST", "PVI_NPT", "PVI_WIN", "PVI_TABLES", "PVI_NO_XCD", "PVI_TV0", "PVI_TV1",
-                  "PVI_PERSIST", "PVI_PERSIST_WGS", "PVI_RSMOD"):
+                  "PVI_BANDS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -454,18 +448,12 @@ def test_f32_kernel_variants_agree(name, variants):
     if four_d:
         # ... while the round-3 kernel splits every operand into integer + fraction in float64 at set-up and takes the arm too.
         # Whatever the coefficient tables, the launch order or the tile shape: the same bits.
-        for tag in ("lean", "lean_win1", "lean_tab0", "lean_tab1", "lean_noxcd", "lean_shape", "lean_persist", "lean_persist1",
-                    "lean_persist_shape", "lean_nopersist"):
+        for tag in ("lean", "lean_win1", "lean_tab0", "lean_tab1", "lean_noxcd", "lean_shape", "lean_bands2"):
             assert path_of(outs[tag][2]) == "path=lean" and "win=1" in outs[tag][2], (tag, outs[tag][2])
             assert np.array_equal(outs[tag][0], outs["lean_win1"][0]) and np.array_equal(outs[tag][1], outs["lean_win1"][1]), (tag, outs[tag][2])
         assert "tables=0" in outs["lean_tab0"][2] and "gx=node" in outs["lean_tab0"][2], outs["lean_tab0"][2]
         assert "tile=3x" in outs["lean_shape"][2], outs["lean_shape"][2]       # (columns are evened out over the tiles)
-        for tag in ("lean_quad", "lean_quad_shape", "lean_quad_rsmod", "lean_quad3", "lean_quad3_shape"):     # the same arithmetic per cell: the same bits
-            assert path_of(outs[tag][2]) == "path=lean" and ("win=3" if "quad3" in tag else "win=2") in outs[tag][2], (tag, outs[tag][2])
-            assert "kernel=k_sweep_lean4q<" in outs[tag][2], (tag, outs[tag][2])
-            assert np.array_equal(outs[tag][0], outs["lean_win1"][0]) and np.array_equal(outs[tag][1], outs["lean_win1"][1]), (tag, outs[tag][2])
-        assert "persist=1" in outs["lean_persist"][2] and "kernel=k_sweep_lean4p<" in outs["lean_persist"][2], outs["lean_persist"][2]
-        assert "persist=0" in outs["lean_nopersist"][2] and "kernel=k_sweep_lean4<" in outs["lean_nopersist"][2], outs["lean_nopersist"][2]
+        assert "kernel=k_sweep_lean4<" in outs["lean"][2], outs["lean"][2]
         # its split displacement is the more accurate float32 form: at least as close to the float64 oracle as the others
         assert relerr(outs["lean_win1"][0], ref) <= max(relerr(outs["lean_nosplit"][0], ref), 5e-7), \
             (relerr(outs["lean_win1"][0], ref), relerr(outs["lean_nosplit"][0], ref))
