@@ -24,6 +24,18 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, int TV1, int RS,
     float acc = 0.f;
     for (int it = 0; it < iters; ++it) {
         const unsigned a = base + (unsigned)(it & 7) * SLOT;
+        if (SLOT == 10) {  // pair layout, (j3, j3 + 1) with ONE ds_read_b128 at an address that is only 8-byte aligned
+            v4f q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned ad = (a + (unsigned)u * (unsigned)(RS * SLOT)) / 10 * 8;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(q[u]) : "v"(ad));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += q[u].x * q[u].y + q[u].z * q[u].w;
+            continue;
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const unsigned ad = a + (unsigned)u * (unsigned)(RS * SLOT);
@@ -88,6 +100,12 @@ int main() {
         const int rs = tv1 == 64 ? 64 : (tv1 == 34 ? 66 : 49);
         run<9>("read2_b64", tv1, rs, -1, -1);
         run<9>("read2_b64", tv1, rs, 9, 41);
+    }
+    for (int tv1 : {64, 34, 17}) {
+        const int rs = tv1 == 64 ? 64 : (tv1 == 34 ? 66 : 49);
+        run<10>("b128@8", tv1, rs, -1, -1);
+        run<10>("b128@8", tv1, rs, 9, 41);
+        run<10>("b128@8", tv1, rs, 20, 20);
     }
     run<4>("b32", 64, 64, -1, -1);
     run<4>("b32", 34, 66, 9, 41);

@@ -1,15 +1,12 @@
 #!/bin/bash
-# A/B on one box: the library of the previous commit (pyro_amd/libpyrovi_prev.so, built by hand) against the current one
 cd /root/repo; mkdir -p gpurun_out
-L=gpurun_out/r04_ab.log; : > $L
-for rep in 1 2; do
-for lib in pyro_amd/libpyrovi_prev.so pyro_amd/libpyrovi.so; do
-  for w in "c3 200" "c4 40"; do
-    echo "== $lib $w" >> $L
-    PYROVI_LIB=/root/repo/$lib timeout 300 python tools/tools_time.py $w 2>&1 | grep -E "TIME|nodes|rror" | cut -c1-260 >> $L
-  done
+L=gpurun_out/r04_fill128.log; : > $L
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "variants_agree or cartpole or twolink" > gpurun_out/r04_fill128_tests.log 2>&1
+grep -E "passed|failed|Error|assert" gpurun_out/r04_fill128_tests.log | tail -5 >> $L
+for w in "c3 200" "c4 40"; do
+  echo "== $w" >> $L
+  timeout 300 python tools/tools_time.py $w 2>&1 | grep -E "TIME|rror" | cut -c1-300 >> $L
 done
-done
-echo "== ORDER=1 c3" >> $L
-timeout 300 python tools/tools_time.py c3 200 ORDER=1 2>&1 | grep -E "TIME|rror" >> $L
+bash tools/tools_ldsconf.sh c3 c3_f128 TV0=19 TV1=51 >> $L 2>&1
+bash tools/tools_ldsconf.sh c4 c4_f128 TV0=55 TV1=26 >> $L 2>&1
 cat $L
