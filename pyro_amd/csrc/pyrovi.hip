@@ -92,6 +92,7 @@ struct SweepCtl {
     unsigned nblocks;
     int split_finish;          // 1: the statistics are folded by k_sweep_finish after the sweep kernel (large grids)
     int xcd_remap;             // k_sweep64: contiguous logical block ranges per XCD
+    int regtab;                // k_sweep64m, 2-D, few actions: the per-action cells and costs stay in registers over the sweeps
 };
 
 // order-preserving encoding of doubles for integer atomicMax
@@ -521,6 +522,7 @@ __device__ inline void block_stats_f32_at(int* red, float j, float dmax, float n
 }
 
 // the workgroup's three maxima -> out[0..2] (plain stores by threads 0..2; the multi-sweep kernel's barrier publishes them)
+template <bool WRITE_THROUGH = false>
 __device__ inline void block_max3_store(double j, double dmax, double ndmin, double* out) {
     __shared__ double red3[3][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -536,7 +538,11 @@ __device__ inline void block_max3_store(double j, double dmax, double ndmin, dou
     if (threadIdx.x < 3) {
         double v = red3[threadIdx.x][0];
         for (int w = 1; w < nw; ++w) v = fmax(v, red3[threadIdx.x][w]);
-        out[threadIdx.x] = v;
+        if constexpr (WRITE_THROUGH)  // (an sc1 store: it leaves the XCD's L2 for memory, no release fence needed)
+            __hip_atomic_store((unsigned long long*)(out + threadIdx.x), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        else
+            out[threadIdx.x] = v;
     }
 }
 
@@ -962,6 +968,20 @@ __device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target)
     __syncthreads();
 }
 
+// The same barrier for data that is published WRITE-THROUGH (sc1 stores: they leave the XCD's L2 for memory) and read with
+// sc1 loads (which bypass the CU's L1): no L2 write-back, no invalidate -- the two fences are 1.7 us each
+// (MI355X_MICROARCH.md, inter-workgroup visibility: producer "sc1 payload -> asm vmcnt(0) -> flag", consumer "sc1 loads may
+// replace the acquire only when the producer stored sc1").  Every thread waits for its own stores to have left.
+__device__ __forceinline__ void grid_barrier_wt(unsigned* counter, unsigned target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+}
+
 // MULTI (round 4): the device form of the driver loops dynamicprogramming.py:265-314 for grids whose
 // workgroups are all resident.  ONE launch runs up to `nsweeps` backups: everything of a node that does not change between
 // sweeps (coordinates, position row, weights, dynamics prologue) stays in its thread's registers, J ping-pongs between the
@@ -1105,10 +1125,95 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
 #pragma unroll
             for (int i = 0; i < DOF; ++i) y[i] = (xn[i] - l0[i]) / (l1[i] - l0[i]);
         }
+        // ---- REGTAB (multi-sweep launch, 2-D grid, at most RT actions): what a cell needs from one sweep to the next is only
+        // J.  The cell of every action (offset of its lower corner, fraction along axis 1, in the box or not) and its cost
+        // G do not change, so they are formed ONCE, by the expressions of the loops below, and stay in registers; a sweep is
+        // then 2 A independent 16-byte loads -- ONE memory round trip instead of A / 4 dependent ones -- A bilinear sums and
+        // the argmin.  J is stored write-through and loaded with sc1 loads, so the barrier between two sweeps needs no L2
+        // write-back and no invalidate (grid_barrier_wt).  Same operations per cell in the same order: the same bits.
+        constexpr int RT = 12;
+        [[maybe_unused]] unsigned rt_off[RT];
+        [[maybe_unused]] double rt_y[RT], rt_G[RT];
+        [[maybe_unused]] unsigned rt_in = 0u;
+        [[maybe_unused]] bool regtab = false;
+        [[maybe_unused]] double jprev = 0.0;
+        if constexpr (MULTI && DOF == 1) {
+            regtab = sc.regtab != 0 && P.A <= RT;
+            if (regtab) {
+                jprev = Jin[self];
+#pragma unroll
+                for (int a = 0; a < RT; ++a) {
+                    rt_off[a] = 0u;
+                    rt_y[a] = 0.0;
+                    rt_G[a] = P.INF;
+                }
+                if (pos_in) {
+                    const unsigned base = (unsigned)((long long)(ci[0] - P.store_begin) * P.strd[0]);
+                    double tr[8];
+                    D::trig_from_tables(P, idx, tr);
+                    D dyn;
+                    dyn.init(P.c, x, tr);
+#pragma unroll
+                    for (int a = 0; a < RT; ++a) {
+                        if (a < P.A) {
+                            const Act64 ac = act64[a];
+                            double u[2] = {ac.u0, ac.u1}, acc[1];
+                            dyn.accel(u, acc);
+                            const double xa = acc[0] * P.dt + x[1];
+                            const bool in = !(xa < P.glo[1]) && !(xa > P.ghi[1]);
+                            double ya = 0.0;
+                            const int ca = interval_frac64(tab[1], P.dim[1], P.glo[1], P.inv_step[1], in ? xa : P.glo[1], ya);
+                            rt_off[a] = (base + (unsigned)ca) * 8u;
+                            rt_y[a] = ya;
+                            rt_in |= in ? (1u << a) : 0u;
+                            const double g = on_target ? 0.0 : (gx + ac.gu);
+                            rt_G[a] = (in && ac.aok != 0.0) ? g * P.dt : P.INF;
+                        }
+                    }
+                }
+            }
+        }
       for (int ks = 0;; ++ks) {  // (one trip unless MULTI)
         double best = P.INF;  // position row outside the box: every action costs INF + alpha*0, the first one wins
         int arg = 0;
-        if (pos_in) {
+        [[maybe_unused]] bool rt_done = false;
+        if constexpr (MULTI && DOF == 1) {
+            if (regtab) {
+                rt_done = true;
+                if (pos_in) {
+                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                    constexpr unsigned OOB = 0xffffffffu;  // beyond num_records: the hardware returns zeros without an access
+                    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Jin, 0, 0xfffffff0u, 0x00020000);
+                    const unsigned s0B = (unsigned)P.strd[0] * 8u;
+                    v4u r0[RT], r1[RT];
+#pragma unroll
+                    for (int a = 0; a < RT; ++a) {
+                        if (a < P.A) {  // (uniform)
+                            const unsigned vo = ((rt_in >> a) & 1u) ? rt_off[a] : OOB;
+                            r0[a] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 16);    // aux 16 = sc1: bypasses the CU's L1
+                            r1[a] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, s0B, 16);
+                        }
+                    }
+                    const double a0 = 1.0 - y[0];
+#pragma unroll
+                    for (int a = 0; a < RT; ++a) {
+                        if (a < P.A) {
+                            const double q00 = __hiloint2double((int)r0[a].y, (int)r0[a].x), q01 = __hiloint2double((int)r0[a].w, (int)r0[a].z);
+                            const double q10 = __hiloint2double((int)r1[a].y, (int)r1[a].x), q11 = __hiloint2double((int)r1[a].w, (int)r1[a].z);
+                            const double ya = rt_y[a], a1 = 1.0 - ya;
+                            const double Jt = q00 * a0 * a1 + q01 * a0 * ya + q10 * y[0] * a1 + q11 * y[0] * ya;
+                            const double Jn = ((rt_in >> a) & 1u) ? Jt : 0.0;
+                            const double q = rt_G[a] + alpha * Jn;
+                            if (a == 0 || q < best) {
+                                best = q;
+                                arg = a;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (pos_in && !rt_done) {
             int r0 = ci[0];
             if (r0 < P.store_begin || r0 + 1 >= P.store_end) {
                 halo_bad = true;
@@ -1382,9 +1487,17 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
         }
         if (halo_bad) atomicOr(&sc.ctrl->halo_err, 1);
         if (store_ok) {
-            Jout[self] = best;
+            double d;
+            if (rt_done) {  // write-through; the node's previous value is this thread's own last result
+                __hip_atomic_store((unsigned long long*)(Jout + self), (unsigned long long)__double_as_longlong(best), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                d = best - jprev;
+                jprev = best;
+            } else {
+                Jout[self] = best;
+                d = best - Jin[self];
+            }
             pi[o] = (PI_T)arg;
-            const double d = best - Jin[self];
             st_j = best;
             st_dmax = d;
             st_ndmin = -d;
@@ -1398,14 +1511,38 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
             // see multi64_applies) -- no atomics, no second round trip.  Two sets, alternating: a workgroup can run at most
             // one barrier ahead of the slowest reader.
             double* part = (double*)sc.slot + (size_t)(ks & 1) * 64 * 4;
-            block_max3_store(st_j, st_dmax, st_ndmin, part + 4 * blockIdx.x);
-            grid_barrier(&sc.ctrl->ticket, (unsigned)(ks + 1) * gridDim.x);
+            double v0 = -INFINITY, v1 = -INFINITY, v2 = -INFINITY;
+            if (rt_done) {
+                // REGTAB: J and the statistics went out write-through and are read with sc1 loads: nothing to fence.
+                // (Measured and not kept: arrival and statistics as ONE tagged 16-byte granule per value, polled by every
+                //  workgroup -- no counter, one round trip less on paper, the same 5.0 us per sweep on C1.)
+                block_max3_store<true>(st_j, st_dmax, st_ndmin, part + 4 * blockIdx.x);
+                grid_barrier_wt(&sc.ctrl->ticket, (unsigned)(ks + 1) * gridDim.x);
+                if (threadIdx.x < 64) {
+                    const int l = threadIdx.x;
+                    if (l < (int)gridDim.x) {  // (sc1 loads: they bypass the CU's L1, which may hold these words from two sweeps ago)
+                        auto ld = [&](int k) {
+                            return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)(part + 4 * l + k), __ATOMIC_RELAXED,
+                                                                                      __HIP_MEMORY_SCOPE_AGENT));
+                        };
+                        v0 = ld(0);
+                        v1 = ld(1);
+                        v2 = ld(2);
+                    }
+                }
+            } else {
+                block_max3_store(st_j, st_dmax, st_ndmin, part + 4 * blockIdx.x);
+                grid_barrier(&sc.ctrl->ticket, (unsigned)(ks + 1) * gridDim.x);
+                if (threadIdx.x < 64) {
+                    const int l = threadIdx.x;
+                    const bool has = l < (int)gridDim.x;
+                    v0 = has ? __builtin_nontemporal_load(part + 4 * l + 0) : -INFINITY;
+                    v1 = has ? __builtin_nontemporal_load(part + 4 * l + 1) : -INFINITY;
+                    v2 = has ? __builtin_nontemporal_load(part + 4 * l + 2) : -INFINITY;
+                }
+            }
             if (threadIdx.x < 64) {
                 const int l = threadIdx.x;
-                const bool has = l < (int)gridDim.x;
-                double v0 = has ? __builtin_nontemporal_load(part + 4 * l + 0) : -INFINITY;
-                double v1 = has ? __builtin_nontemporal_load(part + 4 * l + 1) : -INFINITY;
-                double v2 = has ? __builtin_nontemporal_load(part + 4 * l + 2) : -INFINITY;
                 v0 = wave_max(v0);
                 v1 = wave_max(v1);
                 v2 = wave_max(v2);
@@ -2802,6 +2939,7 @@ static const char* const OVERRIDE_KEYS[] = {
     "BANDS",       // 4-D lean sweep launch order: bands of the tile list per XCD pass (default: sized for the L2)
     "TABLES",      // lean sweep per-node coefficient tables: 0 per-node arrays, 1 factorised where the dynamics allow
     "DEFER",       // 0: the 2-D float32 sweep keeps its in-kernel ticket / k_sweep_finish per sweep instead of the deferred fold
+    "REGTAB",      // 0: the multi-sweep launch of 2-D grids recomputes the per-action cells every sweep (fence-based barrier)
     "MULTI",       // 0: one launch per sweep also where a batch could run as ONE multi-sweep launch (k_sweep64m)
 };
 static std::vector<std::pair<std::string, std::string>> g_overrides;
@@ -2891,6 +3029,7 @@ struct pvi_problem {
     bool spline = false;
     int multi64 = -1;         // multi-sweep launch of the float64 sweep (k_sweep64m): -1 not decided, 0 no, 1 yes
     char multi_why[96] = "";
+    int regtab64 = -1;            // the multi-sweep launches keep the per-action cells in registers (2-D, <= 12 actions)
     char kname[128] = "";     // the sweep kernel of the last launch, as a kernel trace prints it (spaces removed): pvi_describe `kernel=`
 };
 
@@ -4380,9 +4519,9 @@ static int describe_impl(pvi_handle h, char* buf, int32_t n) {
                        : h->okmask3 ? "fast3"
                        : (h->d.dynamics_id == PVI_DYN_TABLE ? (h->packed ? "table-packed" : "table") : "exact-f32");
     if (h->d.dtype == PVI_F64 && h->use64 && h->d.dynamics_id != PVI_DYN_TABLE) {
-        snprintf(buf, (size_t)n, "path=exact-f64v2 mapping=%s off32=%d sparse=%d inbox=%.4f multi=%d note=%s",
+        snprintf(buf, (size_t)n, "path=exact-f64v2 mapping=%s off32=%d sparse=%d inbox=%.4f multi=%d regtab=%d note=%s",
                  h->P.n == 4 ? (h->patch64 ? "patch8x8" : "line64") : "line64",
-                 (int)((unsigned long long)h->stored * 8ull < (1ull << 32)), h->sparse64, h->infrac64, h->multi64, h->multi_why);
+                 (int)((unsigned long long)h->stored * 8ull < (1ull << 32)), h->sparse64, h->infrac64, h->multi64, h->regtab64, h->multi_why);
         return PVI_OK;
     }
     if (h->lean4_ok) {
@@ -4847,6 +4986,7 @@ static int launch_sweep(pvi_problem* h, int src, double alpha, hipStream_t st, i
     sc.nblocks = 0;
     sc.split_finish = deferred ? 2 : 0;  // (2: the 2-D lean sweep folds the previous sweep's statistics itself)
     sc.xcd_remap = 0;
+    sc.regtab = 0;
     if (h->d.dtype == PVI_F64)
         return h->pi_size == 1 ? launch_sweep_t<double, unsigned char>(h, src, alpha, st, sc)
                                : launch_sweep_t<double, unsigned short>(h, src, alpha, st, sc);
@@ -4906,6 +5046,8 @@ static int launch_multi64(pvi_problem* h, int src, double alpha, double tol, int
     sc.nblocks = grid_for(h->owned);
     sc.split_finish = 0;
     sc.xcd_remap = (sc.nblocks >= 64u && !(ovr("XCD64") && !atoi(ovr("XCD64")))) ? 1 : 0;
+    sc.regtab = (h->P.n == 2 && h->P.A <= 12 && !ovr_is("REGTAB", 0)) ? 1 : 0;  // (12 = RT of sweep64_body)
+    h->regtab64 = sc.regtab;
     const void* kfn = h->pi_size == 1 ? multi64_kernel<unsigned char>(h->d.dynamics_id) : multi64_kernel<unsigned short>(h->d.dynamics_id);
     DevP P = h->P;
     const double* Jin = (const double*)h->J[src];

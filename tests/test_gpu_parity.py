@@ -1272,6 +1272,8 @@ def test_base_class_with_obstacles_over_torch_dist_comm(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,tol,extra", [("config1_pendulum_101x101x11", 0.1, {}),
                                             ("pendulum_demo_51x51x9", -1.0, {}),
+                                            ("pendulum_lowdef_41x21x3", -1.0, {}),      # a zone of on-target nodes (EPS = 1)
+                                            ("pendulum_21x21x5", -1.0, {}),
                                             ("cartpole_11p4x5", -1.0, {"PVI_PATCH": "0", "PVI_SPARSE": "0"})])
 def test_multi_sweep_launch_is_bit_identical(name, tol, extra, variants):
     """a batch of sweeps as ONE cooperative launch (k_sweep64m: per-node state in registers, ping-pong J, grid
@@ -1282,8 +1284,10 @@ def test_multi_sweep_launch_is_bit_identical(name, tol, extra, variants):
     p = oracle_problem(g, *case)
     alpha = float(g["alpha"]) if "alpha" in g.files else 1.0
     outs = {}
-    for tag, env in (("multi", {}), ("single", {"PVI_MULTI": "0"})):
-        for k in ("PVI_MULTI", "PVI_PATCH", "PVI_SPARSE"):
+    # "multi": on 2-D grids with few actions the per-action cells stay in registers and J travels write-through (REGTAB);
+    # "multi_fenced": the same launch recomputing them every sweep, with the fence-based barrier
+    for tag, env in (("multi", {}), ("multi_fenced", {"PVI_REGTAB": "0"}), ("single", {"PVI_MULTI": "0"})):
+        for k in ("PVI_MULTI", "PVI_PATCH", "PVI_SPARSE", "PVI_REGTAB"):
             variants.delenv(k)
         for k, v in {**extra, **env}.items():
             variants.setenv(k, v)
@@ -1294,10 +1298,29 @@ def test_multi_sweep_launch_is_bit_identical(name, tol, extra, variants):
         h.close()
     assert "multi=1" in outs["multi"][4] and "kernel=k_sweep64m<" in outs["multi"][4], outs["multi"][4]
     assert "multi=0" in outs["single"][4] and "kernel=k_sweep64<" in outs["single"][4], outs["single"][4]
-    assert outs["multi"][3] == outs["single"][3] == (618 if tol > 0 else 9)
-    for i in (0, 1, 5):
-        assert np.array_equal(outs["multi"][i], outs["single"][i]), i
-    assert np.array_equal(outs["multi"][2], outs["single"][2])          # the statistics of every sweep
+    two_d = len(p.levels) == 2
+    assert ("regtab=1" if two_d else "regtab=0") in outs["multi"][4], outs["multi"][4]
+    if two_d:   # the write-through hand-off between the sweeps, again and again, with a second handle sweeping beside it
+        for k in ("PVI_MULTI", "PVI_PATCH", "PVI_SPARSE", "PVI_REGTAB"):
+            variants.delenv(k)
+        noise = native_problem(p, dtype="float32")
+        noise.terminal_cost()
+        for rep in range(6):
+            h = native_problem(p, dtype="float64")
+            h.terminal_cost()
+            for _ in range(100):                     # (its own stream: small kernels coming and going on other CUs)
+                noise.sweep_async(alpha)
+            stats, n = h.sweep(700 if tol > 0 else 9, alpha, tol)
+            assert n == outs["single"][3] and np.array_equal(h.get_J(), outs["single"][0]) and np.array_equal(stats, outs["single"][2]), rep
+            h.close()
+        noise.synchronize()
+        noise.close()
+    assert "multi=1" in outs["multi_fenced"][4] and "regtab=0" in outs["multi_fenced"][4], outs["multi_fenced"][4]
+    for tag in ("multi", "multi_fenced"):
+        assert outs[tag][3] == outs["single"][3] == (618 if tol > 0 else 9), tag
+        for i in (0, 1, 5):
+            assert np.array_equal(outs[tag][i], outs["single"][i]), (tag, i)
+        assert np.array_equal(outs[tag][2], outs["single"][2]), tag          # the statistics of every sweep
 
 
 # ------------------------------------------------------------------------------- interpol_method = 'nearest'
