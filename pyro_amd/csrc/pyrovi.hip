@@ -93,6 +93,7 @@ struct SweepCtl {
     int split_finish;          // 1: the statistics are folded by k_sweep_finish after the sweep kernel (large grids)
     int xcd_remap;             // k_sweep64: contiguous logical block ranges per XCD
     int regtab;                // k_sweep64m, 2-D, few actions: the per-action cells and costs stay in registers over the sweeps
+    int win_bytes;             // ... and LDS bytes behind the level tables for the workgroup's window of J (0: gathers from memory)
 };
 
 // order-preserving encoding of doubles for integer atomicMax
@@ -1137,6 +1138,9 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
         [[maybe_unused]] unsigned rt_in = 0u;
         [[maybe_unused]] bool regtab = false;
         [[maybe_unused]] double jprev = 0.0;
+        [[maybe_unused]] int win_r0 = 0, win_n = 0;
+        [[maybe_unused]] bool win_ok = false;
+        [[maybe_unused]] double* win = nullptr;
         if constexpr (MULTI && DOF == 1) {
             regtab = sc.regtab != 0 && P.A <= RT;
             if (regtab) {
@@ -1147,8 +1151,28 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
                     rt_y[a] = 0.0;
                     rt_G[a] = P.INF;
                 }
+                // The workgroup's window of J: the rows of axis 0 its nodes' position rows touch (every thread's two rows lie
+                // within a few rows of its node's), whole rows.  Per sweep the window comes in ONCE, coalesced, and the 2 A
+                // gathers of a thread read LDS: 22 sc1 loads per thread -- 90 KB per workgroup through the L2, none of it
+                // shared in the L1 they bypass -- were 4 800 of the 12 500 cycles of a sweep on C1 (s_memtime stamps).
+                __shared__ int s_wr[2];
+                if (threadIdx.x == 0) {
+                    s_wr[0] = 0x7fffffff;
+                    s_wr[1] = -1;
+                }
+                __syncthreads();
                 if (pos_in) {
-                    const unsigned base = (unsigned)((long long)(ci[0] - P.store_begin) * P.strd[0]);
+                    atomicMin(&s_wr[0], ci[0]);
+                    atomicMax(&s_wr[1], ci[0] + 1);
+                }
+                __syncthreads();
+                win = (double*)(lr_lds + P.dim[1]);  // behind the level table of axis 1 (the only one in LDS on a 2-D grid)
+                win_r0 = s_wr[0];
+                win_n = s_wr[1] >= s_wr[0] ? (s_wr[1] - s_wr[0] + 1) * (int)P.strd[0] : 0;  // doubles
+                win_ok = win_n > 0 && (long long)win_n * 8 <= (long long)sc.win_bytes;
+                if (pos_in) {
+                    const unsigned base = win_ok ? (unsigned)((long long)(ci[0] - win_r0) * P.strd[0])
+                                                 : (unsigned)((long long)(ci[0] - P.store_begin) * P.strd[0]);
                     double tr[8];
                     D::trig_from_tables(P, idx, tr);
                     D dyn;
@@ -1173,6 +1197,11 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
                 }
             }
         }
+      // REGTAB: the statistics of sweep k are loaded behind sweep k's barrier but folded while the J loads of sweep k + 1 are in
+      // flight (one memory round trip for both); a sweep that turns out to come after the stop is dropped before it stores
+      [[maybe_unused]] double pv0 = -INFINITY, pv1 = -INFINITY, pv2 = -INFINITY;
+      [[maybe_unused]] bool pending = false;
+      __shared__ double folded[4];
       for (int ks = 0;; ++ks) {  // (one trip unless MULTI)
         double best = P.INF;  // position row outside the box: every action costs INF + alpha*0, the first one wins
         int arg = 0;
@@ -1180,12 +1209,21 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
         if constexpr (MULTI && DOF == 1) {
             if (regtab) {
                 rt_done = true;
-                if (pos_in) {
-                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                v4u r0[RT], r1[RT];
+                constexpr int WCH = 5;  // 16-byte chunks of the window per thread
+                v4u wv[WCH];
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Jin, 0, 0xfffffff0u, 0x00020000);
+                if (win_ok) {  // (block-uniform) the window: chunk c of thread t = doubles 2 (t + 256 c), 2 (t + 256 c) + 1
+                    const unsigned org = (unsigned)((long long)(win_r0 - P.store_begin) * P.strd[0]) * 8u;
+#pragma unroll
+                    for (int c = 0; c < WCH; ++c) {
+                        const int e = 2 * ((int)threadIdx.x + 256 * c);
+                        wv[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, e < win_n ? org + (unsigned)e * 8u : 0xffffffffu, 0, 16);
+                    }
+                } else if (pos_in) {
                     constexpr unsigned OOB = 0xffffffffu;  // beyond num_records: the hardware returns zeros without an access
-                    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Jin, 0, 0xfffffff0u, 0x00020000);
                     const unsigned s0B = (unsigned)P.strd[0] * 8u;
-                    v4u r0[RT], r1[RT];
 #pragma unroll
                     for (int a = 0; a < RT; ++a) {
                         if (a < P.A) {  // (uniform)
@@ -1194,6 +1232,57 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
                             r1[a] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, s0B, 16);
                         }
                     }
+                }
+                if (pending) {  // (uniform) the previous sweep's statistics: did it meet the tolerance?
+                    pending = false;
+                    if (threadIdx.x < 64) {
+                        pv0 = wave_max(pv0);
+                        pv1 = wave_max(pv1);
+                        pv2 = wave_max(pv2);
+                        if (threadIdx.x == 0) {
+                            folded[0] = pv0;
+                            folded[1] = pv1;
+                            folded[2] = -pv2;
+                            folded[3] = fmax(fabs(pv1), fabs(-pv2));
+                        }
+                    }
+                    __syncthreads();
+                    const double delta = folded[3];
+                    const bool stop = sc.tol >= 0.0 && delta <= sc.tol;
+                    if (blockIdx.x == 0 && threadIdx.x == 0) {
+                        double* res = sc.result + 4 * (ks - 1);
+                        res[0] = folded[0];
+                        res[1] = folded[1];
+                        res[2] = folded[2];
+                        res[3] = delta;
+                        sc.ctrl->k_done = ks;
+                        if (stop) sc.ctrl->done = 1;
+                    }
+                    if (stop) break;  // sweep ks - 1 was the last one: nothing of this sweep has been stored
+                }
+                if (win_ok) {
+                    // (a window of more than WCH x 512 doubles does not pass win_ok: see the host's win_bytes)
+#pragma unroll
+                    for (int c = 0; c < WCH; ++c) {
+                        const int e = 2 * ((int)threadIdx.x + 256 * c);
+                        if (e < win_n) win[e] = __hiloint2double((int)wv[c].y, (int)wv[c].x);
+                        if (e + 1 < win_n) win[e + 1] = __hiloint2double((int)wv[c].w, (int)wv[c].z);
+                    }
+                    __syncthreads();
+                    if (pos_in) {
+                        const int s0 = (int)P.strd[0];
+#pragma unroll
+                        for (int a = 0; a < RT; ++a) {
+                            if (a < P.A) {
+                                const double* w0 = win + (rt_off[a] >> 3);  // (a cell outside the box points at the window's start)
+                                const double q00 = w0[0], q01 = w0[1], q10 = w0[s0], q11 = w0[s0 + 1];
+                                r0[a] = (v4u){(unsigned)__double2loint(q00), (unsigned)__double2hiint(q00), (unsigned)__double2loint(q01), (unsigned)__double2hiint(q01)};
+                                r1[a] = (v4u){(unsigned)__double2loint(q10), (unsigned)__double2hiint(q10), (unsigned)__double2loint(q11), (unsigned)__double2hiint(q11)};
+                            }
+                        }
+                    }
+                }
+                if (pos_in) {
                     const double a0 = 1.0 - y[0];
 #pragma unroll
                     for (int a = 0; a < RT; ++a) {
@@ -1505,7 +1594,6 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
         if constexpr (!MULTI) {
             break;
         } else {
-            __shared__ double folded[4];
             // The statistics ride on the barrier: every workgroup stores its three maxima (plain stores, published by the
             // barrier's release), and behind the barrier every workgroup reads all of them (lane = workgroup: at most 64,
             // see multi64_applies) -- no atomics, no second round trip.  Two sets, alternating: a workgroup can run at most
@@ -1529,6 +1617,17 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
                         v1 = ld(1);
                         v2 = ld(2);
                     }
+                }
+                if (ks + 1 < nsweeps) {  // folded behind the next sweep's J loads
+                    pv0 = v0;
+                    pv1 = v1;
+                    pv2 = v2;
+                    pending = true;
+                    const double* t = Jin;  // ping-pong
+                    Jin = Jout;
+                    Jout = const_cast<double*>(t);
+                    st_j = st_dmax = st_ndmin = -INFINITY;
+                    continue;
                 }
             } else {
                 block_max3_store(st_j, st_dmax, st_ndmin, part + 4 * blockIdx.x);
@@ -2939,6 +3038,7 @@ static const char* const OVERRIDE_KEYS[] = {
     "BANDS",       // 4-D lean sweep launch order: bands of the tile list per XCD pass (default: sized for the L2)
     "TABLES",      // lean sweep per-node coefficient tables: 0 per-node arrays, 1 factorised where the dynamics allow
     "DEFER",       // 0: the 2-D float32 sweep keeps its in-kernel ticket / k_sweep_finish per sweep instead of the deferred fold
+    "JWIN",        // 0: the register-table sweeps gather J from memory instead of the workgroup's LDS window
     "REGTAB",      // 0: the multi-sweep launch of 2-D grids recomputes the per-action cells every sweep (fence-based barrier)
     "MULTI",       // 0: one launch per sweep also where a batch could run as ONE multi-sweep launch (k_sweep64m)
 };
@@ -4987,6 +5087,7 @@ static int launch_sweep(pvi_problem* h, int src, double alpha, hipStream_t st, i
     sc.split_finish = deferred ? 2 : 0;  // (2: the 2-D lean sweep folds the previous sweep's statistics itself)
     sc.xcd_remap = 0;
     sc.regtab = 0;
+    sc.win_bytes = 0;
     if (h->d.dtype == PVI_F64)
         return h->pi_size == 1 ? launch_sweep_t<double, unsigned char>(h, src, alpha, st, sc)
                                : launch_sweep_t<double, unsigned short>(h, src, alpha, st, sc);
@@ -5025,7 +5126,8 @@ static bool multi64_applies(pvi_problem* h) {
     if (!kfn) return no("dynamics");
     int coop = 0, per_cu = 0, ncu = 0;
     if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, h->device) != hipSuccess || !coop) return no("no cooperative launch");
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, h->levr_bytes) != hipSuccess) return no("occupancy query");
+    // (with the largest window the launch may ask for: launch_multi64)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, h->levr_bytes + 5 * 512 * 8) != hipSuccess) return no("occupancy query");
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) return no("device query");
     const unsigned g = grid_for(h->owned);
     if ((long long)g > (long long)per_cu * ncu) return no("more workgroups than are resident");
@@ -5048,6 +5150,10 @@ static int launch_multi64(pvi_problem* h, int src, double alpha, double tol, int
     sc.xcd_remap = (sc.nblocks >= 64u && !(ovr("XCD64") && !atoi(ovr("XCD64")))) ? 1 : 0;
     sc.regtab = (h->P.n == 2 && h->P.A <= 12 && !ovr_is("REGTAB", 0)) ? 1 : 0;  // (12 = RT of sweep64_body)
     h->regtab64 = sc.regtab;
+    // LDS for the workgroup's window of J behind the level table: at most 5 x 512 doubles (WCH of sweep64_body), within 48 KB
+    sc.win_bytes = 0;
+    if (sc.regtab && !ovr_is("JWIN", 0) && h->levr_bytes + 4096 <= 48 * 1024)
+        sc.win_bytes = (int)std::min<size_t>(5 * 512 * 8, 48 * 1024 - h->levr_bytes);
     const void* kfn = h->pi_size == 1 ? multi64_kernel<unsigned char>(h->d.dynamics_id) : multi64_kernel<unsigned short>(h->d.dynamics_id);
     DevP P = h->P;
     const double* Jin = (const double*)h->J[src];
@@ -5057,7 +5163,7 @@ static int launch_multi64(pvi_problem* h, int src, double alpha, double tol, int
     const double2* levr = h->levr;
     void* args[] = {&P, &Jin, &Jout, &pi, &alpha, &sc, &act64, &levr, &nsweeps};
     set_kname(h, "k_sweep64m", (int)h->d.dynamics_id, h->pi_size == 1 ? tname<unsigned char>() : tname<unsigned short>());
-    HIPCHK(hipLaunchCooperativeKernel(kfn, dim3(sc.nblocks), dim3(256), args, (unsigned)h->levr_bytes, h->stream));
+    HIPCHK(hipLaunchCooperativeKernel(kfn, dim3(sc.nblocks), dim3(256), args, (unsigned)(h->levr_bytes + (size_t)sc.win_bytes), h->stream));
     return PVI_OK;
 }
 
