@@ -2001,15 +2001,36 @@ __global__ __launch_bounds__(256) void k_sweep3_fast(DevP P, const float* __rest
     using D = Dyn3<DYN>;
     constexpr int N = D::N, M = D::M;
     if (sc.ctrl->done) return;
-    // (Plain block order.  Contiguous block ranges per XCD, as in k_sweep64, were measured in round 4: 0.478 against 0.458 ms on
-    //  the 201 x 201 x 401 helicopter grid -- the 2.4 GB this sweep moves through the fabric per launch are not what it waits for.)
+    // (Contiguous block ranges per XCD along axis 0, as in k_sweep64, were measured in round 4: 0.478 against 0.458 ms on the
+    //  201 x 201 x 401 helicopter grid.  The split along axis 1 below takes the bytes this sweep moves through the fabric from
+    //  1.15 to 0.13 GB of reads per launch at the same 0.46 ms: the sweep does not wait for them, but they are no longer moved.)
     const unsigned lb = blockIdx.x;
-    const long long o = (long long)lb * blockDim.x + threadIdx.x;
+    long long o = (long long)lb * blockDim.x + threadIdx.x;
     const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
+    int idx[N];
+    bool live = o < owned;
+    bool decoded = false;
+    if constexpr (N == 3) {
+      if (sc.xcd_remap == 3) {
+        decoded = true;
+        // XCD x (= block b % 8) sweeps ITS eighth of axis 1 for every row of axis 0 in turn.  The gathers of a node go to the
+        // planes i0 + d0(a) of ALL actions -- twenty-odd planes of axes (1, 2) -- at its own (i1, i2) plus a small shift: with
+        // an eighth of axis 1 per XCD those planes' strips (22 x 27 rows x 1.6 KB on the 201 x 201 x 401 helicopter grid:
+        // 1 MB) stay in the XCD's 4 MB L2 while axis 0 advances, instead of 22 whole planes (7 MB) per XCD.
+        const int x8 = (int)(lb & 7u), c0 = (int)((long long)P.dim[1] * x8 / 8), c1 = (int)((long long)P.dim[1] * (x8 + 1) / 8);
+        const long long per0 = (long long)(c1 - c0) * P.dim[2], n = (long long)(lb >> 3) * blockDim.x + threadIdx.x;
+        const int r = (int)(n / per0);
+        const int rem = (int)(n - (long long)r * per0);
+        live = r < P.row_end - P.row_begin;
+        idx[0] = P.row_begin + r;
+        idx[1] = c0 + rem / P.dim[2];
+        idx[2] = rem - (rem / P.dim[2]) * P.dim[2];
+        o = ((long long)r * P.dim[1] + idx[1]) * P.dim[2] + idx[2];
+      }
+    }
+    if (!decoded && live) decode_node<N>(P, o, idx);
     double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
-    if (o < owned) {
-        int idx[N];
-        decode_node<N>(P, o, idx);
+    if (live) {
         double x[N], dx[N];
         long long self = (long long)(idx[0] - P.store_begin) * P.strd[0];
 #pragma unroll
@@ -3035,9 +3056,11 @@ static const char* const OVERRIDE_KEYS[] = {
     "SPLINE_CHUNK",            // spline mode: rows per chunk of the substitution passes
     "WIN",         // 0: no LDS-window kernel for 4-D float32 sweeps (plain-gather k_sweep_fast)
     "XCD_CHUNK",   // 4-D float64 sweep: rows of axis 0 per chunk dealt round-robin to the XCDs (0: one contiguous eighth per XCD)
+    "L4PIN",       // 4-D lean sweep tiling "cap/threads/widest" (the `choice=` token of pvi_describe): no timed candidates
     "BANDS",       // 4-D lean sweep launch order: bands of the tile list per XCD pass (default: sized for the L2)
     "TABLES",      // lean sweep per-node coefficient tables: 0 per-node arrays, 1 factorised where the dynamics allow
     "DEFER",       // 0: the 2-D float32 sweep keeps its in-kernel ticket / k_sweep_finish per sweep instead of the deferred fold
+    "XCD3",        // 0: float32 3-D sweep in plain block order instead of an eighth of axis 1 per XCD
     "JWIN",        // 0: the register-table sweeps gather J from memory instead of the workgroup's LDS window
     "REGTAB",      // 0: the multi-sweep launch of 2-D grids recomputes the per-action cells every sweep (fence-based barrier)
     "MULTI",       // 0: one launch per sweep also where a batch could run as ONE multi-sweep launch (k_sweep64m)
@@ -3101,6 +3124,7 @@ struct pvi_problem {
     int lean4_stage = 2;          // actions whose gathers are in flight together (sweep_lean4.inc)
     int lean4_ptab_inv = 0;       // bit 0 / 1: the (position node, action) table does not depend on axis 0 / 1
     long long lean4_ptab_groups = 0;
+    char lean4_choice[32] = "-";  // rows cap / threads / widest tile of the tiling in use (pvi_override L4PIN takes it back)
     char lean4_cands[960] = "";  // the timed tile shapes of set-up: rows x columns : ms
     unsigned lean4_grid = 0;
     size_t lean4_lds = 0;
@@ -3746,7 +3770,12 @@ static int lean4_setup(pvi_problem* h) {
     const size_t budget = ovr("LDS_KB") ? (size_t)atoi(ovr("LDS_KB")) * 1024 : (size_t)80 * 1024;  // two workgroups per CU
     std::vector<Lean4Cand> cands;
     const int V1 = P.dim[3];
-    if (ovr("TV0") && ovr("TV1")) {  // rows cap, and the tile width the workgroup is sized for (cap x width threads)
+    int pin[3] = {0, 0, 0};
+    if (ovr("L4PIN") && sscanf(ovr("L4PIN"), "%d/%d/%d", &pin[0], &pin[1], &pin[2]) == 3 && pin[0] > 0 && pin[1] >= 64 && pin[2] > 0) {
+        // exactly one candidate of the list below -- rows cap / threads / widest tile, as `choice=` of pvi_describe prints it:
+        // the counter passes pin the shape an unprofiled create chose (the timed choice can flip under the profiler)
+        cands.push_back({pin[0], pin[1], pin[2]});
+    } else if (ovr("TV0") && ovr("TV1")) {  // rows cap, and the tile width the workgroup is sized for (cap x width threads)
         cands.push_back({atoi(ovr("TV0")), std::min(512, ((atoi(ovr("TV0")) * atoi(ovr("TV1")) + 63) / 64) * 64), atoi(ovr("TV1"))});
     } else {
         // Tilings worth timing: workgroups of 3 .. 8 waves, and for each the row caps whose tiles (step-aligned row pieces,
@@ -3783,7 +3812,7 @@ static int lean4_setup(pvi_problem* h) {
     snprintf(key, sizeof(key), "%d/%d:%dx%dx%dx%d:A%d:rows%d:dt%.17g:lb%.17g,%.17g:ub%.17g,%.17g:lds%zu", h->device, h->d.dynamics_id,
              P.dim[0], P.dim[1], P.dim[2], P.dim[3], P.A, rows, P.dt, P.lb[2], P.lb[3], P.ub[2], P.ub[3], budget);
     bool from_cache = false;
-    if (!ovr_is("TUNE", 0) && !(ovr("TV0") && ovr("TV1")) && !ovr_is("TUNE", 2)) {
+    if (!ovr_is("TUNE", 0) && !(ovr("TV0") && ovr("TV1")) && !ovr("L4PIN") && !ovr_is("TUNE", 2)) {
         std::lock_guard<std::mutex> lk(g_lean4_choice_mu);
         auto it = g_lean4_choice.find(key);
         if (it != g_lean4_choice.end()) {
@@ -3886,6 +3915,7 @@ static int lean4_setup(pvi_problem* h) {
         g_lean4_choice[key] = cands[(size_t)best];
     }
     if (from_cache) snprintf(h->lean4_cands, sizeof(h->lean4_cands), "cached");
+    snprintf(h->lean4_choice, sizeof(h->lean4_choice), "%d/%d/%d", cands[(size_t)best].cap, cands[(size_t)best].w, cands[(size_t)best].wmax);
     h->lean_why[0] = 0;
     h->lean4_ok = true;
     return PVI_OK;
@@ -4628,9 +4658,9 @@ static int describe_impl(pvi_handle h, char* buf, int32_t n) {
         // win=1: position-paired window + ds_read_b64 (sweep_lean4.inc); tables: bit d set = the displacement table does
         // not span axis d; rowpieces / bands: the step-aligned row pieces of axis 2 and their grouping in the launch order
         snprintf(buf, (size_t)n, "path=lean tile=%dx%d grid=%ux1x1 block=%d pw1=%d lds_bytes=%zu lsplit=0 tb_tile=1 dma16=0 npt=1 "
-                 "reach=0 opmag=0 sparse=0 win=1 tables=%d ptab=%d gx=%s stage=%d tiles_per_plane=%d bands=%d cands=%s note=%s", h->L4.TV0, h->L4.TV1,
+                 "reach=0 opmag=0 sparse=0 win=1 tables=%d ptab=%d gx=%s stage=%d choice=%s tiles_per_plane=%d bands=%d cands=%s note=%s", h->L4.TV0, h->L4.TV1,
                  h->lean4_grid, h->lean4_block, h->L4.RS, h->lean4_lds, h->lean4_tables, h->lean4_ptab_inv, h->L4.gx ? "node" : "axes", h->lean4_stage,
-                 h->L4.ntr, h->lean4_bands, h->lean4_cands[0] ? h->lean4_cands : "-", h->lean_why);
+                 h->lean4_choice, h->L4.ntr, h->lean4_bands, h->lean4_cands[0] ? h->lean4_cands : "-", h->lean_why);
         return PVI_OK;
     }
     snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d npt=%d reach=%d opmag=%d sparse=%d win=0 tables=0 note=%s",
@@ -4981,9 +5011,19 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
     }
     if constexpr (sizeof(REAL) == 4) {
         if (h->okmask3 && !h->force_exact) {
+            unsigned g3 = g;
+            if (h->P.n == 3 && h->P.dim[1] >= 64 && !ovr_is("XCD3", 0)) {  // an eighth of axis 1 per XCD (see the kernel)
+                const long long rows = h->P.row_end - h->P.row_begin;
+                long long mx = 0;
+                for (int x8 = 0; x8 < 8; ++x8)
+                    mx = std::max(mx, rows * ((long long)h->P.dim[1] * (x8 + 1) / 8 - (long long)h->P.dim[1] * x8 / 8) * h->P.dim[2]);
+                g3 = (unsigned)(8 * ((mx + 255) / 256));
+                sc.xcd_remap = 3;
+                sc.nblocks = g3;
+            }
 #define FAST3(DYN)                                                                                                  \
     set_kname(h, "k_sweep3_fast", (int)DYN, tname<PI_T>());                                                         \
-    hipLaunchKernelGGL((k_sweep3_fast<DYN, PI_T>), g, 256, 0, st, h->P, Jin, Jout, pi, (float)alpha, sc, h->P.utab, h->P.gu, \
+    hipLaunchKernelGGL((k_sweep3_fast<DYN, PI_T>), g3, 256, 0, st, h->P, Jin, Jout, pi, (float)alpha, sc, h->P.utab, h->P.gu, \
                        h->okmask3)
             switch (h->d.dynamics_id) {
                 case PVI_DYN_HELICOPTER: FAST3(PVI_DYN_HELICOPTER); break;

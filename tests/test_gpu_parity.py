@@ -2514,15 +2514,17 @@ def test_h3_full_size_fast_sweep_against_the_plain_kernel(variants):
     with contextlib.redirect_stdout(io.StringIO()):
         c = configs.build("h3")
     outs = {}
-    for tag, env in (("fast3", {}), ("plain", {"PVI_NO_FAST": "1"})):
+    # "fast3": every XCD sweeps its eighth of axis 1 (201 = 8 x 25 + 1: ragged eighths); "fast3_plain_order": blocks in node order
+    for tag, env in (("fast3", {}), ("fast3_plain_order", {"PVI_XCD3": "0"}), ("plain", {"PVI_NO_FAST": "1"})):
         variants.delenv("PVI_NO_FAST")
+        variants.delenv("PVI_XCD3")
         for k, v in env.items():
             variants.setenv(k, v)
         with contextlib.redirect_stdout(io.StringIO()):
             dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(c["grid_sys"], c["cf"], dtype="float32")
         dp.save_time_history = False
         desc = dp._p.describe()
-        assert desc.startswith("path=fast3" if tag == "fast3" else "path=exact-f32"), desc
+        assert desc.startswith("path=fast3" if tag.startswith("fast3") else "path=exact-f32"), desc
         res, done = [], 0
         for k in (1, 5, 30):
             dp._p.sweep(k - done, 1.0, -1.0)
@@ -2531,6 +2533,9 @@ def test_h3_full_size_fast_sweep_against_the_plain_kernel(variants):
         outs[tag] = res
         dp._p.close()
     variants.delenv("PVI_NO_FAST")
+    variants.delenv("PVI_XCD3")
+    for (Ja, pa), (Jb, pb) in zip(outs["fast3"], outs["fast3_plain_order"]):       # the launch order changes no bit
+        assert np.array_equal(Ja, Jb) and np.array_equal(pa, pb)
     for (Jf, pf), (Jp, pp_) in zip(outs["fast3"], outs["plain"]):
         scale = np.abs(Jp).max()
         assert np.abs(Jf - Jp).max() <= 2e-6 * scale

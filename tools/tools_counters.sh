@@ -4,7 +4,7 @@
 W=$1
 cd /tmp && export TMPDIR=/tmp
 OUT=/root/repo/gpurun_out/counters_$W; mkdir -p $OUT
-# 2-D lean sweeps: the timed choice between near-equal tile shapes flips under the profiler (counter collection serialises
+# lean sweeps (2-D and 4-D): the timed choice between near-equal tile shapes flips under the profiler (counter collection serialises
 # the launches): take the shape an UNPROFILED create chooses and pin it for the passes, so that the counters describe the
 # variant bench.py runs
 PIN=$(python /root/repo/tools/tools_describe.py $W 2>/dev/null | python3 -c "
@@ -12,6 +12,8 @@ import sys,re
 d=dict(t.split('=',1) for t in sys.stdin.read().split() if '=' in t)
 if d.get('path')=='lean' and d.get('win')=='0' and d.get('lsplit')=='0' and 'tile' in d:
     a,b=d['tile'].split('x'); print('TV0=%s TV1=%s NPT=%s' % (a,b,d.get('npt','1')))
+elif d.get('path')=='lean' and d.get('win')=='1' and d.get('choice','-')!='-':
+    print('L4PIN=%s' % d['choice'])
 ")
 echo "pins: $PIN"
 i=0
