@@ -425,6 +425,22 @@ def test_f32_kernel_variants_agree(name, variants):
         desc = h.describe()                              # (after the sweeps: `kernel=` names the kernel of the last launch)
         outs[tag] = (h.get_J(), h.get_pi(), desc)
         h.close()
+    if four_d:
+        # the tiling a create chose, taken back by L4PIN (what the counter passes do: tools/tools_counters.sh): the same launch
+        tok = dict(t.split("=", 1) for t in outs["lean"][2].split() if "=" in t)
+        assert tok.get("choice", "-") != "-", outs["lean"][2]
+        for k in ("PVI_LSPLIT", "PVI_NO_LEAN", "PVI_NO_FAST", "PVI_NPT", "PVI_WIN", "PVI_TABLES", "PVI_NO_XCD", "PVI_TV0", "PVI_TV1",
+                  "PVI_BANDS"):
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("PVI_L4PIN", tok["choice"])
+        h = native_problem(p, dtype="float32")
+        h.terminal_cost()
+        h.sweep(nsw, alpha, -1.0)
+        pinned = dict(t.split("=", 1) for t in h.describe().split() if "=" in t)
+        assert [pinned[k] for k in ("tile", "grid", "block", "lds_bytes", "choice")] == [tok[k] for k in ("tile", "grid", "block", "lds_bytes", "choice")]
+        assert np.array_equal(h.get_J(), outs["lean"][0]) and np.array_equal(h.get_pi(), outs["lean"][1])
+        h.close()
+        monkeypatch.delenv("PVI_L4PIN", raising=False)
     for tag, (J, pi, desc) in outs.items():
         assert relerr(J, ref) <= REL_F32, (tag, desc)
         assert relerr(J, outs["exact32"][0]) <= 2e-6, (tag, desc)

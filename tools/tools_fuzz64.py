@@ -19,7 +19,9 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 VARIANTS = [("ref", {"NO_SWEEP64": 1}), ("dense-line", {"SPARSE": 0, "PATCH": 0}),
             ("dense-patch", {"SPARSE": 0, "PATCH": 1}), ("sparse-line", {"SPARSE": 1, "PATCH": 0}),
-            ("sparse-patch", {"SPARSE": 1, "PATCH": 1}), ("auto", {})]          # pvi_override pins
+            ("sparse-patch", {"SPARSE": 1, "PATCH": 1}), ("auto", {}),          # pvi_override pins
+            # small grids: one launch per sweep / the fenced multi-sweep launch / the register table without the LDS window
+            ("single", {"MULTI": 0}), ("multi-fenced", {"REGTAB": 0}), ("regtab-nowin", {"JWIN": 0})]
 fails = 0
 for case in range(n_cases):
     kind = rng.choice(["pendulum", "inverted", "cartpole", "doublependulum", "twolink", "twolink"])
@@ -27,7 +29,7 @@ for case in range(n_cases):
         if kind in ("pendulum", "inverted"):
             s = pendulum.SinglePendulum() if kind == "pendulum" else pendulum.InvertedPendulum()
             dims = [int(rng.integers(4, 200)), int(rng.integers(4, 200))]
-            udims = [int(rng.integers(1, 70))]
+            udims = [int(rng.integers(1, 70)) if rng.random() < 0.5 else int(rng.integers(1, 13))]
         else:
             s = {"cartpole": cartpole.CartPole, "doublependulum": pendulum.DoublePendulum,
                  "twolink": manipulator.TwoLinkManipulator}[kind]()
@@ -62,7 +64,7 @@ for case in range(n_cases):
     fails += bool(bad)
     frac = [w for w in res["sparse-patch"][3].split() if w.startswith("inbox")]
     print("%3d %-14s dims %-20s A %-8s dt %.2f a %.2f INF %6.0f sw %d  auto: %s %s %s" % (
-        case, kind, dims, udims, dt, alpha, cf.INF, nsw, " ".join(w for w in res["auto"][3].split() if w.startswith(("mapping", "sparse"))),
+        case, kind, dims, udims, dt, alpha, cf.INF, nsw, " ".join(w for w in res["auto"][3].split() if w.startswith(("mapping", "sparse", "multi", "regtab"))),
         frac[0] if frac else "", "FAIL " + ",".join(bad) if bad else ""), flush=True)
 print("cases %d  failures %d" % (n_cases, fails))
 sys.exit(1 if fails else 0)
