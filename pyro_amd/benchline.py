@@ -48,6 +48,9 @@ def compact_line(full, full_path=None):
     rl = full.get("roofline_lds")
     if rl:
         out["roofline_lds"] = {k: _r(rl.get(k)) for k in ("frac", "lds_busy_frac", "bank_conflict_share")}
+    fv = full.get("flops_frac_vector_peak")
+    if fv:                                  # algorithmic flops of the evaluated cells / the dtype's vector peak: what the loop reaches
+        out["vector_peak_frac"] = _r(fv.get("frac"))
     if full.get("counters_error"):
         out["counters_error"] = str(full["counters_error"])[:200]
     cb = full.get("cpu_baseline")
