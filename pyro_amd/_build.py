@@ -74,6 +74,29 @@ def build(force=False, verbose=True):
     return OUT
 
 
+def build_all(force=False, verbose=True):
+    """Product and sanitized library side by side (two hipcc processes: the translation unit compiles in ~75 s / ~95 s, one
+    after the other they were the 3 minutes of every build)."""
+    need = force or not up_to_date()
+    need_san = force or not (os.path.exists(OUT_SAN) and all(os.path.getmtime(p) <= os.path.getmtime(OUT_SAN) for p in sources()))
+    cmds = []
+    if need:
+        cmds.append([hipcc()] + FLAGS + ["-o", OUT] + SRC)
+    if need_san:
+        cmds.append([hipcc(), "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
+                     "-shared", "-fsanitize=undefined,bounds", "-fno-sanitize=vptr,function", "-fno-sanitize-recover=undefined",
+                     "-fno-gpu-sanitize", "-shared-libsan", "-o", OUT_SAN] + SRC)
+    procs = []
+    for cmd in cmds:
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd, cwd=ROOT)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    return OUT, OUT_SAN
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print("built", OUT)
