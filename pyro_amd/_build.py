@@ -6,20 +6,32 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
-SRC = [os.path.join(PKG, "csrc", "pyrovi.hip")]
+CSRC = os.path.join(PKG, "csrc")
+# The library is three translation units over two shared headers (core.h: device-side common code; host.h: the handle, helpers,
+# cross-unit entry points).  They compile side by side (~30 s instead of the 75 s of the one-file build of rounds 1-4) and an
+# edit recompiles only the units that include the file:
+UNITS = {
+    "pyrovi": ["pyrovi.hip", "sweep_spline.inc", "shard.inc"],   # C ABI, exact / table / spline / n = 3 kernels, rollouts, sharding
+    "f64": ["f64.hip"],                                          # k_sweep64 family, k_sweep64m
+    "lean": ["lean.hip", "sweep_lean.inc", "sweep_lean4.inc"],   # float32 LDS-window families + k_sweep_fast, their set-up
+}
+COMMON = [os.path.join(CSRC, "core.h"), os.path.join(CSRC, "host.h")]
+SRC = [os.path.join(CSRC, u[0]) for u in UNITS.values()]
 HDR = [os.path.join(ROOT, "include", "pyrovi.h")]
+OBJ = os.path.join(PKG, "_obj")
 
 
 def sources():
-    """Every file the library is compiled from: the translation unit, the kernel files it includes, the C ABI header."""
-    csrc = os.path.join(PKG, "csrc")
-    return sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".inc", ".h"))) + HDR
+    """Every file the library is compiled from: the translation units, the kernel files they include, the headers."""
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".inc", ".h"))) + HDR
 OUT = os.path.join(PKG, "libpyrovi.so")
 # -ffp-contract=off: the f64 kernels mirror the reference's NumPy arithmetic (no implicit FMA)
 # -fno-slp-vectorize: the pairing pass packs independent scalar float32 steps of the action loops into v_pk_* pairs that
 #   need their halves transposed first (15 register moves per four cells of the 4-D loop); where packed math pays, the
 #   kernels spell it out on 2-vectors themselves
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC"]
+FLAGS_SAN = ["--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
+             "-fsanitize=undefined,bounds", "-fno-sanitize=vptr,function", "-fno-sanitize-recover=undefined", "-fno-gpu-sanitize"]
 
 
 def hipcc():
@@ -53,39 +65,28 @@ def build_sanitized(force=False, verbose=True):
     library builds with it -- but ROCm's ASan runtime intercepts hsa_amd_memory_pool_allocate to put DEVICE memory under
     its allocator and aborts with "out of memory" on the GPU boxes, with or without HSA_XNACK=1: it cannot be preloaded
     under python there.)"""
-    if not force and os.path.exists(OUT_SAN) and all(os.path.getmtime(p) <= os.path.getmtime(OUT_SAN) for p in sources()):
-        return OUT_SAN
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
-           "-fsanitize=undefined,bounds", "-fno-sanitize=vptr,function", "-fno-sanitize-recover=undefined",
-           "-fno-gpu-sanitize", "-shared-libsan", "-o", OUT_SAN] + SRC
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=ROOT)
-    return OUT_SAN
+    return _make(OUT_SAN, "san", FLAGS_SAN, ["-shared", "-fPIC", "-fsanitize=undefined,bounds", "-shared-libsan"], force, verbose)
 
 
-def build(force=False, verbose=True):
-    if not force and up_to_date():
-        return OUT
-    cmd = [hipcc()] + FLAGS + ["-o", OUT] + SRC
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=ROOT)
-    return OUT
+def _stale(obj, unit):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [os.path.join(CSRC, f) for f in UNITS[unit]] + COMMON + HDR
+    return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build_all(force=False, verbose=True):
-    """Product and sanitized library side by side (two hipcc processes: the translation unit compiles in ~75 s / ~95 s, one
-    after the other they were the 3 minutes of every build)."""
-    need = force or not up_to_date()
-    need_san = force or not (os.path.exists(OUT_SAN) and all(os.path.getmtime(p) <= os.path.getmtime(OUT_SAN) for p in sources()))
-    cmds = []
-    if need:
-        cmds.append([hipcc()] + FLAGS + ["-o", OUT] + SRC)
-    if need_san:
-        cmds.append([hipcc(), "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
-                     "-shared", "-fsanitize=undefined,bounds", "-fno-sanitize=vptr,function", "-fno-sanitize-recover=undefined",
-                     "-fno-gpu-sanitize", "-shared-libsan", "-o", OUT_SAN] + SRC)
+def _compile_jobs(tag, flags, force):
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = []
+    for unit in UNITS:
+        obj = os.path.join(OBJ, "%s.%s.o" % (unit, tag))
+        if force or _stale(obj, unit):
+            jobs.append([hipcc()] + flags + ["-c", "-o", obj, os.path.join(CSRC, UNITS[unit][0])])
+    return jobs
+
+
+def _run_all(cmds, verbose):
     procs = []
     for cmd in cmds:
         if verbose:
@@ -94,6 +95,34 @@ def build_all(force=False, verbose=True):
     for cmd, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
+
+
+def _link(out, tag, link_flags, verbose):
+    cmd = [hipcc(), "--offload-arch=gfx950"] + link_flags + ["-o", out] + [os.path.join(OBJ, "%s.%s.o" % (u, tag)) for u in UNITS]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=ROOT)
+
+
+def _make(out, tag, flags, link_flags, force, verbose):
+    jobs = _compile_jobs(tag, flags, force)
+    if not jobs and os.path.exists(out) and all(os.path.getmtime(os.path.join(OBJ, "%s.%s.o" % (u, tag))) <= os.path.getmtime(out) for u in UNITS):
+        return out
+    _run_all(jobs, verbose)
+    _link(out, tag, link_flags, verbose)
+    return out
+
+
+def build(force=False, verbose=True):
+    return _make(OUT, "o3", FLAGS, ["-shared", "-fPIC"], force, verbose)
+
+
+def build_all(force=False, verbose=True):
+    """Product and sanitized library: all six compilations side by side, then the two links."""
+    jobs = _compile_jobs("o3", FLAGS, force) + _compile_jobs("san", FLAGS_SAN, force)
+    _run_all(jobs, verbose)
+    build(False, verbose)
+    build_sanitized(False, verbose)
     return OUT, OUT_SAN
 
 

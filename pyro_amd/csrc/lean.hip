@@ -1,0 +1,1206 @@
+// lean.hip -- the float32 production families of the sweep: LDS-window kernels for 2-D grids (k_sweep_lean, sweep_lean.inc) and
+// 4-D grids (k_sweep_lean4, sweep_lean4.inc), the plain-gather k_sweep_fast, their set-up (per-node coefficient tables, tilings,
+// timed candidates, launch schedules) and launchers.  One of the three translation units of libpyrovi (pyrovi.hip, f64.hip,
+// lean.hip); see core.h / host.h.
+#include "core.h"
+#include "host.h"
+
+// =================================================================================================
+// f32 fast path ("v1").  Same recursion; the inner loop is float32 and system independent:
+//   * per state (float64, reference operation order): node coordinates, position rows of x_next
+//     (exact), dynamics prologue, and the AFFINE form of the velocity displacement measured in grid
+//     cells,  rel_d(u) = (x_next_d - x_d)/dx_d = ta_d + sum_k tB_dk u_k   (mechanical systems are
+//     affine in u), rounded once to float32;
+//   * per action (float32): rel, interval = own index + floor(rel), fraction = rel - floor(rel),
+//     2^n gathers, lerps, Bellman min.  Working relative to the node keeps |rel| small, so the
+//     fraction carries ~1e-6 cells of error instead of the 6e-5 of an absolute float32 coordinate;
+//   * validity is decided from the float32 margin to the box unless that margin is inside a guard
+//     band; then the cell is re-evaluated in float64 with the exact operation order (rare branch),
+//     so the in/out-of-bounds classification equals the float64 kernel's bit for bit.
+// Requires isavalidstate box == grid end points (always true for GridDynamicSystem grids).
+// `lsplit`: log2 of the lanes that share one state (small grids), actions interleaved over them.
+// =================================================================================================
+
+template <int DYN, typename PI_T, bool UNIFORM>
+__global__ __launch_bounds__(256) void k_sweep_fast(DevP P, FastP F, const float* __restrict__ Jin,
+                                                    float* __restrict__ Jout, PI_T* __restrict__ pi, float alpha,
+                                                    SweepCtl sc, const float4* __restrict__ actp) {
+    using D = Dyn<DYN>;
+    constexpr int DOF = D::DOF, N = 2 * DOF, M = D::M, NP = 1 << DOF;
+    if (sc.ctrl->done) return;
+    const int split = UNIFORM ? 1 : (1 << F.lsplit);
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long o = UNIFORM ? t : (t >> F.lsplit);
+    const int part = UNIFORM ? 0 : (int)(t & (split - 1));
+    const long long owned = (long long)(P.row_end - P.row_begin) * P.plane;
+    const bool live = o < owned;
+    const float INF_F = (float)P.INF;
+
+    int idx[N];
+    int bp[NP];
+    float wp[NP], ta[DOF], tB[DOF][M], selff[DOF], nm1f[DOF];
+    int vstr[DOF], vdim[DOF];
+    bool pos_in = false, on_target = false;
+    float gxdt = 0.f;
+    long long self = 0;
+    if (live) {
+        decode_node<N>(P, o, idx);
+        double x[N], dx[N];
+        self = (long long)(idx[0] - P.store_begin) * P.strd[0];
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+            x[d] = P.lev[d][idx[d]];
+            dx[d] = x[d] - P.xbar[d];
+            if (d > 0) self += idx[d] * P.strd[d];
+        }
+        const double gx = quad_form<N>(P.Q, dx);
+        on_target = P.ontarget && (l2norm<N>(dx) < P.EPS);
+        gxdt = (float)(gx * P.dt);
+        // position rows (exact, float64)
+        pos_in = true;
+        int ci[DOF];
+        float yp[DOF];
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) {
+            const double xn = x[DOF + i] * P.dt + x[i];
+            pos_in = pos_in && !(xn < P.glo[i]) && !(xn > P.ghi[i]);
+            ci[i] = find_interval(P.lev[i], P.dim[i], P.glo[i], P.inv_step[i], xn);
+            yp[i] = (float)((xn - P.lev[i][ci[i]]) / (P.lev[i][ci[i] + 1] - P.lev[i][ci[i]]));
+        }
+        if (pos_in) {
+            int r0 = ci[0];
+            if (r0 < P.store_begin || r0 + 1 >= P.store_end) {
+                atomicOr(&sc.ctrl->halo_err, 1);
+                r0 = min(max(r0, P.store_begin), P.store_end - 2);
+            }
+            ci[0] = r0 - P.store_begin;
+        } else {
+#pragma unroll
+            for (int i = 0; i < DOF; ++i) ci[i] = 0;
+        }
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            int b = 0;
+            float w = 1.f;
+#pragma unroll
+            for (int i = 0; i < DOF; ++i) {
+                const int bit = (c >> (DOF - 1 - i)) & 1;
+                b += (ci[i] + bit) * (int)P.strd[i];
+                w *= bit ? yp[i] : (1.f - yp[i]);
+            }
+            bp[c] = b;
+            wp[c] = w;
+        }
+        double tr[8], a64[DOF], B64[DOF][M];
+        D::trig_from_tables(P, idx, tr);
+        D dyn;
+        dyn.init(P.c, x, tr);
+        dyn.affine(a64, B64);
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) {
+            const double sc = P.dt * P.inv_step[DOF + i];
+            ta[i] = (float)(a64[i] * sc);
+#pragma unroll
+            for (int k = 0; k < M; ++k) tB[i][k] = (float)(B64[i][k] * sc);
+            selff[i] = (float)idx[DOF + i];
+            nm1f[i] = (float)(P.dim[DOF + i] - 1 - idx[DOF + i]);
+            vstr[i] = (int)P.strd[DOF + i];
+            vdim[i] = P.dim[DOF + i];
+        }
+    }
+
+    float best = INFINITY;
+    int arg = 0x7fffffff;
+    if (live) {
+        for (int a = part; a < P.A; a += split) {
+            const float4 act = actp[a];  // (a restrict kernel argument: scalar loads when a is wave-uniform)
+            float rel[DOF], m = INFINITY;
+#pragma unroll
+            for (int i = 0; i < DOF; ++i) {
+                float r = fmaf(tB[i][0], act.x, ta[i]);
+                if (M == 2) r = fmaf(tB[i][M - 1], act.y, r);
+                rel[i] = r;
+                m = fminf(m, fminf(r + selff[i], nm1f[i] - r));
+            }
+            const bool aok = act.w != 0.f;
+            bool inb = pos_in && (m >= 0.f);
+            if (pos_in && fabsf(m) < F.guard) {
+                // rare: within the guard band of a bound -> exact float64 classification
+                double x[N], tr[8], u[M], acc[DOF];
+#pragma unroll
+                for (int d = 0; d < N; ++d) x[d] = P.lev[d][idx[d]];
+                D::trig_from_tables(P, idx, tr);
+                D dyn;
+                dyn.init(P.c, x, tr);
+#pragma unroll
+                for (int k = 0; k < M; ++k) u[k] = P.utab[a * M + k];
+                dyn.accel(u, acc);
+                inb = true;
+#pragma unroll
+                for (int i = 0; i < DOF; ++i) {
+                    const double xn = acc[i] * P.dt + x[DOF + i];
+                    inb = inb && !(xn < P.glo[DOF + i]) && !(xn > P.ghi[DOF + i]);
+                }
+            }
+            float Jn = 0.f;
+            if (inb) {
+                int off = 0;
+                float yv[DOF];
+#pragma unroll
+                for (int i = 0; i < DOF; ++i) {
+                    const float fl = floorf(rel[i]);
+                    int di = (int)fl;
+                    const int ii = min(max(idx[DOF + i] + di, 0), vdim[i] - 2);
+                    di = ii - idx[DOF + i];
+                    yv[i] = fminf(fmaxf(rel[i] - (float)di, 0.f), 1.f);
+                    off += ii * vstr[i];
+                }
+                float sv[NP];
+#pragma unroll
+                for (int v = 0; v < NP; ++v) {
+                    int vo = off;
+#pragma unroll
+                    for (int i = 0; i < DOF; ++i) vo += ((v >> (DOF - 1 - i)) & 1) ? vstr[i] : 0;
+                    float acc = wp[0] * Jin[bp[0] + vo];
+#pragma unroll
+                    for (int c = 1; c < NP; ++c) acc = fmaf(wp[c], Jin[bp[c] + vo], acc);
+                    sv[v] = acc;
+                }
+#pragma unroll
+                for (int i = DOF - 1; i >= 0; --i) {
+#pragma unroll
+                    for (int k = 0; k < (1 << i); ++k) sv[k] = fmaf(yv[i], sv[2 * k + 1] - sv[2 * k], sv[2 * k]);
+                }
+                Jn = sv[0];
+            }
+            const float G = (inb && aok) ? (on_target ? 0.f : gxdt + act.z) : INF_F;
+            const float q = fmaf(alpha, Jn, G);
+            if (q < best) {  // strict: keeps the first (smallest a) minimum within this lane
+                best = q;
+                arg = a;
+            }
+        }
+    }
+    if (!UNIFORM) {
+        for (int off = split >> 1; off > 0; off >>= 1) {
+            const float q2 = __shfl_xor(best, off, 64);
+            const int a2 = __shfl_xor(arg, off, 64);
+            if (q2 < best || (q2 == best && a2 < arg)) {
+                best = q2;
+                arg = a2;
+            }
+        }
+    }
+    double st_j = -INFINITY, st_dmax = -INFINITY, st_ndmin = -INFINITY;
+    if (live && part == 0) {
+        Jout[self] = best;
+        pi[o] = (PI_T)arg;
+        const double jn = (double)best, d = jn - (double)Jin[self];
+        st_j = jn;
+        st_dmax = d;
+        st_ndmin = -d;
+    }
+    block_stats(st_j, st_dmax, st_ndmin, sc.slot);
+    sweep_finish(sc);
+}
+
+
+#include "sweep_lean.inc"
+#include "sweep_lean4.inc"
+
+
+static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats) {
+    const DevP& P = h->P;
+    LeanP& L = h->LP;
+    const int DOF = P.dof;
+    // 4-D: tiles of the (i2, i3) velocity plane, one (i0, i1) position node per workgroup;
+    // 2-D: tiles of the (i0, i1) grid itself (TV0 rows share most of their window rows)
+    L.dof1 = DOF == 1;
+    L.V0 = DOF == 2 ? P.dim[2] : (P.row_end - P.row_begin);
+    L.V1 = P.dim[P.n - 1];
+    L.ntx = (L.V1 + tv1_t - 1) / tv1_t;
+    L.TV1 = ovr("TV_EXACT") ? tv1_t : (L.V1 + L.ntx - 1) / L.ntx;
+    const int tv0 = std::max(1, std::min(L.V0, tv0_t));
+    L.nty = (L.V0 + tv0 - 1) / tv0;
+    L.TV0 = (L.V0 + L.nty - 1) / L.nty;
+    L.tv1_magic = ((1 << 20) + L.TV1 - 1) / L.TV1;
+    L.half = ((L.TV0 + L.npt - 1) / L.npt) * L.TV1;  // nodes per band: thread t owns tile nodes t + k * half, k < npt
+    L.posdim1 = DOF == 2 ? P.dim[1] : 1;
+    L.pd_magic = magic32((unsigned)L.posdim1);
+    L.vplane = (long long)L.V0 * L.V1;
+    L.owned = h->owned;
+    const int pnodes = DOF == 2 ? (P.row_end - P.row_begin) * L.posdim1 : 1;
+    const long long ntiles = (long long)L.ntx * L.nty * pnodes;
+    if (ntiles >= 0x7fffffffLL) return 1;
+    L.ntx_magic = magic32((unsigned)L.ntx);
+    L.ntxy_magic = magic32((unsigned)(L.ntx * L.nty));
+    L.nblocks = (unsigned)ntiles;
+    L.xq = L.nblocks / 8u;
+    L.xrem = L.nblocks % 8u;
+    L.xcd_remap = ovr("NO_XCD") ? 0 : 1;
+    h->lean_grid = dim3((unsigned)ntiles, 1, 1);
+    int rc;
+    if (L.win) dev_release(h, L.win);
+    if (L.tbt) dev_release(h, L.tbt);
+    L.win = nullptr;
+    L.tbt = nullptr;
+    L.tb_tile = 0;
+    if ((rc = dev_alloc(h, (size_t)ntiles * 8, &L.win))) return rc;
+    if ((rc = dev_alloc(h, (size_t)ntiles * 4, &L.tbt))) return rc;
+    hipLaunchKernelGGL(k_lean_winit, grid_for(std::max<long long>(ntiles * 4, 4)), 256, 0, h->stream, L.win, ntiles,
+                       L.summary);
+    const int sthreads = ((L.TV0 * L.TV1 + 63) / 64) * 64;
+    if (sthreads > 1024) return 1;
+    switch (h->d.dynamics_id) {
+        case PVI_DYN_PENDULUM:
+            hipLaunchKernelGGL((k_lean_setup<PVI_DYN_PENDULUM>), h->lean_grid, sthreads, 0, h->stream, P, L, h->F.act);
+            break;
+        case PVI_DYN_CARTPOLE:
+            hipLaunchKernelGGL((k_lean_setup<PVI_DYN_CARTPOLE>), h->lean_grid, sthreads, 0, h->stream, P, L, h->F.act);
+            break;
+        case PVI_DYN_NODE_1x1:
+            hipLaunchKernelGGL((k_lean_setup<PVI_DYN_NODE_1x1>), h->lean_grid, sthreads, 0, h->stream, P, L, h->F.act);
+            break;
+        case PVI_DYN_NODE_2x1:
+            hipLaunchKernelGGL((k_lean_setup<PVI_DYN_NODE_2x1>), h->lean_grid, sthreads, 0, h->stream, P, L, h->F.act);
+            break;
+        case PVI_DYN_NODE_2x2:
+            hipLaunchKernelGGL((k_lean_setup<PVI_DYN_NODE_2x2>), h->lean_grid, sthreads, 0, h->stream, P, L, h->F.act);
+            break;
+        default:
+            hipLaunchKernelGGL((k_lean_setup<PVI_DYN_TWOLINK>), h->lean_grid, sthreads, 0, h->stream, P, L, h->F.act);
+            break;
+    }
+    HIPCHK(hipGetLastError());
+    int summary[8];
+    HIPCHK(hipMemcpyAsync(summary, L.summary, sizeof(summary), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->lean_reach = summary[4];
+    h->lean_opmag = summary[5];
+    if (summary[3]) {
+        snprintf(h->lean_why, sizeof(h->lean_why), "%s", (summary[3] & 2) ? "an action fails isavalidinput" : "halo too small");
+        return (summary[3] & 1) ? 2 : 1;
+    }
+    // row pitch: >= longest row + 1 (the j+1 corner), odd so that rows start on different banks.
+    // (A pitch congruent to the tile width modulo 32 -- consecutive lanes on consecutive banks across
+    // tile rows -- was measured: fewer conflict cycles per LDS instruction, but the larger pitch costs
+    // LDS capacity and one more address add per corner; no net gain.  PVI_RS_MODE=1 selects it.)
+    L.tb_tile = (summary[2] == 0 && !ovr("NO_TBTILE")) ? 1 : 0;
+    int rs = (summary[1] + 1) | 1;
+    // 2-D pair windows are a few KB: pitches 64 and 128 have their own kernels (row + 1 is an immediate offset of the read)
+    if (DOF == 1 && !ovr("NO_RS64")) rs = rs <= 64 ? 64 : (rs <= 128 ? 128 : rs);
+    // 16-byte window DMA (4-D; J buffers with slack behind them): rows are packed with a pitch that is a multiple of
+    // 4 floats, one instruction then moves 256 consecutive window floats (about four rows).  PVI_DMA16=0: 4-byte DMA.
+    L.dma16 = (DOF == 2 && (h->own_J || (h->d.flags & PVI_FLAG_EXT_J_SLACK)) &&
+               !(ovr("DMA16") && !atoi(ovr("DMA16")))) ? 1 : 0;
+    if (L.dma16) {
+        rs = (summary[1] + 3) & ~3;
+        // pitch 64 has its own kernel (the next velocity row is an immediate offset of the LDS read): rows a little
+        // shorter are padded to it when the window still fits
+        if (rs > 48 && rs < 64 && (long long)summary[0] * 64 + 128 <= lds_budget_floats && !ovr("NO_RS64")) rs = 64;
+        L.rs_magic = magic32((unsigned)rs);
+    }
+    // (2-D windows are staged as pairs -- 8 bytes per column, sweep_lean.inc lds_corners -- 4-D windows as single floats)
+    const long long need = (long long)summary[0] * rs * (DOF == 1 ? 2 : 1) + 128;
+    if (need <= lds_budget_floats) {
+        L.RS = rs;
+        h->lean_pw1 = rs;
+        L.lds_floats = (int)((need + 3) & ~3ll);
+        h->lean_lds = (size_t)L.lds_floats * 4;
+        return 0;
+    }
+    snprintf(h->lean_why, sizeof(h->lean_why), "tile %dx%d needs %lld LDS floats (%d rows x pitch %d; budget %d)", L.TV0,
+             L.TV1, need, summary[0], rs, lds_budget_floats);
+    return 1;
+}
+
+// =====================================================================================================================
+// lean path of 4-D grids (sweep_lean4.inc): set-up tables, tiling candidates, launch schedule
+// =====================================================================================================================
+
+template <typename PI_T>
+static int launch_lean4_t(pvi_problem* h, const float* Jin, float* Jout, float alpha, hipStream_t st, SweepCtl sc, bool probe = false) {
+    const Lean4P& L = h->L4;
+    sc.nblocks = h->lean4_grid;
+    sc.split_finish = 1;
+    PI_T* pi = (PI_T*)h->pi;
+#define L4K(KFN)                                                                                                       \
+    {                                                                                                                  \
+        auto kfn = KFN;                                                                                                \
+        if (h->lean4_lds > 48 * 1024)                                                                                  \
+            HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PVI_LDS_MAX));    \
+        hipLaunchKernelGGL(kfn, dim3(h->lean4_grid), dim3(h->lean4_block), h->lean4_lds, st, h->P, L, Jin, Jout, pi, alpha, \
+                           sc, (const float*)L.ptab, (const Lean4Tile*)h->lean4_tiles);                                \
+    }
+#define L4(DYN)                                   \
+    if (probe)                                    \
+        L4K((k_sweep_lean4_probe<DYN, PI_T>))     \
+    else {                                        \
+        set_kname(h, "k_sweep_lean4", (int)DYN, tname<PI_T>()); \
+        L4K((k_sweep_lean4<DYN, PI_T>))           \
+    }
+    switch (h->d.dynamics_id) {
+        case PVI_DYN_CARTPOLE: L4(PVI_DYN_CARTPOLE) break;
+        case PVI_DYN_NODE_2x1: L4(PVI_DYN_NODE_2x1) break;
+        case PVI_DYN_NODE_2x2: L4(PVI_DYN_NODE_2x2) break;
+        default: L4(PVI_DYN_TWOLINK) break;
+    }
+#undef L4
+#undef L4K
+    hipLaunchKernelGGL(k_sweep_finish, 1, STAT_SHARDS, 0, st, sc);
+    HIPCHK(hipGetLastError());
+    return PVI_OK;
+}
+
+// Row pieces of axis 2 for ONE row i0 of axis 0: cut where the axis-0 corner index of the position row steps (so that a
+// tile sees one pair plane), then into near-equal parts of at most `cap` rows.  Per i0, because a step that falls on a level
+// exactly (v dt / dx an integer) lands one row earlier or later depending on the rounding of x0 + v dt for that i0: one
+// segmentation for all rows would have to cut on both sides and leave one-row pieces (measured: 21 pieces instead of 16 on
+// C3, 63 % of the lanes live).
+static void lean4_row_pieces(const std::vector<int2>& pt0, int i0, int V0, int cap, std::vector<int2>& out) {
+    out.clear();
+    int a = 0;
+    for (int j = 1; j <= V0; ++j) {
+        if (j < V0) {
+            const int2 p = pt0[(size_t)i0 * V0 + j - 1], q = pt0[(size_t)i0 * V0 + j];
+            if ((p.x < 0 ? -0x40000000 : p.x) == (q.x < 0 ? -0x40000000 : q.x)) continue;
+        }
+        const int len = j - a, n = (len + cap - 1) / cap;
+        for (int k = 0; k < n; ++k) {
+            const int s0 = a + (int)((long long)len * k / n), s1 = a + (int)((long long)len * (k + 1) / n);
+            out.push_back(make_int2(s0, s1 - s0));
+        }
+        a = j;
+    }
+}
+// Tiles of the velocity plane for ONE row i0: every row piece is split into near-equal column chunks as wide as the
+// workgroup allows (rows x columns <= threads), so that short pieces get wide tiles and every workgroup is about full
+// (with one column split for all pieces 20 % of the lanes were idle on C3).  `wmax` bounds the width: the window of a wide tile
+// of a far-reaching system (C4: 32 pairs of reach along axis 3) may cost a workgroup of occupancy.
+static void lean4_row_tiles(const std::vector<int2>& pt0, int i0, int V0, int V1, int cap, int threads, int wmax, std::vector<int4>& out) {
+    std::vector<int2> pieces;
+    lean4_row_pieces(pt0, i0, V0, cap, pieces);
+    out.clear();
+    for (const int2& pc : pieces) {
+        const int w = std::max(1, std::min(std::min(V1, wmax), threads / pc.y));
+        const int n = (V1 + w - 1) / w;
+        for (int k = 0; k < n; ++k) {
+            const int c0 = (int)((long long)V1 * k / n), c1 = (int)((long long)V1 * (k + 1) / n);
+            out.push_back(make_int4(pc.x, pc.y, c0, c1 - c0));
+        }
+    }
+}
+
+// Launch order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with a private 4 MiB L2.
+// XCD x sweeps ITS chunk of axis 1 for every owned row of axis 0 in turn (bands of the row's tile list outermost, so that
+// the planes of three consecutive axis-0 rows over the chunk fit its L2): the axis-0 planes a tile gathers from were
+// fetched for the previous row a moment ago.  Lists are interleaved into physical order and padded to equal length.
+static void lean4_schedule(int R, int N1, int ntr, int nbands, std::vector<unsigned>& out, int r0 = 0) {
+    // Round 4: an XCD's share of a row is a contiguous EIGHTH of the row's (axis-1 index, tile) list -- not a whole number of
+    // axis-1 indices.  Splitting by index gave 13, 13, 12, 13, ... of C3's 101 to the XCDs: the lists were padded to the
+    // longest with empty workgroups and five XCDs idled 8 % of every row (the plain order, which balances by construction,
+    // ran 2.90 ms against 3.10 ms with the same tiles; profiles/r04_launch_order.log).
+    std::vector<std::vector<unsigned>> lists(8);
+    for (int b = 0; b < nbands; ++b) {
+        const int k0 = (int)((long long)ntr * b / nbands), k1 = (int)((long long)ntr * (b + 1) / nbands), kb = k1 - k0;
+        const long long E = (long long)N1 * kb;  // entries of one row of axis 0 in this band: i1-major, tile-minor
+        for (int r = r0; r < r0 + R; ++r)  // (r0, R: the rows of a timed candidate; the whole slab otherwise)
+            for (int x = 0; x < 8; ++x) {
+                const long long e0 = E * x / 8, e1 = E * (x + 1) / 8;
+                for (long long e = e0; e < e1; ++e) {
+                    const int i1 = (int)(e / kb), k = k0 + (int)(e - (long long)i1 * kb);
+                    lists[x].push_back((unsigned)((long long)(r * N1 + i1) * ntr + k));
+                }
+            }
+    }
+    size_t mx = 0;
+    for (auto& l : lists) mx = std::max(mx, l.size());
+    out.assign(8 * mx, 0xffffffffu);
+    for (int x = 0; x < 8; ++x)
+        for (size_t j = 0; j < lists[x].size(); ++j) out[8 * j + x] = lists[x][j];
+}
+
+struct Lean4Cand {
+    int cap, w, wmax;  // rows cap, workgroup threads, widest tile
+};
+// the tiling a create of this process chose for a problem shape (device, dynamics, dims, actions, rows, dt, velocity box):
+// a second handle of the same shape -- the float32 / float64 pair of a convergence check, the pieces of a shard, a bench
+// that builds its workload twice -- takes it without timing anything (pvi_override("TUNE", "2") times again)
+static std::map<std::string, Lean4Cand> g_lean4_choice;
+static std::mutex g_lean4_choice_mu;
+
+// one candidate tiling: tile lists, window boxes, row pitch, schedule.  rc 0 = usable, 1 = does not fit, < 0 error.
+static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int threads, int wmax, size_t lds_budget, int* narrower = nullptr,
+                     int sub_r0 = 0, int sub_rows = -1) {
+    const DevP& P = h->P;
+    Lean4P& L = h->L4;
+    const int rows = P.row_end - P.row_begin;
+    if (threads > 512 || threads < 64 || (threads & 63)) return 1;
+    std::vector<std::vector<int4>> per((size_t)rows);
+    int ntr = 1, tv0 = 1, tv1 = 1;
+    for (int r = 0; r < rows; ++r) {
+        lean4_row_tiles(pt0, P.row_begin + r, P.dim[2], P.dim[3], cap, threads, wmax, per[(size_t)r]);
+        ntr = std::max(ntr, (int)per[(size_t)r].size());
+    }
+    for (auto& v : per)
+        for (auto& t : v) {
+            tv0 = std::max(tv0, t.y);
+            tv1 = std::max(tv1, t.w);
+        }
+    const size_t nlists = per.size();
+    std::vector<int4> tlist(nlists * ntr, make_int4(0, 0, 0, 0));
+    for (size_t r = 0; r < nlists; ++r)
+        for (size_t k = 0; k < per[r].size(); ++k) tlist[r * ntr + k] = per[r][k];
+    L.V0 = P.dim[2];
+    L.V1 = P.dim[3];
+    L.TV0 = tv0;
+    L.TV1 = tv1;
+    L.ntr = ntr;
+    L.posdim1 = P.dim[1];
+    L.pd_magic = magic32((unsigned)L.posdim1);
+    L.ntr_magic = magic32((unsigned)ntr);
+    L.vplane = (long long)L.V0 * L.V1;
+    L.owned = h->owned;
+    const long long npos = (long long)rows * P.dim[1], ntiles = npos * ntr;
+    if (ntiles >= 0x7fffffffLL / 8) return 1;
+    int rc;
+    if (L.tlist) dev_release(h, (void*)L.tlist);
+    if (L.win) dev_release(h, L.win);
+    if (L.sched) dev_release(h, (void*)L.sched);
+    L.tlist = nullptr;
+    L.win = nullptr;
+    L.sched = nullptr;
+    int4* d_tl = nullptr;
+    if ((rc = dev_alloc(h, tlist.size(), &d_tl))) return rc;
+    HIPCHK(hipMemcpyAsync(d_tl, tlist.data(), tlist.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+    L.tlist = d_tl;
+    if ((rc = dev_alloc(h, (size_t)ntiles * 8, &L.win))) return rc;
+    HIPCHK(hipMemsetAsync(L.summary, 0, 6 * sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_lean4_tiles, dim3((unsigned)ntiles), dim3(threads), 0, h->stream, P, L, ntiles);
+    HIPCHK(hipGetLastError());
+    int summary[8];
+    HIPCHK(hipMemcpyAsync(summary, L.summary, sizeof(summary), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));  // (also: `tlist` has been copied)
+    // Row pitch in slots: the fill writes whole groups of four columns.  (Tiles differ in width, so no pitch is congruent to
+    // all of them; tools/ldsgather.hip: a row wrap or a displacement step inside a wave costs a ds_read_b64 4.3 -> 5.0 clk at
+    // worst, whatever the pitch -- the 4.4 clk of the conflict-free read is what counts.)
+    int rs = std::max(4, (summary[1] + 3) & ~3);
+    size_t lds = (size_t)std::max(summary[0], 1) * (size_t)rs * 8 + 256;
+    if (narrower) {  // the widest tile whose window lets as many workgroups onto a CU as the register budget does (24 waves)
+        *narrower = 0;
+        const size_t room = (size_t)160 * 1024 / (size_t)std::max(1, 1536 / threads) - 512;
+        if (lds > room && summary[0] > 0) {
+            const int rs_fit = (int)((room - 256) / 8 / (size_t)summary[0]) & ~3, w_fit = tv1 - (rs - rs_fit);
+            if (w_fit >= 12 && w_fit < tv1) *narrower = w_fit;
+        }
+    }
+    if (lds > lds_budget) {
+        snprintf(h->lean_why, sizeof(h->lean_why), "tiles of %d threads, <= %d rows need %zu LDS bytes (%d window rows x %d pairs; budget %zu)",
+                 threads, cap, lds, summary[0], rs, lds_budget);
+        return 1;
+    }
+    L.RS = rs;
+    h->lean4_rsk = 0;
+    h->lean4_lds = lds;
+    h->lean4_block = threads;
+    hipLaunchKernelGGL(k_lean4_off, grid_for(h->lean4_ptab_groups * 4), 256, 0, h->stream, L, h->lean4_ptab_groups);
+    // bands of the tile list: an XCD's working set is three axis-0 rows x (its share of axis 1 + position reach) x band rows x
+    // V1 floats.  Round 3 sized the bands for 1.5 MB of the 4 MB L2 (C3: 2 bands, C4: 3); measured on the balanced schedule
+    // of round 4, ONE band is fastest on both (C3 2.77 against 2.91 ms, C4 19.13 against 19.30 ms; profiles/r04_launch_order.log)
+    // -- the sweep is not bound by what the bands save -- but the bytes it moves through the L2s are: C4 with 1 / 2 / 3 / 4 / 6
+    // bands: 17.1 / 15.3 / 14.3 / 11.6 / 13.3 GB per launch at 19.1 / 18.9 / 19.0 / 18.9 / 19.1 ms
+    // (profiles/r04_c4_bands_traffic.log).  2.2 MB of working set per band gives C3 its one band (2 MB) and C4 four.
+    const int n1c = (P.dim[1] + 7) / 8 + 3;
+    const double per_row = 3.0 * n1c * (double)L.V1 * 4.0;
+    const int band_rows = std::max(8, (int)(2.2e6 / per_row) - (summary[0] ? 12 : 0));  // (bands are ranges of the tile LIST: no need to hold a whole tile's rows)
+    int nbands = std::max(1, std::min(ntr, (L.V0 + band_rows - 1) / band_rows));
+    if (ovr("BANDS") && atoi(ovr("BANDS")) > 0) nbands = std::min(ntr, atoi(ovr("BANDS")));  // (experiments: the launch order only)
+    h->lean4_bands = nbands;
+    std::vector<unsigned> sched;
+    // (sub_rows: a timed candidate sweeps a few rows of axis 0 from the middle of the slab -- the tiling is the same for every
+    //  row, so a tenth of the grid ranks the candidates at a tenth of the cost; window boxes and pitch are those of the slab)
+    if (sub_rows > 0 && sub_rows < rows && !ovr_is("NO_XCD", 1))
+        lean4_schedule(sub_rows, P.dim[1], ntr, nbands, sched, sub_r0);
+    else
+        lean4_schedule(rows, P.dim[1], ntr, ovr_is("NO_XCD", 1) ? 1 : nbands, sched);
+    if (ovr_is("NO_XCD", 1)) {  // plain order (experiments, tests): tile ids ascending
+        sched.resize((size_t)ntiles);
+        for (long long t = 0; t < ntiles; ++t) sched[(size_t)t] = (unsigned)t;
+    }
+    unsigned* d_sched = nullptr;
+    if ((rc = dev_alloc(h, sched.size(), &d_sched))) return rc;
+    HIPCHK(hipMemcpy(d_sched, sched.data(), sched.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    L.sched = d_sched;
+    h->lean4_grid = (unsigned)sched.size();
+    if (h->lean4_tiles) dev_release(h, h->lean4_tiles);
+    Lean4Tile* d_tiles = nullptr;
+    if ((rc = dev_alloc(h, sched.size(), &d_tiles))) return rc;
+    h->lean4_tiles = d_tiles;
+    hipLaunchKernelGGL(k_lean4_desc, grid_for((long long)sched.size()), 256, 0, h->stream, P, L, (const unsigned*)d_sched,
+                       (long long)sched.size(), d_tiles);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int pvi_plan_plane_tiles(int32_t V0, int32_t V1, const int32_t* corner0, int32_t cap, int32_t threads, int32_t wmax,
+                                    int32_t* tiles4, int32_t max_tiles) {
+    if (V0 < 1 || V1 < 1 || !corner0 || cap < 1 || wmax < 1 || (!tiles4 && max_tiles > 0) || max_tiles < 0)
+        return fail(PVI_EINVAL, "pvi_plan_plane_tiles: bad argument");
+    if (threads < 64 || threads > 512 || (threads & 63)) return fail(PVI_EINVAL, "threads must be 64 ... 512 in steps of 64");
+    std::vector<int2> pt0((size_t)V0);
+    for (int j = 0; j < V0; ++j) pt0[(size_t)j] = make_int2(corner0[j], 0);
+    std::vector<int4> out;
+    lean4_row_tiles(pt0, 0, V0, V1, cap, threads, wmax, out);
+    for (size_t k = 0; k < out.size() && (int)k < max_tiles; ++k) {
+        tiles4[4 * k] = out[k].x;
+        tiles4[4 * k + 1] = out[k].y;
+        tiles4[4 * k + 2] = out[k].z;
+        tiles4[4 * k + 3] = out[k].w;
+    }
+    return (int)out.size();
+}
+
+extern "C" int64_t pvi_plan_schedule(int32_t rows, int32_t n1, int32_t tiles_per_plane, int32_t bands, uint32_t* out, int64_t max_blocks) {
+    if (rows < 1 || n1 < 1 || tiles_per_plane < 1 || bands < 1 || bands > tiles_per_plane || (!out && max_blocks > 0) || max_blocks < 0)
+        return fail(PVI_EINVAL, "pvi_plan_schedule: bad argument");
+    if ((long long)rows * n1 * tiles_per_plane >= 0x7fffffffLL / 8) return fail(PVI_EINVAL, "pvi_plan_schedule: too many tiles");
+    std::vector<unsigned> sched;
+    lean4_schedule(rows, n1, tiles_per_plane, bands, sched);
+    for (size_t k = 0; k < sched.size() && (long long)k < max_blocks; ++k) out[k] = sched[k];
+    return (int64_t)sched.size();
+}
+
+static int lean4_setup(pvi_problem* h) {
+    const DevP& P = h->P;
+    Lean4P& L = h->L4;
+    memset(&L, 0, sizeof(L));
+    h->lean4_ok = false;
+    if (!h->fast_ok || P.dof != 2 || ovr("NO_LEAN") || ovr_is("WIN", 0) || h->stored >= 0x7fffffffLL) return PVI_OK;
+    if (!(h->own_J || (h->d.flags & PVI_FLAG_EXT_J_SLACK))) return PVI_OK;  // the 16-byte window loads may run 12 bytes past a row
+    if (P.strd[0] * 16 >= (1LL << 31)) return PVI_OK;  // the window fill addresses planes by 32-bit byte offsets from the window origin
+    const int rows = P.row_end - P.row_begin;
+    const long long npos = (long long)rows * P.dim[1];
+    int rc;
+    L.owned = h->owned;
+    h->lean4_stage = 2;
+    L.ngroups = (P.A + 3) / 4;
+    float2* tsp_node = nullptr;
+    float* gx_node = nullptr;
+    int2 *pt0 = nullptr, *pt1 = nullptr;
+    if ((rc = dev_alloc(h, (size_t)h->owned, &L.flag))) return rc;
+    if ((rc = dev_alloc(h, (size_t)P.dim[0] * P.dim[2], &pt0))) return rc;
+    if ((rc = dev_alloc(h, (size_t)P.dim[1] * P.dim[3], &pt1))) return rc;
+    if ((rc = dev_alloc(h, 8, &L.summary))) return rc;
+    float* ptab_full = nullptr;
+    if ((rc = dev_alloc(h, (size_t)npos * L.ngroups * 24, &ptab_full))) return rc;
+    if ((rc = dev_alloc(h, (size_t)2 * h->owned, &tsp_node))) return rc;
+    L.pt0 = pt0;
+    L.pt1 = pt1;
+    // g_x: a sum of per-axis terms when Q is diagonal (then no per-node array); TABLES=0 keeps the per-node arrays
+    const bool want_tables = !ovr_is("TABLES", 0);
+    bool diag = want_tables;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            if (i != j && h->d.Q[i * 4 + j] != 0.0) diag = false;
+    if (diag) {
+        for (int d = 0; d < 4; ++d) {
+            std::vector<double> t((size_t)P.dim[d]);
+            for (int k = 0; k < P.dim[d]; ++k) {
+                const double dx = h->d.x_level[d][k] - h->d.xbar[d];
+                // quad_form: row_d = sum_j Q[d][j] dx_j with the off-diagonal terms exactly zero, term = dx_d * row_d
+                t[(size_t)k] = dx * (h->d.Q[d * 4 + d] * dx);
+            }
+            if ((rc = dev_upload(h, t.data(), t.size(), &L.gt[d]))) return rc;
+        }
+    } else {
+        if ((rc = dev_alloc(h, (size_t)h->owned, &gx_node))) return rc;
+        // (the sweep loads both forms of g_x without a branch and keeps the one that applies: one-word zero tables to read)
+        const double zero = 0.0;
+        for (int d = 0; d < 4; ++d)
+            if ((rc = dev_upload(h, &zero, 1, &L.gt[d]))) return rc;
+    }
+    L.gx = gx_node;
+    HIPCHK(hipMemsetAsync(L.summary, 0, 8 * sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_lean_pairs, grid_for((long long)P.dim[0] * P.dim[2]), 256, 0, h->stream, P, 0, pt0);
+    hipLaunchKernelGGL(k_lean_pairs, grid_for((long long)P.dim[1] * P.dim[3]), 256, 0, h->stream, P, 1, pt1);
+#define L4DISPATCH(MACRO)                                  \
+    switch (h->d.dynamics_id) {                            \
+        case PVI_DYN_CARTPOLE: MACRO(PVI_DYN_CARTPOLE) break; \
+        case PVI_DYN_NODE_2x1: MACRO(PVI_DYN_NODE_2x1) break; \
+        case PVI_DYN_NODE_2x2: MACRO(PVI_DYN_NODE_2x2) break; \
+        default: MACRO(PVI_DYN_TWOLINK) break;                \
+    }
+#define L4PT(DYN) hipLaunchKernelGGL((k_lean4_ptab<DYN>), grid_for(npos * L.ngroups * 4), 256, 0, h->stream, P, L, ptab_full);
+    L4DISPATCH(L4PT)
+#undef L4PT
+    // the (position node, action) table rarely depends on both position axes (cart-pole, two-link arm: H(q) depends on the
+    // second joint only): keep it over the axes it does depend on -- a CU then finds its rows in the scalar cache
+    L.pcs[0] = P.dim[1];
+    L.pcs[1] = 1;
+    L.ptab = ptab_full;
+    h->lean4_ptab_inv = 0;
+    if (want_tables) {
+        const int all = 3;
+        int inv = 0;
+        HIPCHK(hipMemcpyAsync(L.summary + 7, &all, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_lean4_ptab_inv, grid_for(npos * L.ngroups * 24), 256, 0, h->stream, P, L, (const float*)ptab_full, L.summary + 7);
+        HIPCHK(hipMemcpyAsync(&inv, L.summary + 7, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (inv) {
+            const int n0 = (inv & 1) ? 1 : rows, n1 = (inv & 2) ? 1 : P.dim[1];
+            float* compact = nullptr;
+            if ((rc = dev_alloc(h, (size_t)n0 * n1 * L.ngroups * 24, &compact))) return rc;
+            hipLaunchKernelGGL(k_lean4_ptab_compact, grid_for((long long)n0 * n1 * L.ngroups * 24), 256, 0, h->stream, P, L,
+                               (const float*)ptab_full, compact, n0, n1);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(h->stream));
+            dev_release(h, ptab_full);
+            L.ptab = compact;
+            L.pcs[0] = (inv & 1) ? 0 : n1;
+            L.pcs[1] = (inv & 2) ? 0 : 1;
+            h->lean4_ptab_inv = inv;
+        }
+    }
+    h->lean4_ptab_groups = (long long)((h->lean4_ptab_inv & 1) ? 1 : rows) * ((h->lean4_ptab_inv & 2) ? 1 : P.dim[1]) * L.ngroups;
+#define L4ND(DYN) hipLaunchKernelGGL((k_lean4_node<DYN>), grid_for(h->owned), 256, 0, h->stream, P, L, tsp_node, gx_node);
+    L4DISPATCH(L4ND)
+#undef L4ND
+#undef L4DISPATCH
+    HIPCHK(hipGetLastError());
+    int summary[8];
+    HIPCHK(hipMemcpyAsync(summary, L.summary, sizeof(summary), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    auto give_up = [&](const char* why) {
+        snprintf(h->lean_why, sizeof(h->lean_why), "%s", why);
+        dev_release(h, L.flag); dev_release(h, pt0); dev_release(h, pt1); dev_release(h, L.summary); dev_release(h, L.ptab);
+        dev_release(h, tsp_node); dev_release(h, gx_node);
+        if (L.tsp && L.tsp != tsp_node) dev_release(h, (void*)L.tsp);
+        if (L.tlist) dev_release(h, (void*)L.tlist);
+        if (L.win) dev_release(h, L.win);
+        if (L.sched) dev_release(h, (void*)L.sched);
+        for (int d = 0; d < 4; ++d) dev_release(h, (void*)L.gt[d]);
+        memset(&L, 0, sizeof(L));
+        return PVI_OK;
+    };
+    if (summary[3]) return give_up((summary[3] & 2) ? "an action fails isavalidinput" : "halo too small");
+    // ---- the axes the displacement does not depend on -> compact table ---------------------------------------------------
+    const long long full[4] = {P.plane, (long long)P.dim[2] * P.dim[3], P.dim[3], 1};
+    int inv = 0;
+    if (want_tables) {
+        const int all = 0xf;
+        HIPCHK(hipMemcpyAsync(L.summary + 6, &all, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_lean4_invariance, grid_for(h->owned), 256, 0, h->stream, P, L, (const float2*)tsp_node);
+        HIPCHK(hipMemcpyAsync(&inv, L.summary + 6, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    h->lean4_tables = inv;
+    if (inv) {
+        const int dims[4] = {rows, P.dim[1], P.dim[2], P.dim[3]};
+        int nk[4];
+        long long cs = 1;
+        for (int d = 3; d >= 0; --d) {
+            nk[d] = (inv >> d) & 1 ? 1 : dims[d];
+            L.cs[d] = (inv >> d) & 1 ? 0 : (int)cs;
+            cs *= nk[d];
+        }
+        L.csize = cs;
+        float2* compact = nullptr;
+        if ((rc = dev_alloc(h, (size_t)2 * cs, &compact))) return rc;
+        hipLaunchKernelGGL(k_lean4_compact, grid_for(cs), 256, 0, h->stream, P, L, (const float2*)tsp_node, compact, nk[0], nk[1], nk[2], nk[3]);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));
+        dev_release(h, tsp_node);
+        tsp_node = nullptr;
+        L.tsp = compact;
+    } else {
+        for (int d = 0; d < 4; ++d) L.cs[d] = (int)full[d];
+        L.csize = h->owned;
+        L.tsp = tsp_node;
+    }
+    // ---- the velocity cells every node reaches, once: each candidate tiling folds them into its window boxes ---------------
+    struct BoxGuard {  // (set-up scratch: four bytes per owned node, gone on every way out)
+        Lean4P& L;
+        ~BoxGuard() {
+            if (L.box) (void)hipFree((void*)L.box);
+            L.box = nullptr;
+        }
+    } box_guard{L};
+    if (!ovr_is("TUNE", 0) && !(ovr("TV0") && ovr("TV1"))) {  // (a single candidate computes its boxes directly)
+        char4* box = nullptr;
+        if (hipMalloc((void**)&box, (size_t)h->owned * sizeof(char4)) != hipSuccess) {
+            (void)hipGetLastError();  // no room: the direct path
+            box = nullptr;
+        }
+        if (box) {
+            L.box = box;
+            L.V0 = P.dim[2];  // (the geometry fields every candidate sets again in lean4_try)
+            L.V1 = P.dim[3];
+            L.posdim1 = P.dim[1];
+            L.vplane = (long long)L.V0 * L.V1;
+            L.owned = h->owned;
+            int over = 0;
+            HIPCHK(hipMemcpyAsync(L.summary + 7, &over, sizeof(int), hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(k_lean4_nodebox, grid_for(h->owned), 256, 0, h->stream, P, L, box);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(&over, L.summary + 7, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (over) {  // a reach beyond +-126 cells does not fit a byte
+                (void)hipFree(box);
+                L.box = nullptr;
+            }
+        }
+    }
+    // ---- tiling candidates, timed ------------------------------------------------------------------------------------------
+    std::vector<int2> hpt0((size_t)P.dim[0] * P.dim[2]);
+    HIPCHK(hipMemcpy(hpt0.data(), pt0, hpt0.size() * sizeof(int2), hipMemcpyDeviceToHost));
+    const size_t budget = ovr("LDS_KB") ? (size_t)atoi(ovr("LDS_KB")) * 1024 : (size_t)80 * 1024;  // two workgroups per CU
+    std::vector<Lean4Cand> cands;
+    const int V1 = P.dim[3];
+    int pin[3] = {0, 0, 0};
+    if (ovr("L4PIN") && sscanf(ovr("L4PIN"), "%d/%d/%d", &pin[0], &pin[1], &pin[2]) == 3 && pin[0] > 0 && pin[1] >= 64 && pin[2] > 0) {
+        // exactly one candidate of the list below -- rows cap / threads / widest tile, as `choice=` of pvi_describe prints it:
+        // the counter passes pin the shape an unprofiled create chose (the timed choice can flip under the profiler)
+        cands.push_back({pin[0], pin[1], pin[2]});
+    } else if (ovr("TV0") && ovr("TV1")) {  // rows cap, and the tile width the workgroup is sized for (cap x width threads)
+        cands.push_back({atoi(ovr("TV0")), std::min(512, ((atoi(ovr("TV0")) * atoi(ovr("TV1")) + 63) / 64) * 64), atoi(ovr("TV1"))});
+    } else {
+        // Tilings worth timing: workgroups of 3 .. 8 waves, and for each the row caps whose tiles (step-aligned row pieces,
+        // each split into columns as wide as the workgroup allows) keep the largest share of the lanes busy = nodes of a
+        // velocity plane / (tiles x threads), judged on a middle row.  The best caps per workgroup size are timed.
+        std::vector<int4> tl;
+        for (int min_threads : {192, 64}) {  // (small grids: whatever fills a wave)
+            for (int threads : {512, 384, 320, 256, 192, 128, 64}) {
+                if (threads < min_threads || (min_threads == 64 && threads >= 192)) continue;
+                struct Eff {
+                    double e;
+                    int cap;
+                };
+                std::vector<Eff> effs;
+                size_t last_n = 0;
+                for (int cap = std::min(P.dim[2], threads / 8); cap >= 2; --cap) {
+                    lean4_row_tiles(hpt0, P.row_begin + rows / 2, P.dim[2], V1, cap, threads, V1, tl);
+                    if (tl.size() == last_n) continue;  // (most caps give the same pieces as their neighbour)
+                    last_n = tl.size();
+                    int wmin = V1;
+                    for (auto& t : tl) wmin = std::min(wmin, t.w);
+                    if (wmin < std::min(V1, 12)) continue;  // very narrow tiles: the window is all halo
+                    effs.push_back({(double)P.dim[2] * V1 / ((double)tl.size() * threads), cap});
+                }
+                std::sort(effs.begin(), effs.end(), [](const Eff& a, const Eff& b) { return a.e > b.e; });
+                for (size_t i = 0; i < effs.size() && i < 4 && cands.size() < 24; ++i)
+                    if (effs[i].e >= 0.85 * effs[0].e) cands.push_back({effs[i].cap, threads, V1});
+            }
+            if (!cands.empty()) break;
+        }
+    }
+    // ---- the choice of an earlier create of the same problem shape in this process -------------------------------------------
+    char key[256];
+    snprintf(key, sizeof(key), "%d/%d:%dx%dx%dx%d:A%d:rows%d:dt%.17g:lb%.17g,%.17g:ub%.17g,%.17g:lds%zu", h->device, h->d.dynamics_id,
+             P.dim[0], P.dim[1], P.dim[2], P.dim[3], P.A, rows, P.dt, P.lb[2], P.lb[3], P.ub[2], P.ub[3], budget);
+    bool from_cache = false;
+    if (!ovr_is("TUNE", 0) && !(ovr("TV0") && ovr("TV1")) && !ovr("L4PIN") && !ovr_is("TUNE", 2)) {
+        std::lock_guard<std::mutex> lk(g_lean4_choice_mu);
+        auto it = g_lean4_choice.find(key);
+        if (it != g_lean4_choice.end()) {
+            cands.assign(1, it->second);
+            from_cache = true;
+        }
+    }
+    const bool tune = !ovr_is("TUNE", 0) && cands.size() > 1;
+    // Timed candidates (round 4): every candidate sweeps the SAME few rows of axis 0 from the middle of the slab -- one warm-up
+    // and five timed sweeps, each between its own pair of events -- and is judged by the MEDIAN; a later candidate displaces
+    // the best so far only by 5 %.  Round 3 timed two whole-grid sweeps per candidate (C4: 52 x 25 ms) and a 2 % margin: the
+    // choice flipped between runs (55x26 / 55x22, a 9 % swing of the bench line) and set-up took 3.5-6 s.
+    const int sub_rows = std::min(rows, 12), sub_r0 = (rows - sub_rows) / 2;
+    hipEvent_t tev[7] = {};
+    struct EvGuard {
+        hipEvent_t* e;
+        ~EvGuard() {
+            for (int i = 0; i < 7; ++i)
+                if (e[i]) (void)hipEventDestroy(e[i]);
+        }
+    } ev_guard{tev};
+    if (tune)
+        for (auto& e : tev) HIPCHK(hipEventCreate(&e));
+    float best_ms = 1e30f;
+    int best = -1;
+    for (size_t ci = 0; ci < cands.size(); ++ci) {
+        int narrower = 0;
+        rc = lean4_try(h, hpt0, cands[ci].cap, cands[ci].w, cands[ci].wmax, budget, &narrower, tune ? sub_r0 : 0,
+                       tune ? sub_rows : -1);
+        if (rc < 0) return rc;
+        if (rc) continue;
+        if (!tune) {
+            best = (int)ci;
+            break;
+        }
+        float ms = 0.f;
+        SweepCtl sc;
+        memset(&sc, 0, sizeof(sc));
+        sc.ctrl = h->ctrl;
+        sc.slot = h->slots;
+        sc.result = h->results;
+        sc.tol = -1.0;
+        bool hopeless = false;
+        for (int rep = 0; rep < 6 && rc == 0 && !hopeless; ++rep) {  // one warm-up, five timed
+            HIPCHK(hipEventRecord(tev[rep], h->stream));
+            hipLaunchKernelGGL(k_reset_stats, 1, STAT_WORDS, 0, h->stream, h->slots, STAT_WORDS);
+            hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, h->stream, h->ctrl);
+            rc = h->pi_size == 1 ? launch_lean4_t<unsigned char>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc, true)
+                                 : launch_lean4_t<unsigned short>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc, true);
+            if (rc) return rc;
+            if (rep == 0) {  // (the warm-up sweep of a shape far off the best: not worth five more)
+                float warm = 0.f;
+                HIPCHK(hipEventRecord(tev[6], h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                HIPCHK(hipEventElapsedTime(&warm, tev[0], tev[6]));
+                if (best >= 0 && warm > 1.6f * best_ms) {
+                    hopeless = true;
+                    ms = warm;
+                }
+            }
+        }
+        if (rc) return rc;
+        if (!hopeless) {
+            HIPCHK(hipEventRecord(tev[6], h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            float t[5];
+            for (int i = 0; i < 5; ++i) HIPCHK(hipEventElapsedTime(&t[i], tev[1 + i], tev[i + 2 <= 5 ? i + 2 : 6]));
+            std::sort(t, t + 5);
+            ms = t[2];
+        }
+        {
+            // (milliseconds of the timed rows scaled to the slab: comparable with a whole sweep)
+            const float full = ms * (float)rows / (float)sub_rows;
+            const size_t at = strlen(h->lean4_cands);
+            if (cands[ci].wmax < V1)
+                snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, ",%d/%d/%d:%.2f", cands[ci].cap, cands[ci].w, cands[ci].wmax, full);
+            else
+                snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, "%s%d/%d:%.2f", at ? "," : "", cands[ci].cap, cands[ci].w, full);
+        }
+        // (a narrower twin of a shape that is in the running: one more workgroup per CU may pay for the extra window halo)
+        if (narrower && cands[ci].wmax == V1 && ms < 1.1f * best_ms && cands.size() < 48)
+            cands.push_back({cands[ci].cap, cands[ci].w, narrower});
+        if (ms < 0.95f * best_ms) {  // a later candidate must win by 5 %: within the timing noise the choice stays put, so the
+            best_ms = ms;            // shape (and with it the committed counter passes) is the same from run to run
+            best = (int)ci;
+        }
+    }
+    if (best < 0) return give_up(h->lean_why[0] ? h->lean_why : "no tile shape fits the LDS budget");
+    if (tune) {
+        if ((rc = lean4_try(h, hpt0, cands[(size_t)best].cap, cands[(size_t)best].w, cands[(size_t)best].wmax, budget, nullptr)))
+            return rc < 0 ? rc : give_up("tile shape lost");
+        // the timed sweeps wrote into the second J buffer, pi and the control block
+        HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream));
+        HIPCHK(hipMemsetAsync(h->pi, 0, (size_t)h->owned * h->pi_size, h->stream));
+        HIPCHK(hipMemsetAsync(h->J[h->cur ^ 1], 0, (size_t)h->stored * 4, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    if (best >= 0 && !from_cache && tune) {
+        std::lock_guard<std::mutex> lk(g_lean4_choice_mu);
+        g_lean4_choice[key] = cands[(size_t)best];
+    }
+    if (from_cache) snprintf(h->lean4_cands, sizeof(h->lean4_cands), "cached");
+    snprintf(h->lean4_choice, sizeof(h->lean4_choice), "%d/%d/%d", cands[(size_t)best].cap, cands[(size_t)best].w, cands[(size_t)best].wmax);
+    h->lean_why[0] = 0;
+    h->lean4_ok = true;
+    return PVI_OK;
+}
+
+int lean_setup(pvi_problem* h) {
+    const DevP& P = h->P;
+    LeanP& L = h->LP;
+    const float* actc = L.actc;  // uploaded by pvi_create together with the float4 action table
+    memset(&L, 0, sizeof(L));
+    L.actc = actc;
+    h->lean_ok = false;
+    if (!h->fast_ok || ovr("NO_LEAN")) return PVI_OK;
+    const int DOF = P.dof, M = P.m;
+    int rc;
+    if ((rc = lean4_setup(h))) return rc;
+    if (h->lean4_ok) return PVI_OK;  // 4-D grids: the paired-window kernel (sweep_lean4.inc)
+    if ((rc = dev_alloc(h, (size_t)DOF * h->owned, &L.ta))) return rc;
+    if ((rc = dev_alloc(h, (size_t)DOF * M * h->owned, &L.tB))) return rc;
+    if ((rc = dev_alloc(h, (size_t)h->owned, &L.gx))) return rc;
+    if ((rc = dev_alloc(h, (size_t)h->owned, &L.flag))) return rc;
+    if ((rc = dev_alloc(h, (size_t)P.dim[0] * P.dim[DOF], &L.pt0))) return rc;
+    if (DOF == 2 && (rc = dev_alloc(h, (size_t)P.dim[1] * P.dim[3], &L.pt1))) return rc;
+    if ((rc = dev_alloc(h, 8, &L.summary))) return rc;
+    L.guard = h->F.guard;
+    hipLaunchKernelGGL(k_lean_pairs, grid_for((long long)P.dim[0] * P.dim[DOF]), 256, 0, h->stream, P, 0, L.pt0);
+    if (DOF == 2)
+        hipLaunchKernelGGL(k_lean_pairs, grid_for((long long)P.dim[1] * P.dim[3]), 256, 0, h->stream, P, 1, L.pt1);
+    HIPCHK(hipGetLastError());
+    // lanes per node for small grids: as many as still fit ONE round of resident waves (1024 SIMDs x 8 waves x 64
+    // lanes); a second round costs more than the extra parallelism brings (201x201x201: 27 -> 23 us)
+    int ls = 0;
+    // (measured: 401^2 x 101 is best at 4 lanes per node -- 1.2 rounds, 25 actions per lane; 201^2 x 201 loses at 16
+    //  lanes with 12 actions per lane: allow a quarter round more while a lane keeps >= 16 actions)
+    while (((h->owned << (ls + 1)) <= (1ll << 19) ||
+            ((h->owned << (ls + 1)) <= 655360 && P.A / (2 << ls) >= 16)) &&
+           (2 << ls) <= 16 && (4 << ls) <= P.A)
+        ++ls;
+    if (const char* e = ovr("LSPLIT")) ls = atoi(e);
+    L.lsplit = ls;
+    const int spb = std::max(16, 256 >> ls);  // nodes per workgroup
+    int budget = DOF == 1 ? 8 * 1024 : 20 * 1024;  // floats: 32 KB (2-D), 80 KB (4-D: two workgroups per CU)
+    if (const char* e = ovr("LDS_KB")) budget = atoi(e) * 256;
+    budget = std::min(budget, 40000);
+    int shapes[8][2];
+    int ns = 0;
+    if (ovr("TV0") && ovr("TV1")) {
+        shapes[ns][0] = atoi(ovr("TV0"));
+        shapes[ns++][1] = atoi(ovr("TV1"));
+    } else if (DOF == 1) {
+        // measured on 1001^2 x 51: 8x32 51.7 us, 4x63 52.3, 2x126 53.8, 1x251 55.0, 512-thread shapes 56-60
+        shapes[ns][0] = std::max(1, spb / 32); shapes[ns++][1] = 32;
+        shapes[ns][0] = std::max(1, spb / 64); shapes[ns++][1] = 64;
+        shapes[ns][0] = 1; shapes[ns++][1] = spb;
+        shapes[ns][0] = 1; shapes[ns++][1] = std::max(16, spb / 2);
+    } else {
+        // 4-D: long tiles along the last axis amortise the window best (measured on 101^4: 10x51 tile)
+        const int V1 = P.dim[3];
+        const int t1 = (V1 + (V1 + 63) / 64 - 1) / ((V1 + 63) / 64);
+        shapes[ns][0] = std::max(1, 2 * spb / t1); shapes[ns++][1] = t1;
+        shapes[ns][0] = std::max(1, spb / t1); shapes[ns++][1] = t1;
+        shapes[ns][0] = std::max(1, 2 * spb / 32); shapes[ns++][1] = 32;
+        shapes[ns][0] = std::max(1, spb / 32); shapes[ns++][1] = 32;
+        shapes[ns][0] = std::max(1, spb / 16); shapes[ns++][1] = 16;
+    }
+    // two nodes per thread (2-D, uniform action walk; tiles twice as tall for the same workgroup size) halve the
+    // per-wave fixed work and fit 1001^2 into one round of resident waves (A = 1: 21 -> 15 us), but the two
+    // register-resident node contexts cost the action loop more than that (C2 43.7 -> 49 us at 71 VGPRs / 7 waves,
+    // 55 us squeezed to 63 VGPRs): opt-in for experiments, PVI_NPT=2
+    L.npt = 1;
+    if (DOF == 1 && ls == 0 && ovr("NPT")) {
+        const int want = atoi(ovr("NPT"));
+        if (want == 2) L.npt = want;
+    }
+    // 4-D: the best tile shape depends on how the grid divides (101^4: 15x34 beats 10x51 by 8 %, 151^4: 19x26 beats
+    // 16x31 by 7 %) -- time the candidates (widths V1/k, as many rows as fit 512 threads) with two real sweeps each and
+    // keep the fastest.  Results do not depend on the shape (same arithmetic per node).  PVI_TUNE=0 switches it off.
+    if (DOF == 2 && ls == 0 && !(ovr("TV0") && ovr("TV1")) && !(ovr("TUNE") && !atoi(ovr("TUNE")))) {
+        const int V1 = P.dim[3];
+        float best_ms = 1e30f;
+        int best[2] = {0, 0};
+        for (int k = 1; k <= 8; ++k) {
+            const int w = (V1 + k - 1) / k;
+            if (w > 64 && k < 8) continue;
+            if (w < 16) break;
+            const int t0 = std::max(1, std::min(L.V0 ? L.V0 : P.dim[2], 512 / w));
+            rc = lean_try(h, t0, w, budget);
+            if (rc < 0) return rc;
+            if (rc == 2) break;
+            if (rc != 0) continue;
+            const int threads = L.TV0 * L.TV1;
+            h->lean_block = ((threads + 63) / 64) * 64;
+            if (h->lean_block > 512) continue;
+            h->lean_ok = true;
+            h->lean_lds_attr = false;
+            float ms = 0.f;
+            for (int rep = 0; rep < 3 && rc == 0; ++rep) {  // one warm-up, two timed
+                if (rep == 1) HIPCHK(hipEventRecord(h->ev0, h->stream));
+                hipLaunchKernelGGL(k_reset_stats, 1, STAT_WORDS, 0, h->stream, h->slots, STAT_WORDS);
+                hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, h->stream, h->ctrl);
+                rc = launch_sweep(h, h->cur, 1.0, h->stream, 0, -1.0);
+            }
+            h->lean_ok = false;
+            if (rc) return rc;
+            HIPCHK(hipEventRecord(h->ev1, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+            if (ms < best_ms) {
+                best_ms = ms;
+                best[0] = L.TV0;
+                best[1] = L.TV1;
+            }
+        }
+        if (best[0]) {
+            ns = 0;
+            shapes[ns][0] = best[0];
+            shapes[ns++][1] = best[1];
+        }
+        // the timed sweeps wrote garbage into the second J buffer, pi and the control block: clear what a caller
+        // could observe before the first pvi_terminal_cost / pvi_set_J
+        HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream));
+        HIPCHK(hipMemsetAsync(h->pi, 0, (size_t)h->owned * h->pi_size, h->stream));
+        HIPCHK(hipMemsetAsync(h->J[h->cur ^ 1], 0, (size_t)h->stored * (h->d.dtype == PVI_F64 ? 8 : 4), h->stream));
+    }
+    // first candidate shape that fits the LDS budget (rc: 0 taken / lean_ok set, < 0 error)
+    int rowmul = 1;  // 2-D: 2 = twice the rows per workgroup at one node per thread (512 threads)
+    auto take_shape = [&]() -> int {
+        for (int k = 0; k < ns; ++k) {
+            int r = lean_try(h, shapes[k][0] * L.npt * rowmul, shapes[k][1], budget);
+            if (r < 0) return r;
+            if (r == 2) break;
+            if (r == 0) {
+                const int threads = L.npt > 1 ? L.half : ((L.TV0 * L.TV1) << L.lsplit);
+                h->lean_block = ((threads + 63) / 64) * 64;
+                if (h->lean_block > (L.npt > 1 ? 256 : 512)) continue;
+                h->lean_ok = true;
+                h->lean_lds_attr = false;
+                return 0;
+            }
+        }
+        return 0;
+    };
+    // 2-D grids walked uniformly: one or two nodes per thread?  Two halve the waves (dispatch, per-wave set-up, one
+    // round of resident waves instead of two) but leave less to overlap; which wins depends on the action count
+    // (2001^2 x 21: 67.7 -> 59.1 us with two, 1001^2 x 51: 35.4 -> 37.5 us), so both run a few timed sweeps here and
+    // the faster stays.  Results do not depend on it (same arithmetic per node).  PVI_NPT fixes it, PVI_TUNE=0 keeps 1.
+    if (DOF == 1 && ls == 0 && !ovr("NPT") && h->owned >= (1 << 17) && !(ovr("TUNE") && !atoi(ovr("TUNE")))) {
+        // (clocks ramp up during the first sweeps after a create: the candidates alternate, two rounds of 40 timed
+        //  sweeps behind 20 untimed ones each, and a candidate is judged by its faster round)
+        // third candidate: one node per thread in 512-thread workgroups (half as many workgroups to dispatch, the window
+        // shared by twice the rows): 1001^2 x 51 35.9 -> 33.1 us (768 threads: 39 us, 1024: 50 us)
+        float best_of[4] = {0.f, 1e30f, 1e30f, 1e30f};
+        for (int round = 0; round < 2; ++round)
+            for (int cand = 1; cand <= 3; ++cand) {
+                L.npt = cand == 2 ? 2 : 1;
+                rowmul = cand == 3 ? 2 : 1;
+                h->lean_ok = false;
+                if ((rc = take_shape()) < 0) return rc;
+                if (!h->lean_ok) continue;
+                float ms = 0.f;
+                for (int rep = 0; rep < 60 && rc == 0; ++rep) {
+                    if (rep == 20) HIPCHK(hipEventRecord(h->ev0, h->stream));
+                    hipLaunchKernelGGL(k_reset_stats, 1, STAT_WORDS, 0, h->stream, h->slots, STAT_WORDS);
+                    hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, h->stream, h->ctrl);
+                    rc = launch_sweep(h, h->cur, 1.0, h->stream, 0, -1.0);
+                }
+                h->lean_ok = false;
+                if (rc) return rc;
+                HIPCHK(hipEventRecord(h->ev1, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+                best_of[cand] = std::min(best_of[cand], ms);
+            }
+        int best_cand = 1;  // a candidate other than the plain one must win by 2 %
+        if (best_of[2] < 0.98f * best_of[best_cand]) best_cand = 2;
+        if (best_of[3] < (best_cand == 1 ? 0.98f : 1.f) * best_of[best_cand]) best_cand = 3;
+        const int best_npt = best_cand == 2 ? 2 : 1;
+        rowmul = best_cand == 3 ? 2 : 1;
+        L.npt = best_npt;
+        HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(Ctrl), h->stream));
+        HIPCHK(hipMemsetAsync(h->pi, 0, (size_t)h->owned * h->pi_size, h->stream));
+        HIPCHK(hipMemsetAsync(h->J[h->cur ^ 1], 0, (size_t)h->stored * (h->d.dtype == PVI_F64 ? 8 : 4), h->stream));
+    }
+    if ((rc = take_shape()) < 0) return rc;
+    if (h->lean_ok && L.tb_tile) {  // tB lives per tile: the per-node copy is not needed any more
+        dev_release(h, L.tB);
+        L.tB = nullptr;
+    }
+    // float32 accuracy guard: the displacement rel = ta + sum tB u is formed from float32 copies of ta and tB.  When
+    // those operands are hundreds of cells and cancel (light links with strong actuators: the default two-link arm has
+    // |ta| + |tB u| up to 3800 cells), their rounding alone moves the fraction by > 1e-5 cells and J by > 1e-5
+    // relative (tools/tools_fuzz.py).  Such problems run the kernel with float64 dynamics and float32 storage instead.
+    if (h->lean_opmag > 256) {
+        snprintf(h->lean_why, sizeof(h->lean_why), "float32 displacement operands reach %d cells: float64 dynamics", h->lean_opmag);
+        h->lean_ok = false;
+        h->fast_ok = false;
+    }
+    if (!h->lean_ok) {  // release the per-node arrays: the fast / tiled kernels do not need them
+        dev_release(h, L.ta); dev_release(h, L.tB); dev_release(h, L.gx); dev_release(h, L.flag);
+        dev_release(h, L.win); dev_release(h, L.tbt);
+        L.ta = L.tB = L.gx = nullptr; L.flag = nullptr; L.win = nullptr; L.tbt = nullptr;
+    }
+    return PVI_OK;
+}
+
+// =================================================================================================
+// launchers of the sweeps (called from launch_sweep_t, pyrovi.hip)
+// =================================================================================================
+int launch_lean4(pvi_problem* h, const float* Jin, float* Jout, float alpha, hipStream_t st, SweepCtl sc) {
+    return h->pi_size == 1 ? launch_lean4_t<unsigned char>(h, Jin, Jout, alpha, st, sc) : launch_lean4_t<unsigned short>(h, Jin, Jout, alpha, st, sc);
+}
+
+template <typename PI_T>
+static int launch_lean2_t(pvi_problem* h, const float* Jin, float* Jout, float alpha, hipStream_t st, SweepCtl sc) {
+    PI_T* pi = (PI_T*)h->pi;
+    {
+        {
+            const float al = alpha;
+            sc.nblocks = h->lean_grid.x;
+            if (sc.split_finish != 2)
+                sc.split_finish = ((sc.nblocks >= 16384u || ovr_is("SPLIT_FINISH", 1)) && !ovr("NO_SPLIT_FINISH")) ? 1 : 0;
+#define LEAN3(DYN, U, NP) LEAN4(DYN, U, NP, 0)
+#define LEAN4(DYN, U, NP, RSK)                                                                                      \
+    {                                                                                                               \
+        auto kfn = k_sweep_lean<DYN, PI_T, U, NP, RSK>;                                                                  \
+        set_kname(h, "k_sweep_lean", (int)DYN, tname<PI_T>(), (bool)U, (int)NP, (int)RSK);                              \
+        if (!h->lean_lds_attr && h->lean_lds > 48 * 1024) {                                                         \
+            HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PVI_LDS_MAX)); \
+            h->lean_lds_attr = true;                                                                                \
+        }                                                                                                           \
+        hipLaunchKernelGGL(kfn, h->lean_grid, h->lean_block, h->lean_lds, st, h->P, h->LP, h->F.act, h->LP.actc, Jin, Jout, pi, al, \
+                           sc);                                                                                     \
+        if (sc.split_finish == 1) hipLaunchKernelGGL(k_sweep_finish, 1, STAT_SHARDS, 0, st, sc);                    \
+    }
+#define LEAN(DYN)                                                  \
+    if (h->LP.lsplit == 0) {                                       \
+        if (h->LP.RS == 64)                          \
+            LEAN4(DYN, true, 1, 64)                                \
+        else if (Dyn<DYN>::DOF == 1 && h->LP.RS == 128) \
+            LEAN4(DYN, true, 1, 128)                               \
+        else                                                       \
+            LEAN3(DYN, true, 1)                                    \
+    } else                                                         \
+        LEAN3(DYN, false, 1)
+            switch (h->d.dynamics_id) {
+                case PVI_DYN_PENDULUM:
+                    if (h->LP.npt == 2 && h->LP.RS == 64)
+                        LEAN4(PVI_DYN_PENDULUM, true, 2, 64)
+                    else if (h->LP.npt == 2 && h->LP.RS == 128)
+                        LEAN4(PVI_DYN_PENDULUM, true, 2, 128)
+                    else if (h->LP.npt == 2)
+                        LEAN3(PVI_DYN_PENDULUM, true, 2)
+                    else
+                        LEAN(PVI_DYN_PENDULUM)
+                    break;
+                case PVI_DYN_CARTPOLE: LEAN(PVI_DYN_CARTPOLE) break;
+                case PVI_DYN_NODE_1x1: LEAN(PVI_DYN_NODE_1x1) break;
+                case PVI_DYN_NODE_2x1: LEAN(PVI_DYN_NODE_2x1) break;
+                case PVI_DYN_NODE_2x2: LEAN(PVI_DYN_NODE_2x2) break;
+                default: LEAN(PVI_DYN_TWOLINK) break;
+            }
+#undef LEAN
+#undef LEAN3
+#undef LEAN4
+            HIPCHK(hipGetLastError());
+            return PVI_OK;
+        }
+    }
+}
+int launch_lean2(pvi_problem* h, const float* Jin, float* Jout, float alpha, hipStream_t st, SweepCtl sc) {
+    return h->pi_size == 1 ? launch_lean2_t<unsigned char>(h, Jin, Jout, alpha, st, sc) : launch_lean2_t<unsigned short>(h, Jin, Jout, alpha, st, sc);
+}
+
+template <typename PI_T>
+static int launch_fast_t(pvi_problem* h, const float* Jin, float* Jout, float alpha, hipStream_t st, SweepCtl sc) {
+    PI_T* pi = (PI_T*)h->pi;
+    {
+        {
+            const unsigned gf = grid_for(h->owned << h->F.lsplit);
+            const float al = alpha;
+            sc.nblocks = gf;
+#define FAST(DYN)                                                                                                  \
+    set_kname(h, "k_sweep_fast", (int)DYN, tname<PI_T>(), h->F.lsplit == 0);                                       \
+    if (h->F.lsplit == 0)                                                                                          \
+        hipLaunchKernelGGL((k_sweep_fast<DYN, PI_T, true>), gf, 256, 0, st, h->P, h->F, Jin, Jout, pi, al, sc, h->F.act);                                                                                  \
+    else                                                                                                           \
+        hipLaunchKernelGGL((k_sweep_fast<DYN, PI_T, false>), gf, 256, 0, st, h->P, h->F, Jin, Jout, pi, al, sc, h->F.act);
+            switch (h->d.dynamics_id) {
+                case PVI_DYN_PENDULUM: FAST(PVI_DYN_PENDULUM) break;
+                case PVI_DYN_CARTPOLE: FAST(PVI_DYN_CARTPOLE) break;
+                default: FAST(PVI_DYN_TWOLINK) break;
+            }
+#undef FAST
+            HIPCHK(hipGetLastError());
+            return PVI_OK;
+        }
+    }
+}
+int launch_fast(pvi_problem* h, const float* Jin, float* Jout, float alpha, hipStream_t st, SweepCtl sc) {
+    return h->pi_size == 1 ? launch_fast_t<unsigned char>(h, Jin, Jout, alpha, st, sc) : launch_fast_t<unsigned short>(h, Jin, Jout, alpha, st, sc);
+}

@@ -280,7 +280,7 @@ def test_build_staleness_covers_every_source_file(tmp_path, monkeypatch):
     """A non-forced build must notice edits to the included kernel files, not only to pyrovi.hip."""
     from pyro_amd import _build
     names = {os.path.basename(p) for p in _build.sources()}
-    assert {"pyrovi.hip", "sweep_lean.inc", "sweep_spline.inc", "pyrovi.h"} <= names
+    assert {"pyrovi.hip", "f64.hip", "lean.hip", "core.h", "host.h", "sweep_lean.inc", "sweep_spline.inc", "pyrovi.h"} <= names
     assert _build.up_to_date()
     inc = [p for p in _build.sources() if p.endswith("sweep_lean.inc")][0]
     st = os.stat(inc)

@@ -1,6 +1,6 @@
 #!/bin/bash
-# compile libpyrovi.so and print a compact per-kernel resource table (optionally filtered by $1)
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -o pyro_amd/libpyrovi.so pyro_amd/csrc/pyrovi.hip -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
+# compile the three units of libpyrovi.so and print a compact per-kernel resource table (optionally filtered by $1)
+(for u in pyrovi f64 lean; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -c -o /tmp/kres_$u.o pyro_amd/csrc/$u.hip -Rpass-analysis=kernel-resource-usage; done) 2>&1 | python3 -c "
 import sys,re
 cur=None; rows={}
 for l in sys.stdin:

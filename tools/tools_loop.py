@@ -2,8 +2,10 @@
 """Print instruction mix of the innermost loops of a kernel (by mangled-name substring) from the -save-temps ISA."""
 import collections, re, subprocess, sys, os
 os.makedirs('/tmp/asm', exist_ok=True)
-subprocess.run("cd /tmp/asm && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -save-temps -c /root/repo/pyro_amd/csrc/pyrovi.hip -o /tmp/asm/p.o 2>/dev/null", shell=True)
-s = open('/tmp/asm/pyrovi-hip-amdgcn-amd-amdhsa-gfx950.s').read()
+s = ""
+for unit in ("pyrovi", "f64", "lean"):        # the three translation units of the library
+    subprocess.run("cd /tmp/asm && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -save-temps -c /root/repo/pyro_amd/csrc/%s.hip -o /tmp/asm/%s.o 2>/dev/null" % (unit, unit), shell=True)
+    s += open('/tmp/asm/%s-hip-amdgcn-amd-amdhsa-gfx950.s' % unit).read()
 for name in sys.argv[1:]:
     show = name.endswith('+')
     name = name.rstrip('+')
