@@ -1,9 +1,13 @@
 #!/bin/bash
+# A/B on one box: experiment builds of the lean unit (pyro_amd/libpyrovi_e<k>.so, built by hand with -DL4EXP=k) against the product
 cd /root/repo; mkdir -p gpurun_out
-L=gpurun_out/r04_fuzz_final.log; : > $L
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "variants_agree or h3_full" > gpurun_out/r04_pin_tests.log 2>&1
-grep -E "passed|failed|Error|assert" gpurun_out/r04_pin_tests.log | tail -5 >> $L
-timeout 1500 python tools/tools_fuzz64.py 160 11 > gpurun_out/r04_fuzz64.log 2>&1; tail -2 gpurun_out/r04_fuzz64.log >> $L
-grep -c "regtab=1" gpurun_out/r04_fuzz64.log >> $L
-FUZZ_4D_MAX=18 timeout 1500 python tools/tools_fuzz.py 80 12 > gpurun_out/r04_fuzz32.log 2>&1; tail -2 gpurun_out/r04_fuzz32.log >> $L
+L=gpurun_out/r04_l4exp.log; : > $L
+for rep in 1 2; do
+for lib in libpyrovi.so libpyrovi_e1.so libpyrovi_e2.so libpyrovi_e3.so libpyrovi_e4.so; do
+  for w in "c3 200" "c4 40"; do
+    echo "== $lib $w" >> $L
+    PYROVI_LIB=/root/repo/pyro_amd/$lib timeout 300 python tools/tools_time.py $w 2>&1 | grep -E "TIME|rror" | cut -c1-200 >> $L
+  done
+done
+done
 cat $L
