@@ -1316,6 +1316,26 @@ def test_multi_sweep_launch_is_bit_identical(name, tol, extra, variants):
     assert "multi=0" in outs["single"][4] and "kernel=k_sweep64<" in outs["single"][4], outs["single"][4]
     two_d = len(p.levels) == 2
     assert ("regtab=1" if two_d else "regtab=0") in outs["multi"][4], outs["multi"][4]
+    if two_d:   # the stop test rides one sweep behind in the register-table form: every stop position, also inside short batches
+        for k in ("PVI_MULTI", "PVI_PATCH", "PVI_SPARSE", "PVI_REGTAB"):
+            variants.delenv(k)
+        for tol_k in (1e30, 60.0, 20.0, 5.0, 2.0, 0.7):
+            for cap in (1, 2, 3, 40):
+                res = []
+                for env in ({}, {"PVI_MULTI": "0"}):
+                    variants.delenv("PVI_MULTI")
+                    for k, v in env.items():
+                        variants.setenv(k, v)
+                    h = native_problem(p, dtype="float64")
+                    h.terminal_cost()
+                    st, n = h.sweep(cap, alpha, tol_k)
+                    st2, n2 = h.sweep(cap, alpha, tol_k)          # a second batch on the same handle
+                    res.append((n, n2, h.get_J(), h.get_pi(), np.array(st), np.array(st2)))
+                    h.close()
+                variants.delenv("PVI_MULTI")
+                assert res[0][0] == res[1][0] and res[0][1] == res[1][1], (tol_k, cap, res[0][:2], res[1][:2])
+                for i in (2, 3, 4, 5):
+                    assert np.array_equal(res[0][i], res[1][i]), (tol_k, cap, i)
     if two_d:   # the write-through hand-off between the sweeps, again and again, with a second handle sweeping beside it
         for k in ("PVI_MULTI", "PVI_PATCH", "PVI_SPARSE", "PVI_REGTAB"):
             variants.delenv(k)
