@@ -97,6 +97,33 @@ __device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target)
     __syncthreads();
 }
 
+// fold of the per-workgroup statistics records of the register-table form: two records per thread -> per-wave maxima -> folded[]
+__device__ __forceinline__ void fold_records(double a0, double a1, double a2, double b0, double b1, double b2, double (*wfold)[4],
+                                             double* folded) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    a0 = wave_max(fmax(a0, b0));
+    a1 = wave_max(fmax(a1, b1));
+    a2 = wave_max(fmax(a2, b2));
+    if (lane == 0) {
+        wfold[0][wave] = a0;
+        wfold[1][wave] = a1;
+        wfold[2][wave] = a2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double m0 = fmax(fmax(wfold[0][0], wfold[0][1]), fmax(wfold[0][2], wfold[0][3]));
+        const double m1 = fmax(fmax(wfold[1][0], wfold[1][1]), fmax(wfold[1][2], wfold[1][3]));
+        const double m2 = fmax(fmax(wfold[2][0], wfold[2][1]), fmax(wfold[2][2], wfold[2][3]));
+        folded[0] = m0;
+        folded[1] = m1;
+        folded[2] = -m2;
+        folded[3] = fmax(fabs(m1), fabs(-m2));
+    }
+    __syncthreads();
+}
+
+#define MULTI_MAX_WG 512  // workgroups of a multi-sweep launch (statistics records per set)
+
 // The same barrier for data that is published WRITE-THROUGH (sc1 stores: they leave the XCD's L2 for memory) and read with
 // sc1 loads (which bypass the CU's L1): no L2 write-back, no invalidate -- the two fences are 1.7 us each
 // (MI355X_MICROARCH.md, inter-workgroup visibility: producer "sc1 payload -> asm vmcnt(0) -> flag", consumer "sc1 loads may
@@ -117,7 +144,7 @@ __device__ __forceinline__ void grid_barrier_wt(unsigned* counter, unsigned targ
 // two buffers, the three statistics of sweep k go to slot k, a grid barrier separates the sweeps, and every workgroup folds
 // the statistics itself and takes the same stop decision (delta <= tol).  Same arithmetic per cell as one launch per sweep:
 // J, pi, the statistics and the stop sweep are bit-identical.
-template <int DYN, typename PI_T, bool OFF32, bool PATCH, bool SPARSE, bool MULTI>
+template <int DYN, typename PI_T, bool OFF32, bool PATCH, bool SPARSE, bool MULTI, bool WIDE = false>
 __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, double* Jout, PI_T* __restrict__ pi, double alpha, SweepCtl sc,
                                              const Act64* __restrict__ act64, const double2* __restrict__ levr,
                                              const uint4* __restrict__ vmask, int nsweeps) {
@@ -260,7 +287,7 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
         // then 2 A independent 16-byte loads -- ONE memory round trip instead of A / 4 dependent ones -- A bilinear sums and
         // the argmin.  J is stored write-through and loaded with sc1 loads, so the barrier between two sweeps needs no L2
         // write-back and no invalidate (grid_barrier_wt).  Same operations per cell in the same order: the same bits.
-        constexpr int RT = 12;
+        constexpr int RT = WIDE ? 24 : 12;  // (WIDE: the form for up to 24 actions and 512 workgroups; its longer code costs C1 a microsecond per sweep)
         [[maybe_unused]] unsigned rt_off[RT];
         [[maybe_unused]] double rt_y[RT], rt_G[RT];
         [[maybe_unused]] unsigned rt_in = 0u;
@@ -327,7 +354,8 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
         }
       // REGTAB: the statistics of sweep k are loaded behind sweep k's barrier but folded while the J loads of sweep k + 1 are in
       // flight (one memory round trip for both); a sweep that turns out to come after the stop is dropped before it stores
-      [[maybe_unused]] double pv0 = -INFINITY, pv1 = -INFINITY, pv2 = -INFINITY;
+      [[maybe_unused]] double pv0 = -INFINITY, pv1 = -INFINITY, pv2 = -INFINITY, pu0 = -INFINITY, pu1 = -INFINITY, pu2 = -INFINITY;
+      __shared__ double wfold[3][4];
       [[maybe_unused]] bool pending = false;
       __shared__ double folded[4];
       for (int ks = 0;; ++ks) {  // (one trip unless MULTI)
@@ -337,93 +365,184 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
         if constexpr (MULTI && DOF == 1) {
             if (regtab) {
                 rt_done = true;
-                typedef unsigned v4u __attribute__((ext_vector_type(4)));
-                v4u r0[RT], r1[RT];
-                constexpr int WCH = 5;  // 16-byte chunks of the window per thread
-                v4u wv[WCH];
-                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Jin, 0, 0xfffffff0u, 0x00020000);
-                if (win_ok) {  // (block-uniform) the window: chunk c of thread t = doubles 2 (t + 256 c), 2 (t + 256 c) + 1
-                    const unsigned org = (unsigned)((long long)(win_r0 - P.store_begin) * P.strd[0]) * 8u;
-#pragma unroll
-                    for (int c = 0; c < WCH; ++c) {
-                        const int e = 2 * ((int)threadIdx.x + 256 * c);
-                        wv[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, e < win_n ? org + (unsigned)e * 8u : 0xffffffffu, 0, 16);
-                    }
-                } else if (pos_in) {
-                    constexpr unsigned OOB = 0xffffffffu;  // beyond num_records: the hardware returns zeros without an access
+                if constexpr (WIDE) {
+                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                    constexpr int RB = 12;  // actions whose 2 x 16-byte gathers are in flight together when they come from memory
+                    v4u r0[RB], r1[RB];
+                    constexpr int WCH = 8;  // 16-byte chunks of the window per thread
+                    v4u wv[WCH];
+                    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Jin, 0, 0xfffffff0u, 0x00020000);
                     const unsigned s0B = (unsigned)P.strd[0] * 8u;
-#pragma unroll
-                    for (int a = 0; a < RT; ++a) {
-                        if (a < P.A) {  // (uniform)
-                            const unsigned vo = ((rt_in >> a) & 1u) ? rt_off[a] : OOB;
-                            r0[a] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 16);    // aux 16 = sc1: bypasses the CU's L1
-                            r1[a] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, s0B, 16);
+                    constexpr unsigned OOB = 0xffffffffu;  // beyond num_records: the hardware returns zeros without an access
+                    auto issue = [&](int b0) {  // the gathers of actions b0 .. b0 + RB - 1, straight from memory
+    #pragma unroll
+                        for (int k = 0; k < RB; ++k) {
+                            if (b0 + k < P.A) {  // (uniform)
+                                const unsigned vo = ((rt_in >> (b0 + k)) & 1u) ? rt_off[b0 + k] : OOB;
+                                r0[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 16);    // aux 16 = sc1: bypasses the CU's L1
+                                r1[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, s0B, 16);
+                            }
                         }
-                    }
-                }
-                if (pending) {  // (uniform) the previous sweep's statistics: did it meet the tolerance?
-                    pending = false;
-                    if (threadIdx.x < 64) {
-                        pv0 = wave_max(pv0);
-                        pv1 = wave_max(pv1);
-                        pv2 = wave_max(pv2);
-                        if (threadIdx.x == 0) {
-                            folded[0] = pv0;
-                            folded[1] = pv1;
-                            folded[2] = -pv2;
-                            folded[3] = fmax(fabs(pv1), fabs(-pv2));
+                    };
+                    const double a0 = 1.0 - y[0];
+                    auto cell = [&](int a, double q00, double q01, double q10, double q11) {
+                        const double ya = rt_y[a], a1 = 1.0 - ya;
+                        const double Jt = q00 * a0 * a1 + q01 * a0 * ya + q10 * y[0] * a1 + q11 * y[0] * ya;
+                        const double Jn = ((rt_in >> a) & 1u) ? Jt : 0.0;
+                        const double q = rt_G[a] + alpha * Jn;
+                        if (a == 0 || q < best) {
+                            best = q;
+                            arg = a;
                         }
+                    };
+                    if (win_ok) {  // (block-uniform) the window: chunk c of thread t = doubles 2 (t + 256 c), 2 (t + 256 c) + 1
+                        const unsigned org = (unsigned)((long long)(win_r0 - P.store_begin) * P.strd[0]) * 8u;
+    #pragma unroll
+                        for (int c = 0; c < WCH; ++c) {
+                            const int e = 2 * ((int)threadIdx.x + 256 * c);
+                            wv[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, e < win_n ? org + (unsigned)e * 8u : OOB, 0, 16);
+                        }
+                    } else if (pos_in) {
+                        issue(0);
                     }
-                    __syncthreads();
-                    const double delta = folded[3];
-                    const bool stop = sc.tol >= 0.0 && delta <= sc.tol;
-                    if (blockIdx.x == 0 && threadIdx.x == 0) {
-                        double* res = sc.result + 4 * (ks - 1);
-                        res[0] = folded[0];
-                        res[1] = folded[1];
-                        res[2] = folded[2];
-                        res[3] = delta;
-                        sc.ctrl->k_done = ks;
-                        if (stop) sc.ctrl->done = 1;
+                    if (pending) {  // (uniform) the previous sweep's statistics: did it meet the tolerance?
+                        pending = false;
+                        fold_records(pv0, pv1, pv2, pu0, pu1, pu2, wfold, folded);
+                        const double delta = folded[3];
+                        const bool stop = sc.tol >= 0.0 && delta <= sc.tol;
+                        if (blockIdx.x == 0 && threadIdx.x == 0) {
+                            double* res = sc.result + 4 * (ks - 1);
+                            res[0] = folded[0];
+                            res[1] = folded[1];
+                            res[2] = folded[2];
+                            res[3] = delta;
+                            sc.ctrl->k_done = ks;
+                            if (stop) sc.ctrl->done = 1;
+                        }
+                        if (stop) break;  // sweep ks - 1 was the last one: nothing of this sweep has been stored
                     }
-                    if (stop) break;  // sweep ks - 1 was the last one: nothing of this sweep has been stored
-                }
-                if (win_ok) {
-                    // (a window of more than WCH x 512 doubles does not pass win_ok: see the host's win_bytes)
-#pragma unroll
-                    for (int c = 0; c < WCH; ++c) {
-                        const int e = 2 * ((int)threadIdx.x + 256 * c);
-                        if (e < win_n) win[e] = __hiloint2double((int)wv[c].y, (int)wv[c].x);
-                        if (e + 1 < win_n) win[e + 1] = __hiloint2double((int)wv[c].w, (int)wv[c].z);
-                    }
-                    __syncthreads();
-                    if (pos_in) {
-                        const int s0 = (int)P.strd[0];
-#pragma unroll
-                        for (int a = 0; a < RT; ++a) {
-                            if (a < P.A) {
-                                const double* w0 = win + (rt_off[a] >> 3);  // (a cell outside the box points at the window's start)
-                                const double q00 = w0[0], q01 = w0[1], q10 = w0[s0], q11 = w0[s0 + 1];
-                                r0[a] = (v4u){(unsigned)__double2loint(q00), (unsigned)__double2hiint(q00), (unsigned)__double2loint(q01), (unsigned)__double2hiint(q01)};
-                                r1[a] = (v4u){(unsigned)__double2loint(q10), (unsigned)__double2hiint(q10), (unsigned)__double2loint(q11), (unsigned)__double2hiint(q11)};
+                    if (win_ok) {
+                        // (a window of more than WCH x 512 doubles does not pass win_ok: see the host's win_bytes)
+    #pragma unroll
+                        for (int c = 0; c < WCH; ++c) {
+                            const int e = 2 * ((int)threadIdx.x + 256 * c);
+                            if (e < win_n) win[e] = __hiloint2double((int)wv[c].y, (int)wv[c].x);
+                            if (e + 1 < win_n) win[e + 1] = __hiloint2double((int)wv[c].w, (int)wv[c].z);
+                        }
+                        __syncthreads();
+                        if (pos_in) {
+                            const int s0 = (int)P.strd[0];
+    #pragma unroll
+                            for (int a = 0; a < RT; ++a) {
+                                if (a < P.A) {
+                                    const double* w0 = win + (rt_off[a] >> 3);  // (a cell outside the box points into the window too)
+                                    cell(a, w0[0], w0[1], w0[s0], w0[s0 + 1]);
+                                }
+                            }
+                        }
+                    } else if (pos_in) {
+    #pragma unroll
+                        for (int b0 = 0; b0 < RT; b0 += RB) {
+                            if (b0 < P.A) {  // (uniform)
+                                if (b0 > 0) issue(b0);  // (a second round trip: only without the window, with more than RB actions)
+    #pragma unroll
+                                for (int k = 0; k < RB; ++k) {
+                                    if (b0 + k < P.A)
+                                        cell(b0 + k, __hiloint2double((int)r0[k].y, (int)r0[k].x), __hiloint2double((int)r0[k].w, (int)r0[k].z),
+                                             __hiloint2double((int)r1[k].y, (int)r1[k].x), __hiloint2double((int)r1[k].w, (int)r1[k].z));
+                                }
                             }
                         }
                     }
-                }
-                if (pos_in) {
-                    const double a0 = 1.0 - y[0];
-#pragma unroll
-                    for (int a = 0; a < RT; ++a) {
-                        if (a < P.A) {
-                            const double q00 = __hiloint2double((int)r0[a].y, (int)r0[a].x), q01 = __hiloint2double((int)r0[a].w, (int)r0[a].z);
-                            const double q10 = __hiloint2double((int)r1[a].y, (int)r1[a].x), q11 = __hiloint2double((int)r1[a].w, (int)r1[a].z);
-                            const double ya = rt_y[a], a1 = 1.0 - ya;
-                            const double Jt = q00 * a0 * a1 + q01 * a0 * ya + q10 * y[0] * a1 + q11 * y[0] * ya;
-                            const double Jn = ((rt_in >> a) & 1u) ? Jt : 0.0;
-                            const double q = rt_G[a] + alpha * Jn;
-                            if (a == 0 || q < best) {
-                                best = q;
-                                arg = a;
+                } else {
+                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                    v4u r0[RT], r1[RT];
+                    constexpr int WCH = 5;  // 16-byte chunks of the window per thread
+                    v4u wv[WCH];
+                    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Jin, 0, 0xfffffff0u, 0x00020000);
+                    if (win_ok) {  // (block-uniform) the window: chunk c of thread t = doubles 2 (t + 256 c), 2 (t + 256 c) + 1
+                        const unsigned org = (unsigned)((long long)(win_r0 - P.store_begin) * P.strd[0]) * 8u;
+    #pragma unroll
+                        for (int c = 0; c < WCH; ++c) {
+                            const int e = 2 * ((int)threadIdx.x + 256 * c);
+                            wv[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, e < win_n ? org + (unsigned)e * 8u : 0xffffffffu, 0, 16);
+                        }
+                    } else if (pos_in) {
+                        constexpr unsigned OOB = 0xffffffffu;  // beyond num_records: the hardware returns zeros without an access
+                        const unsigned s0B = (unsigned)P.strd[0] * 8u;
+    #pragma unroll
+                        for (int a = 0; a < RT; ++a) {
+                            if (a < P.A) {  // (uniform)
+                                const unsigned vo = ((rt_in >> a) & 1u) ? rt_off[a] : OOB;
+                                r0[a] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 16);    // aux 16 = sc1: bypasses the CU's L1
+                                r1[a] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, s0B, 16);
+                            }
+                        }
+                    }
+                    if (pending) {  // (uniform) the previous sweep's statistics: did it meet the tolerance?
+                        pending = false;
+                        if (threadIdx.x < 64) {
+                            pv0 = wave_max(pv0);
+                            pv1 = wave_max(pv1);
+                            pv2 = wave_max(pv2);
+                            if (threadIdx.x == 0) {
+                                folded[0] = pv0;
+                                folded[1] = pv1;
+                                folded[2] = -pv2;
+                                folded[3] = fmax(fabs(pv1), fabs(-pv2));
+                            }
+                        }
+                        __syncthreads();
+                        const double delta = folded[3];
+                        const bool stop = sc.tol >= 0.0 && delta <= sc.tol;
+                        if (blockIdx.x == 0 && threadIdx.x == 0) {
+                            double* res = sc.result + 4 * (ks - 1);
+                            res[0] = folded[0];
+                            res[1] = folded[1];
+                            res[2] = folded[2];
+                            res[3] = delta;
+                            sc.ctrl->k_done = ks;
+                            if (stop) sc.ctrl->done = 1;
+                        }
+                        if (stop) break;  // sweep ks - 1 was the last one: nothing of this sweep has been stored
+                    }
+                    if (win_ok) {
+                        // (a window of more than WCH x 512 doubles does not pass win_ok: see the host's win_bytes)
+    #pragma unroll
+                        for (int c = 0; c < WCH; ++c) {
+                            const int e = 2 * ((int)threadIdx.x + 256 * c);
+                            if (e < win_n) win[e] = __hiloint2double((int)wv[c].y, (int)wv[c].x);
+                            if (e + 1 < win_n) win[e + 1] = __hiloint2double((int)wv[c].w, (int)wv[c].z);
+                        }
+                        __syncthreads();
+                        if (pos_in) {
+                            const int s0 = (int)P.strd[0];
+    #pragma unroll
+                            for (int a = 0; a < RT; ++a) {
+                                if (a < P.A) {
+                                    const double* w0 = win + (rt_off[a] >> 3);  // (a cell outside the box points at the window's start)
+                                    const double q00 = w0[0], q01 = w0[1], q10 = w0[s0], q11 = w0[s0 + 1];
+                                    r0[a] = (v4u){(unsigned)__double2loint(q00), (unsigned)__double2hiint(q00), (unsigned)__double2loint(q01), (unsigned)__double2hiint(q01)};
+                                    r1[a] = (v4u){(unsigned)__double2loint(q10), (unsigned)__double2hiint(q10), (unsigned)__double2loint(q11), (unsigned)__double2hiint(q11)};
+                                }
+                            }
+                        }
+                    }
+                    if (pos_in) {
+                        const double a0 = 1.0 - y[0];
+    #pragma unroll
+                        for (int a = 0; a < RT; ++a) {
+                            if (a < P.A) {
+                                const double q00 = __hiloint2double((int)r0[a].y, (int)r0[a].x), q01 = __hiloint2double((int)r0[a].w, (int)r0[a].z);
+                                const double q10 = __hiloint2double((int)r1[a].y, (int)r1[a].x), q11 = __hiloint2double((int)r1[a].w, (int)r1[a].z);
+                                const double ya = rt_y[a], a1 = 1.0 - ya;
+                                const double Jt = q00 * a0 * a1 + q01 * a0 * ya + q10 * y[0] * a1 + q11 * y[0] * ya;
+                                const double Jn = ((rt_in >> a) & 1u) ? Jt : 0.0;
+                                const double q = rt_G[a] + alpha * Jn;
+                                if (a == 0 || q < best) {
+                                    best = q;
+                                    arg = a;
+                                }
                             }
                         }
                     }
@@ -726,30 +845,59 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
             // barrier's release), and behind the barrier every workgroup reads all of them (lane = workgroup: at most 64,
             // see multi64_applies) -- no atomics, no second round trip.  Two sets, alternating: a workgroup can run at most
             // one barrier ahead of the slowest reader.
-            double* part = (double*)sc.slot + (size_t)(ks & 1) * 64 * 4;
+            // (MULTI_MAX_WG workgroups per set: the register-table form runs up to that many, the fenced form at most 64)
+            double* part = (double*)sc.slot + (size_t)(ks & 1) * MULTI_MAX_WG * 4;
             double v0 = -INFINITY, v1 = -INFINITY, v2 = -INFINITY;
+            [[maybe_unused]] double u0 = -INFINITY, u1 = -INFINITY, u2 = -INFINITY;  // (second record of a thread, register-table form)
             if (rt_done) {
                 // REGTAB: J and the statistics went out write-through and are read with sc1 loads: nothing to fence.
                 // (Measured and not kept: arrival and statistics as ONE tagged 16-byte granule per value, polled by every
                 //  workgroup -- no counter, one round trip less on paper, the same 5.0 us per sweep on C1.)
-                block_max3_store<true>(st_j, st_dmax, st_ndmin, part + 4 * blockIdx.x);
-                grid_barrier_wt(&sc.ctrl->ticket, (unsigned)(ks + 1) * gridDim.x);
-                if (threadIdx.x < 64) {
-                    const int l = threadIdx.x;
-                    if (l < (int)gridDim.x) {  // (sc1 loads: they bypass the CU's L1, which may hold these words from two sweeps ago)
-                        auto ld = [&](int k) {
-                            return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)(part + 4 * l + k), __ATOMIC_RELAXED,
+                if constexpr (WIDE) {
+                    block_max3_store<true>(st_j, st_dmax, st_ndmin, part + 4 * blockIdx.x);
+                    grid_barrier_wt(&sc.ctrl->ticket, (unsigned)(ks + 1) * gridDim.x);
+                    // every thread takes the records of the workgroups t and t + 256 (MULTI_MAX_WG = 512): six sc1 loads (they bypass
+                    // the CU's L1, which may hold these words from two sweeps ago), issued here, waited for where they are folded
+                    {
+                        auto ld = [&](int wg, int k) {
+                            return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)(part + 4 * wg + k), __ATOMIC_RELAXED,
                                                                                       __HIP_MEMORY_SCOPE_AGENT));
                         };
-                        v0 = ld(0);
-                        v1 = ld(1);
-                        v2 = ld(2);
+                        const int w0 = (int)threadIdx.x, w1 = w0 + 256;
+                        if (w0 < (int)gridDim.x) {
+                            v0 = ld(w0, 0);
+                            v1 = ld(w0, 1);
+                            v2 = ld(w0, 2);
+                        }
+                        if (w1 < (int)gridDim.x) {
+                            u0 = ld(w1, 0);
+                            u1 = ld(w1, 1);
+                            u2 = ld(w1, 2);
+                        }
+                    }
+                } else {
+                    block_max3_store<true>(st_j, st_dmax, st_ndmin, part + 4 * blockIdx.x);
+                    grid_barrier_wt(&sc.ctrl->ticket, (unsigned)(ks + 1) * gridDim.x);
+                    if (threadIdx.x < 64) {
+                        const int l = threadIdx.x;
+                        if (l < (int)gridDim.x) {  // (sc1 loads: they bypass the CU's L1, which may hold these words from two sweeps ago)
+                            auto ld = [&](int k) {
+                                return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)(part + 4 * l + k), __ATOMIC_RELAXED,
+                                                                                          __HIP_MEMORY_SCOPE_AGENT));
+                            };
+                            v0 = ld(0);
+                            v1 = ld(1);
+                            v2 = ld(2);
+                        }
                     }
                 }
                 if (ks + 1 < nsweeps) {  // folded behind the next sweep's J loads
                     pv0 = v0;
                     pv1 = v1;
                     pv2 = v2;
+                    pu0 = u0;
+                    pu1 = u1;
+                    pu2 = u2;
                     pending = true;
                     const double* t = Jin;  // ping-pong
                     Jin = Jout;
@@ -768,19 +916,23 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
                     v2 = has ? __builtin_nontemporal_load(part + 4 * l + 2) : -INFINITY;
                 }
             }
-            if (threadIdx.x < 64) {
-                const int l = threadIdx.x;
-                v0 = wave_max(v0);
-                v1 = wave_max(v1);
-                v2 = wave_max(v2);
-                if (l == 0) {
-                    folded[0] = v0;
-                    folded[1] = v1;
-                    folded[2] = -v2;
-                    folded[3] = fmax(fabs(v1), fabs(-v2));
+            if (WIDE && rt_done) {
+                fold_records(v0, v1, v2, u0, u1, u2, wfold, folded);
+            } else {
+                if (threadIdx.x < 64) {
+                    const int l = threadIdx.x;
+                    v0 = wave_max(v0);
+                    v1 = wave_max(v1);
+                    v2 = wave_max(v2);
+                    if (l == 0) {
+                        folded[0] = v0;
+                        folded[1] = v1;
+                        folded[2] = -v2;
+                        folded[3] = fmax(fabs(v1), fabs(-v2));
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
             const double delta = folded[3];
             const bool stop = sc.tol >= 0.0 && delta <= sc.tol;
             if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -815,10 +967,11 @@ __global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restric
     sweep64_body<DYN, PI_T, OFF32, PATCH, SPARSE, false>(P, Jin, Jout, pi, alpha, sc, act64, levr, vmask, 1);
 }
 // (Jin / Jout without __restrict__: the kernel swaps them between its sweeps)
-template <int DYN, typename PI_T>
+// WIDE (2-D grids only): the register-table form for up to 24 actions and 512 workgroups
+template <int DYN, typename PI_T, bool WIDE = false>
 __global__ __launch_bounds__(256) void k_sweep64m(DevP P, const double* Jin, double* Jout, PI_T* __restrict__ pi, double alpha, SweepCtl sc,
                                                   const Act64* __restrict__ act64, const double2* __restrict__ levr, int nsweeps) {
-    sweep64_body<DYN, PI_T, true, false, false, true>(P, Jin, Jout, pi, alpha, sc, act64, levr, nullptr, nsweeps);
+    sweep64_body<DYN, PI_T, true, false, false, true, WIDE>(P, Jin, Jout, pi, alpha, sc, act64, levr, nullptr, nsweeps);
 }
 
 // Validity masks of the SPARSE float64 sweep: bit a of a node's 128-bit word is set when the position row and the cell of
@@ -979,7 +1132,14 @@ int launch_valid_mask(pvi_problem* h, uint4* vm, unsigned long long* cnt) {
 // set-up kept neither patches nor validity masks), whole grid, every workgroup resident.  pvi_override("MULTI", "0") keeps
 // one launch per sweep.
 template <typename PI_T>
-static const void* multi64_kernel(int dyn) {
+static const void* multi64_kernel(int dyn, bool wide = false) {
+    if (wide) {
+        switch (dyn) {
+            case PVI_DYN_PENDULUM: return (const void*)k_sweep64m<PVI_DYN_PENDULUM, PI_T, true>;
+            case PVI_DYN_NODE_1x1: return (const void*)k_sweep64m<PVI_DYN_NODE_1x1, PI_T, true>;
+            default: return nullptr;
+        }
+    }
     switch (dyn) {
         case PVI_DYN_PENDULUM: return (const void*)k_sweep64m<PVI_DYN_PENDULUM, PI_T>;
         case PVI_DYN_CARTPOLE: return (const void*)k_sweep64m<PVI_DYN_CARTPOLE, PI_T>;
@@ -1006,14 +1166,24 @@ bool multi64_applies(pvi_problem* h) {
     int coop = 0, per_cu = 0, ncu = 0;
     if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, h->device) != hipSuccess || !coop) return no("no cooperative launch");
     // (with the largest window the launch may ask for: launch_multi64)
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, h->levr_bytes + 5 * 512 * 8) != hipSuccess) return no("occupancy query");
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, h->levr_bytes + 8 * 512 * 8) != hipSuccess) return no("occupancy query");
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) return no("device query");
     const unsigned g = grid_for(h->owned);
     if ((long long)g > (long long)per_cu * ncu) return no("more workgroups than are resident");
     // Small grids only: a sweep of 40 workgroups is a latency chain that one launch per sweep dominates (C1: 9.9 -> 7.6 us with
     // the first version of the kernel); with hundreds of workgroups every one of them runs the barrier's L2 write-back and
     // invalidate and the sweep gets SLOWER (401 x 401 x 51: 27 -> 62 us, profiles/r04_multi_first.log).
-    if (g > 64u) return no("more than 64 workgroups: one launch per sweep is faster");
+    // The register-table form (2-D, few actions: write-through hand-off, no fences) keeps paying further: 201 x 201 x 21 float64,
+    // 158 workgroups, 12.6 us per sweep as one launch per sweep.
+    const bool regtab = h->P.n == 2 && h->P.A <= 24 && !ovr_is("REGTAB", 0);
+    if (g > (regtab ? (unsigned)MULTI_MAX_WG : 64u)) return no(regtab ? "more than 512 workgroups" : "more than 64 workgroups: one launch per sweep is faster");
+    h->multi_wide = regtab && (h->P.A > 12 || g > 64u);   // (the wide form of the kernel; the narrow one is a microsecond faster on C1)
+    if (h->multi_wide) {
+        kfn = h->pi_size == 1 ? multi64_kernel<unsigned char>(h->d.dynamics_id, true) : multi64_kernel<unsigned short>(h->d.dynamics_id, true);
+        if (!kfn) return no("dynamics");
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, h->levr_bytes + 8 * 512 * 8) != hipSuccess) return no("occupancy query");
+        if ((long long)g > (long long)per_cu * ncu) return no("more workgroups than are resident");
+    }
     h->multi64 = 1;
     return true;
 }
@@ -1027,13 +1197,15 @@ int launch_multi64(pvi_problem* h, int src, double alpha, double tol, int nsweep
     sc.nblocks = grid_for(h->owned);
     sc.split_finish = 0;
     sc.xcd_remap = (sc.nblocks >= 64u && !(ovr("XCD64") && !atoi(ovr("XCD64")))) ? 1 : 0;
-    sc.regtab = (h->P.n == 2 && h->P.A <= 12 && !ovr_is("REGTAB", 0)) ? 1 : 0;  // (12 = RT of sweep64_body)
+    const bool wide = h->multi_wide;   // (multi64_applies: more than 12 actions or more than 64 workgroups, register-table form only)
+    sc.regtab = (h->P.n == 2 && h->P.A <= (wide ? 24 : 12) && !ovr_is("REGTAB", 0)) ? 1 : 0;  // (RT of sweep64_body)
+    if (wide && !sc.regtab) return fail(PVI_ESTATE, "the wide multi-sweep launch needs the register-table form (REGTAB changed after the first sweep?)");
     h->regtab64 = sc.regtab;
-    // LDS for the workgroup's window of J behind the level table: at most 5 x 512 doubles (WCH of sweep64_body), within 48 KB
+    // LDS for the workgroup's window of J behind the level table: at most WCH x 512 doubles (sweep64_body: 5, wide 8), within 48 KB
     sc.win_bytes = 0;
     if (sc.regtab && !ovr_is("JWIN", 0) && h->levr_bytes + 4096 <= 48 * 1024)
-        sc.win_bytes = (int)std::min<size_t>(5 * 512 * 8, 48 * 1024 - h->levr_bytes);
-    const void* kfn = h->pi_size == 1 ? multi64_kernel<unsigned char>(h->d.dynamics_id) : multi64_kernel<unsigned short>(h->d.dynamics_id);
+        sc.win_bytes = (int)std::min<size_t>((wide ? 8 : 5) * 512 * 8, 48 * 1024 - h->levr_bytes);
+    const void* kfn = h->pi_size == 1 ? multi64_kernel<unsigned char>(h->d.dynamics_id, wide) : multi64_kernel<unsigned short>(h->d.dynamics_id, wide);
     DevP P = h->P;
     const double* Jin = (const double*)h->J[src];
     double* Jout = (double*)h->J[src ^ 1];
@@ -1041,7 +1213,7 @@ int launch_multi64(pvi_problem* h, int src, double alpha, double tol, int nsweep
     const Act64* act64 = h->act64;
     const double2* levr = h->levr;
     void* args[] = {&P, &Jin, &Jout, &pi, &alpha, &sc, &act64, &levr, &nsweeps};
-    set_kname(h, "k_sweep64m", (int)h->d.dynamics_id, h->pi_size == 1 ? tname<unsigned char>() : tname<unsigned short>());
+    set_kname(h, "k_sweep64m", (int)h->d.dynamics_id, h->pi_size == 1 ? tname<unsigned char>() : tname<unsigned short>(), wide);
     HIPCHK(hipLaunchCooperativeKernel(kfn, dim3(sc.nblocks), dim3(256), args, (unsigned)(h->levr_bytes + (size_t)sc.win_bytes), h->stream));
     return PVI_OK;
 }

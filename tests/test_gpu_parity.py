@@ -1359,6 +1359,38 @@ def test_multi_sweep_launch_is_bit_identical(name, tol, extra, variants):
         assert np.array_equal(outs[tag][2], outs["single"][2]), tag          # the statistics of every sweep
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,udim", [((201, 201), 21), ((101, 101), 21), ((57, 301), 24), ((333, 45), 13), ((181, 181), 7)])
+def test_wide_multi_sweep_launch_is_bit_identical(dims, udim, variants):
+    """The reference's usual demo sizes in float64 (201 x 201 x 21: 158 workgroups): the WIDE register-table form of the multi-sweep
+    launch (up to 24 actions, 512 workgroups) against one launch per sweep -- J, pi, the statistics of every sweep, the stop."""
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import pendulum
+    from pyro_amd.planning import discretizer, dynamicprogramming
+    outs = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = pendulum.SinglePendulum()
+        grid = discretizer.GridDynamicSystem(s, list(dims), [udim])
+        cf = costfunction.QuadraticCostFunction.from_sys(s)
+        cf.xbar, cf.INF = np.array([-3.14, 0.0]), 300.0
+        for tag, env in (("multi", {}), ("single", {"PVI_MULTI": "0"})):
+            variants.delenv("PVI_MULTI")
+            for k, v in env.items():
+                variants.setenv(k, v)
+            dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(grid, cf, dtype="float64")
+            dp.save_time_history = False
+            st1, n1 = dp._p.sweep(37, 1.0, -1.0)
+            st2, n2 = dp._p.sweep(500, 1.0, 2.0)           # a stop inside the batch
+            outs[tag] = (dp._p.get_J(), dp._p.get_pi(), np.array(st1), np.array(st2), n1, n2, dp._p.describe())
+            dp._p.close()
+        variants.delenv("PVI_MULTI")
+    assert "multi=1" in outs["multi"][6] and "regtab=1" in outs["multi"][6] and "kernel=k_sweep64m<1,unsignedchar,true>" in outs["multi"][6], outs["multi"][6]
+    assert "multi=0" in outs["single"][6]
+    assert outs["multi"][4] == outs["single"][4] == 37 and outs["multi"][5] == outs["single"][5] and 0 < outs["multi"][5] < 500
+    for i in range(4):
+        assert np.array_equal(outs["multi"][i], outs["single"][i]), i
+
+
 # ------------------------------------------------------------------------------- interpol_method = 'nearest'
 @pytest.mark.gpu
 def test_nearest_interpolation_through_the_class_surface_matches_reference():
