@@ -144,7 +144,10 @@ __device__ __forceinline__ void grid_barrier_wt(unsigned* counter, unsigned targ
 // two buffers, the three statistics of sweep k go to slot k, a grid barrier separates the sweeps, and every workgroup folds
 // the statistics itself and takes the same stop decision (delta <= tol).  Same arithmetic per cell as one launch per sweep:
 // J, pi, the statistics and the stop sweep are bit-identical.
-template <int DYN, typename PI_T, bool OFF32, bool PATCH, bool SPARSE, bool MULTI, bool WIDE = false>
+// RTM (multi-sweep launches of 2-D grids): 0 the general form with the fence-based barrier, 1 / 2 the register-table form
+// (narrow: <= 12 actions, <= 64 workgroups; wide: <= 24, <= 512) -- a compile-time choice, so that each kernel carries only its
+// own path (the combined kernel was 57 KB of code and 255 + 122 registers)
+template <int DYN, typename PI_T, bool OFF32, bool PATCH, bool SPARSE, bool MULTI, int RTM = 0>
 __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, double* Jout, PI_T* __restrict__ pi, double alpha, SweepCtl sc,
                                              const Act64* __restrict__ act64, const double2* __restrict__ levr,
                                              const uint4* __restrict__ vmask, int nsweeps) {
@@ -287,6 +290,7 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
         // then 2 A independent 16-byte loads -- ONE memory round trip instead of A / 4 dependent ones -- A bilinear sums and
         // the argmin.  J is stored write-through and loaded with sc1 loads, so the barrier between two sweeps needs no L2
         // write-back and no invalidate (grid_barrier_wt).  Same operations per cell in the same order: the same bits.
+        constexpr bool WIDE = RTM == 2;
         constexpr int RT = WIDE ? 24 : 12;  // (WIDE: the form for up to 24 actions and 512 workgroups; its longer code costs C1 a microsecond per sweep)
         [[maybe_unused]] unsigned rt_off[RT];
         [[maybe_unused]] double rt_y[RT], rt_G[RT];
@@ -297,7 +301,7 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
         [[maybe_unused]] bool win_ok = false;
         [[maybe_unused]] double* win = nullptr;
         if constexpr (MULTI && DOF == 1) {
-            regtab = sc.regtab != 0 && P.A <= RT;
+            regtab = RTM > 0;   // (the host launches this instantiation only for grids of at most RT actions: launch_multi64)
             if (regtab) {
                 jprev = Jin[self];
 #pragma unroll
@@ -361,10 +365,9 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
       for (int ks = 0;; ++ks) {  // (one trip unless MULTI)
         double best = P.INF;  // position row outside the box: every action costs INF + alpha*0, the first one wins
         int arg = 0;
-        [[maybe_unused]] bool rt_done = false;
-        if constexpr (MULTI && DOF == 1) {
-            if (regtab) {
-                rt_done = true;
+        constexpr bool rt_done = MULTI && DOF == 1 && RTM > 0;
+        if constexpr (MULTI && DOF == 1 && RTM > 0) {
+            {
                 if constexpr (WIDE) {
                     typedef unsigned v4u __attribute__((ext_vector_type(4)));
                     constexpr int RB = 12;  // actions whose 2 x 16-byte gathers are in flight together when they come from memory
@@ -916,7 +919,7 @@ __device__ __forceinline__ void sweep64_body(const DevP& P, const double* Jin, d
                     v2 = has ? __builtin_nontemporal_load(part + 4 * l + 2) : -INFINITY;
                 }
             }
-            if (WIDE && rt_done) {
+            if (RTM == 2 && rt_done) {
                 fold_records(v0, v1, v2, u0, u1, u2, wfold, folded);
             } else {
                 if (threadIdx.x < 64) {
@@ -967,11 +970,11 @@ __global__ __launch_bounds__(256) void k_sweep64(DevP P, const double* __restric
     sweep64_body<DYN, PI_T, OFF32, PATCH, SPARSE, false>(P, Jin, Jout, pi, alpha, sc, act64, levr, vmask, 1);
 }
 // (Jin / Jout without __restrict__: the kernel swaps them between its sweeps)
-// WIDE (2-D grids only): the register-table form for up to 24 actions and 512 workgroups
-template <int DYN, typename PI_T, bool WIDE = false>
+// RTM 1 / 2 (2-D grids only): the register-table form, narrow / wide (sweep64_body)
+template <int DYN, typename PI_T, int RTM = 0>
 __global__ __launch_bounds__(256) void k_sweep64m(DevP P, const double* Jin, double* Jout, PI_T* __restrict__ pi, double alpha, SweepCtl sc,
                                                   const Act64* __restrict__ act64, const double2* __restrict__ levr, int nsweeps) {
-    sweep64_body<DYN, PI_T, true, false, false, true, WIDE>(P, Jin, Jout, pi, alpha, sc, act64, levr, nullptr, nsweeps);
+    sweep64_body<DYN, PI_T, true, false, false, true, RTM>(P, Jin, Jout, pi, alpha, sc, act64, levr, nullptr, nsweeps);
 }
 
 // Validity masks of the SPARSE float64 sweep: bit a of a node's 128-bit word is set when the position row and the cell of
@@ -1132,11 +1135,18 @@ int launch_valid_mask(pvi_problem* h, uint4* vm, unsigned long long* cnt) {
 // set-up kept neither patches nor validity masks), whole grid, every workgroup resident.  pvi_override("MULTI", "0") keeps
 // one launch per sweep.
 template <typename PI_T>
-static const void* multi64_kernel(int dyn, bool wide = false) {
-    if (wide) {
+static const void* multi64_kernel(int dyn, int rtm = 0) {
+    if (rtm == 1) {
         switch (dyn) {
-            case PVI_DYN_PENDULUM: return (const void*)k_sweep64m<PVI_DYN_PENDULUM, PI_T, true>;
-            case PVI_DYN_NODE_1x1: return (const void*)k_sweep64m<PVI_DYN_NODE_1x1, PI_T, true>;
+            case PVI_DYN_PENDULUM: return (const void*)k_sweep64m<PVI_DYN_PENDULUM, PI_T, 1>;
+            case PVI_DYN_NODE_1x1: return (const void*)k_sweep64m<PVI_DYN_NODE_1x1, PI_T, 1>;
+            default: return nullptr;
+        }
+    }
+    if (rtm == 2) {
+        switch (dyn) {
+            case PVI_DYN_PENDULUM: return (const void*)k_sweep64m<PVI_DYN_PENDULUM, PI_T, 2>;
+            case PVI_DYN_NODE_1x1: return (const void*)k_sweep64m<PVI_DYN_NODE_1x1, PI_T, 2>;
             default: return nullptr;
         }
     }
@@ -1177,9 +1187,9 @@ bool multi64_applies(pvi_problem* h) {
     // 158 workgroups, 12.6 us per sweep as one launch per sweep.
     const bool regtab = h->P.n == 2 && h->P.A <= 24 && !ovr_is("REGTAB", 0);
     if (g > (regtab ? (unsigned)MULTI_MAX_WG : 64u)) return no(regtab ? "more than 512 workgroups" : "more than 64 workgroups: one launch per sweep is faster");
-    h->multi_wide = regtab && (h->P.A > 12 || g > 64u);   // (the wide form of the kernel; the narrow one is a microsecond faster on C1)
-    if (h->multi_wide) {
-        kfn = h->pi_size == 1 ? multi64_kernel<unsigned char>(h->d.dynamics_id, true) : multi64_kernel<unsigned short>(h->d.dynamics_id, true);
+    h->multi_rtm = regtab ? ((h->P.A > 12 || g > 64u) ? 2 : 1) : 0;   // (the wide form's longer code costs C1 a microsecond per sweep)
+    if (h->multi_rtm) {
+        kfn = h->pi_size == 1 ? multi64_kernel<unsigned char>(h->d.dynamics_id, h->multi_rtm) : multi64_kernel<unsigned short>(h->d.dynamics_id, h->multi_rtm);
         if (!kfn) return no("dynamics");
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, h->levr_bytes + 8 * 512 * 8) != hipSuccess) return no("occupancy query");
         if ((long long)g > (long long)per_cu * ncu) return no("more workgroups than are resident");
@@ -1197,15 +1207,15 @@ int launch_multi64(pvi_problem* h, int src, double alpha, double tol, int nsweep
     sc.nblocks = grid_for(h->owned);
     sc.split_finish = 0;
     sc.xcd_remap = (sc.nblocks >= 64u && !(ovr("XCD64") && !atoi(ovr("XCD64")))) ? 1 : 0;
-    const bool wide = h->multi_wide;   // (multi64_applies: more than 12 actions or more than 64 workgroups, register-table form only)
-    sc.regtab = (h->P.n == 2 && h->P.A <= (wide ? 24 : 12) && !ovr_is("REGTAB", 0)) ? 1 : 0;  // (RT of sweep64_body)
-    if (wide && !sc.regtab) return fail(PVI_ESTATE, "the wide multi-sweep launch needs the register-table form (REGTAB changed after the first sweep?)");
+    const int rtm = h->multi_rtm;      // (multi64_applies: 0 general form, 1 / 2 register-table form narrow / wide)
+    const bool wide = rtm == 2;
+    sc.regtab = rtm > 0 ? 1 : 0;
     h->regtab64 = sc.regtab;
     // LDS for the workgroup's window of J behind the level table: at most WCH x 512 doubles (sweep64_body: 5, wide 8), within 48 KB
     sc.win_bytes = 0;
     if (sc.regtab && !ovr_is("JWIN", 0) && h->levr_bytes + 4096 <= 48 * 1024)
         sc.win_bytes = (int)std::min<size_t>((wide ? 8 : 5) * 512 * 8, 48 * 1024 - h->levr_bytes);
-    const void* kfn = h->pi_size == 1 ? multi64_kernel<unsigned char>(h->d.dynamics_id, wide) : multi64_kernel<unsigned short>(h->d.dynamics_id, wide);
+    const void* kfn = h->pi_size == 1 ? multi64_kernel<unsigned char>(h->d.dynamics_id, rtm) : multi64_kernel<unsigned short>(h->d.dynamics_id, rtm);
     DevP P = h->P;
     const double* Jin = (const double*)h->J[src];
     double* Jout = (double*)h->J[src ^ 1];
@@ -1213,7 +1223,7 @@ int launch_multi64(pvi_problem* h, int src, double alpha, double tol, int nsweep
     const Act64* act64 = h->act64;
     const double2* levr = h->levr;
     void* args[] = {&P, &Jin, &Jout, &pi, &alpha, &sc, &act64, &levr, &nsweeps};
-    set_kname(h, "k_sweep64m", (int)h->d.dynamics_id, h->pi_size == 1 ? tname<unsigned char>() : tname<unsigned short>(), wide);
+    set_kname(h, "k_sweep64m", (int)h->d.dynamics_id, h->pi_size == 1 ? tname<unsigned char>() : tname<unsigned short>(), rtm);
     HIPCHK(hipLaunchCooperativeKernel(kfn, dim3(sc.nblocks), dim3(256), args, (unsigned)(h->levr_bytes + (size_t)sc.win_bytes), h->stream));
     return PVI_OK;
 }

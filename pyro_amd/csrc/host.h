@@ -209,7 +209,7 @@ struct pvi_problem {
     bool spline = false;
     int multi64 = -1;         // multi-sweep launch of the float64 sweep (k_sweep64m): -1 not decided, 0 no, 1 yes
     char multi_why[96] = "";
-    bool multi_wide = false;      // ... in its wide form (up to 24 actions, 512 workgroups)
+    int multi_rtm = 0;            // ... 1 / 2: in its register-table form, narrow / wide (2-D grids, <= 12 / 24 actions, <= 64 / 512 workgroups)
     int regtab64 = -1;            // the multi-sweep launches keep the per-action cells in registers (2-D, <= 12 actions)
     char kname[128] = "";     // the sweep kernel of the last launch, as a kernel trace prints it (spaces removed): pvi_describe `kernel=`
 };

@@ -1384,7 +1384,7 @@ def test_wide_multi_sweep_launch_is_bit_identical(dims, udim, variants):
             outs[tag] = (dp._p.get_J(), dp._p.get_pi(), np.array(st1), np.array(st2), n1, n2, dp._p.describe())
             dp._p.close()
         variants.delenv("PVI_MULTI")
-    assert "multi=1" in outs["multi"][6] and "regtab=1" in outs["multi"][6] and "kernel=k_sweep64m<1,unsignedchar,true>" in outs["multi"][6], outs["multi"][6]
+    assert "multi=1" in outs["multi"][6] and "regtab=1" in outs["multi"][6] and "kernel=k_sweep64m<1,unsignedchar,2>" in outs["multi"][6], outs["multi"][6]
     assert "multi=0" in outs["single"][6]
     assert outs["multi"][4] == outs["single"][4] == 37 and outs["multi"][5] == outs["single"][5] and 0 < outs["multi"][5] < 500
     for i in range(4):
