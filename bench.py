@@ -351,32 +351,50 @@ def cpu_leg(p, cfg, budget_s, depth):
     return cpu, acc
 
 
-def converged_check(cfg, tol=0.1, every=100, max_sweeps=20000):
-    """north_star: "J* match within 1e-5".  The workload solved to `tol` twice on the GPU -- float32 production path and
-    float64 path (oracle-pinned one step at a time by the tests) -- in lockstep batches of `every` sweeps; the drift
-    max |J32 - J64| / max |J64| is recorded after every batch.  Returns the final figure, both sweep counts and the curve."""
+def converged_check(cfg, tol=0.1, every=100, max_sweeps=20000, feedback=True):
+    """north_star: "J* match within 1e-5".  The workload solved to `tol` on the GPU -- float32 production path, float64
+    path (oracle-pinned one step at a time by the tests) and, on 4-D grids, the float32 path with error-feedback storage
+    (PVI_FLAG_F32_FEEDBACK: the accuracy mode, k_sweep_lean4fb) -- in lockstep batches of `every` sweeps; the drift
+    max |J32 - J64| / max |J64| is recorded after every batch.  Returns the final figures, the sweep counts and the curves."""
     from pyro_amd.planning import dynamicprogramming
     g = cfg["grid_sys"]
     hs = {}
     t0 = time.perf_counter()
-    for dt in ("float32", "float64"):
+    kinds = [("float32", "float32", False), ("float64", "float64", False)]
+    if feedback and g.sys.n == 4:
+        kinds.append(("float32fb", "float32", True))
+    for key, dt, fb in kinds:
         with contextlib.redirect_stdout(io.StringIO()):
-            dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, cfg["cf"], dtype=dt)
-        hs[dt] = dp._p
-    done = {"float32": 0, "float64": 0}
-    stop = {"float32": False, "float64": False}
-    curve = []
+            dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, cfg["cf"], dtype=dt, f32_feedback=fb)
+        hs[key] = dp._p
+    done = {k: 0 for k in hs}
+    stop = {k: False for k in hs}
+    secs = {k: 0.0 for k in hs}
+    curve, curve_fb = [], []
     while not all(stop.values()) and max(done.values()) < max_sweeps:
-        for dt, h in hs.items():
-            if not stop[dt]:
+        for key, h in hs.items():
+            if not stop[key]:
+                h.synchronize()
+                t1 = time.perf_counter()
                 st, n = h.sweep(every, 1.0, tol)
-                done[dt] += n
-                stop[dt] = n < every or (n and st[-1][3] <= tol)
+                h.synchronize()
+                secs[key] += time.perf_counter() - t1
+                done[key] += n
+                stop[key] = n < every or (n and st[-1][3] <= tol)
         a, b = hs["float32"].get_J(), hs["float64"].get_J()
-        curve.append([max(done.values()), float(np.abs(a - b).max() / np.abs(b).max())])
+        m = np.abs(b).max()
+        curve.append([max(done["float32"], done["float64"]), float(np.abs(a - b).max() / m)])
+        if "float32fb" in hs:
+            curve_fb.append([max(done["float32fb"], done["float64"]), float(np.abs(hs["float32fb"].get_J() - b).max() / m)])
     out = {"tol": tol, "sweeps_f32": done["float32"], "sweeps_f64": done["float64"], "rel_err": curve[-1][1],
+           "max_transient_rel_err": max(e for _, e in curve),
            "max_J": float(np.abs(b).max()), "drift_curve": curve, "seconds": time.perf_counter() - t0,
            "paths": {k: h.describe() for k, h in hs.items()}}
+    if curve_fb:
+        out["feedback"] = {"sweeps": done["float32fb"], "rel_err": curve_fb[-1][1], "max_transient_rel_err": max(e for _, e in curve_fb),
+                           "ms_per_sweep": secs["float32fb"] / max(1, done["float32fb"]) * 1e3,
+                           "ms_per_sweep_plain": secs["float32"] / max(1, done["float32"]) * 1e3,
+                           "ms_per_sweep_f64": secs["float64"] / max(1, done["float64"]) * 1e3, "drift_curve": curve_fb}
     for h in hs.values():
         h.close()
     return out

@@ -39,6 +39,18 @@ extern "C" {
                                   class's INF + alpha*J_interp (:567).  The two differ only where isavalidstate rejects
                                   states INSIDE the grid box (obstacles): honoured by the n = 3 obstacle dynamics */
 
+#define PVI_FLAG_F32_FEEDBACK 4 /* float32 handles on the 4-D window sweep (k_sweep_lean4): error-feedback storage of J.  A
+                                  float32 J that grows by a near-constant increment per sweep is rounded the same way sweep
+                                  after sweep; on BASELINE configs[2] the iterates drift to 1.5e-5 of max J around sweep
+                                  1 500 before the contraction pulls them back (J* itself: 2e-6).  With this flag every node
+                                  keeps the rounding residual of its own stored value (one more float per node, private to
+                                  the node): the backup of the chosen action is re-evaluated in float64 from the float32
+                                  window, the residual of the previous sweep is added, the sum is stored as float32 and the
+                                  new residual kept -- first-order noise shaping: roundings no longer add up over the
+                                  sweeps.  What the gathers read stays one float32 per node.  pvi_create fails with
+                                  PVI_EINVAL when the handle does not take that sweep (other dtype / dimension / a window
+                                  that does not fit LDS); pvi_set_J and pvi_terminal_cost clear the residuals. */
+
 /* error codes */
 #define PVI_OK 0
 #define PVI_EINVAL -1   /* bad argument / unsupported shape (reference: ValueError / NotImplementedError) */

@@ -25,6 +25,7 @@ CTL_TABLE, CTL_COMPUTED_TORQUE = 0, 1
 PVI_EHALO = -5
 FLAG_EXT_J_SLACK = 1
 FLAG_HARD_INF = 2
+FLAG_F32_FEEDBACK = 4     # error-feedback storage of a float32 J (4-D window sweep; include/pyrovi.h)
 ABI_VERSION = 3
 PVI_MAX_OBS = 8
 

@@ -67,6 +67,10 @@ def compact_line(full, full_path=None):
     if cv:
         out["converged"] = {k: _r(cv.get(k)) for k in ("tol", "sweeps_f32", "sweeps_f64", "rel_err", "max_transient_rel_err",
                                                        "seconds", "error") if k in cv}
+        fb = cv.get("feedback")
+        if fb:      # the float32 accuracy mode (PVI_FLAG_F32_FEEDBACK) solved beside the two
+            out["converged"]["feedback"] = {k: _r(fb.get(k)) for k in ("sweeps", "rel_err", "max_transient_rel_err", "ms_per_sweep",
+                                                                       "ms_per_sweep_plain", "ms_per_sweep_f64") if k in fb}
     tok = dict(t.split("=", 1) for t in str(full.get("kernel_path", "")).split() if "=" in t)
     out["kernel_path"] = " ".join("%s=%s" % (k, tok[k]) for k in ("path", "tile", "block", "lds_bytes", "mapping", "sparse")
                                   if k in tok)

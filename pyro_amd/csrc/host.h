@@ -81,6 +81,7 @@ struct Lean4P {
     int* summary;           // [0] max window rows (pair planes x p1 x j2), [1] longest row, [3] error bits, [4] max pair planes,
                             // [7] some node's cell range does not fit `box`
     const char4* box;       // per owned node: the velocity cells its actions reach, relative to (iv0, iv1) -- set-up only
+    float* jlo;             // [owned] PVI_FLAG_F32_FEEDBACK: rounding residual of the stored J of every node (NULL: plain storage)
 };
 
 // =================================================================================================

@@ -335,7 +335,10 @@ static int launch_lean4_t(pvi_problem* h, const float* Jin, float* Jout, float a
 #define L4(DYN)                                   \
     if (probe)                                    \
         L4K((k_sweep_lean4_probe<DYN, PI_T>))     \
-    else {                                        \
+    else if (L.jlo) {                             \
+        set_kname(h, "k_sweep_lean4fb", (int)DYN, tname<PI_T>()); \
+        L4K((k_sweep_lean4fb<DYN, PI_T>))         \
+    } else {                                      \
         set_kname(h, "k_sweep_lean4", (int)DYN, tname<PI_T>()); \
         L4K((k_sweep_lean4<DYN, PI_T>))           \
     }

@@ -1714,6 +1714,21 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
     HCHK(hipStreamSynchronize(h->stream));
 #undef HCHK
     if ((rc = lean_setup(h))) return bail(rc);
+    if (d->flags & PVI_FLAG_F32_FEEDBACK) {
+        // error-feedback storage: one residual per owned node, private to the node (sweep_lean4.inc lean4_feedback)
+        if (!h->lean4_ok)
+            return bail(fail(PVI_EINVAL, "PVI_FLAG_F32_FEEDBACK needs the float32 window sweep of 4-D grids; this handle does not take it (%s)",
+                             d->dtype != PVI_F32 ? "dtype is not float32" : d->n != 4 ? "not a 4-D grid" : h->lean_why[0] ? h->lean_why : "no window set-up"));
+        float* lo = nullptr;
+        if ((rc = dev_alloc(h, (size_t)h->owned, &lo))) return bail(rc);
+        rc = [&]() -> int {
+            HIPCHK(hipMemsetAsync(lo, 0, (size_t)h->owned * sizeof(float), h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            return PVI_OK;
+        }();
+        if (rc) return bail(rc);
+        h->L4.jlo = lo;
+    }
     if (d->dtype == PVI_F32 && is_dyn3(d->dynamics_id) && A <= 64 && !ovr("NO_FAST")) {
         // fast3: the validity of every cell of an explicit system, once (sweep_lean.inc's idea applied to the obstacle tests)
         unsigned long long* m = nullptr;
@@ -1881,9 +1896,9 @@ static int describe_impl(pvi_handle h, char* buf, int32_t n) {
         // win=1: position-paired window + ds_read_b64 (sweep_lean4.inc); tables: bit d set = the displacement table does
         // not span axis d; rowpieces / bands: the step-aligned row pieces of axis 2 and their grouping in the launch order
         snprintf(buf, (size_t)n, "path=lean tile=%dx%d grid=%ux1x1 block=%d pw1=%d lds_bytes=%zu lsplit=0 tb_tile=1 dma16=0 npt=1 "
-                 "reach=0 opmag=0 sparse=0 win=1 tables=%d ptab=%d gx=%s stage=%d choice=%s tiles_per_plane=%d bands=%d cands=%s note=%s", h->L4.TV0, h->L4.TV1,
+                 "reach=0 opmag=0 sparse=0 win=1 tables=%d ptab=%d gx=%s stage=%d feedback=%d choice=%s tiles_per_plane=%d bands=%d cands=%s note=%s", h->L4.TV0, h->L4.TV1,
                  h->lean4_grid, h->lean4_block, h->L4.RS, h->lean4_lds, h->lean4_tables, h->lean4_ptab_inv, h->L4.gx ? "node" : "axes", h->lean4_stage,
-                 h->lean4_choice, h->L4.ntr, h->lean4_bands, h->lean4_cands[0] ? h->lean4_cands : "-", h->lean_why);
+                 h->L4.jlo ? 1 : 0, h->lean4_choice, h->L4.ntr, h->lean4_bands, h->lean4_cands[0] ? h->lean4_cands : "-", h->lean_why);
         return PVI_OK;
     }
     snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d npt=%d reach=%d opmag=%d sparse=%d win=0 tables=0 note=%s",
@@ -1913,6 +1928,7 @@ static int terminal_cost_t(pvi_problem* h) {
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(h->pi, 0, (size_t)h->owned * h->pi_size, h->stream));
+    if (h->L4.jlo) HIPCHK(hipMemsetAsync(h->L4.jlo, 0, (size_t)h->owned * sizeof(float), h->stream));  // a new J: no residuals
     HIPCHK(hipStreamSynchronize(h->stream));
     return PVI_OK;
 }
@@ -1956,6 +1972,7 @@ extern "C" int pvi_set_J(pvi_handle h, const double* Jr, int32_t row0, int32_t n
     if (rc) return rc;
     HIPCHK(hipSetDevice(h->device));
     const long long n = (long long)nrows * h->plane, off = (long long)(row0 - h->P.store_begin) * h->plane;
+    if (h->L4.jlo) HIPCHK(hipMemsetAsync(h->L4.jlo, 0, (size_t)h->owned * sizeof(float), h->stream));  // a new J: no residuals
     if (h->d.dtype == PVI_F64) {
         HIPCHK(hipMemcpyAsync((double*)h->J[h->cur] + off, Jr, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
     } else {
@@ -2374,10 +2391,14 @@ extern "C" int pvi_self_check(pvi_handle h, double alpha, double* max_rel_diff, 
     const unsigned long long init[3] = {enc_f64(0.0), enc_f64(0.0), 0ull};
     int rc = [&]() -> int {
         HIPCHK(hipMemcpyAsync(out, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
-        // (1) the handle's production path: J_cur -> the other buffer, pi
+        // (1) the handle's production path: J_cur -> the other buffer, pi.  (A dry run: with error-feedback storage the plain
+        //     form of the window sweep runs, which leaves the residuals alone.)
         hipLaunchKernelGGL(k_reset_stats, 1, STAT_WORDS, 0, h->stream, h->slots, STAT_WORDS);
         hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, h->stream, h->ctrl);
+        float* const lo_keep = h->L4.jlo;
+        h->L4.jlo = nullptr;
         int r = launch_sweep(h, h->cur, alpha, h->stream, 0, -1.0);
+        h->L4.jlo = lo_keep;
         if (r) return r;
         // (2) the plain-gather kernel (float64 dynamics, no windows, no set-up tables) into scratch buffers
         void* Ja = h->J[h->cur ^ 1];

@@ -65,8 +65,14 @@ class DynamicProgramming:
     HISTORY_MAX_BYTES = 1 << 30     # save_time_history is dropped beyond this (J+pi per sweep)
     BATCH = 256                     # sweeps enqueued per host round trip when no history is kept
     INTERPOLATION = "linear"        # interpolant of J_k between the nodes (discretizer.py:570-587)
+    F32_FEEDBACK = False            # float32 on 4-D grids: error-feedback storage of J (PVI_FLAG_F32_FEEDBACK, include/pyrovi.h):
+                                    # every node keeps the rounding residual of its stored value, so the float32 iterates stay
+                                    # within ~2e-7 of the float64 ones over thousands of sweeps (plain float32 storage: up to
+                                    # 1.5e-5 mid-solve on BASELINE configs[2]; INTEGRATION.md, accuracy contract)
 
-    def __init__(self, grid_sys, cost_function, final_time=0, dtype="float64", device=0, comm=None):
+    def __init__(self, grid_sys, cost_function, final_time=0, dtype="float64", device=0, comm=None, f32_feedback=None):
+        if f32_feedback is not None:
+            self.F32_FEEDBACK = bool(f32_feedback)
         self.grid_sys, self.sys = grid_sys, grid_sys.sys
         self.cf, self.tf = cost_function, final_time
         self.alpha = 1.0
@@ -127,6 +133,8 @@ class DynamicProgramming:
         if self.comm is not None:
             if self.INTERPOLATION != "linear":
                 raise NotImplementedError("the spline fit couples every row of the grid: single-GPU only")
+            if self.F32_FEEDBACK:
+                raise NotImplementedError("f32_feedback: single-GPU engines only")
             self._p = self.comm.engine(self)
             self.tier = self._p.tier
             return
@@ -141,9 +149,15 @@ class DynamicProgramming:
         if self.tier == "fused":
             # (base class: an invalid cell costs exactly INF; the same as INF + alpha*0 unless the system rejects
             #  states inside the grid box, i.e. obstacles)
+            if self.F32_FEEDBACK and (self.dtype != np.float32 or self.sys.n != 4):
+                raise NotImplementedError("f32_feedback is the float32 storage mode of the 4-D window sweep (dtype %s, n = %d)"
+                                          % (self.dtype, self.sys.n))
             self._p = self.grid_sys._device_problem(cost=cost, dtype=self.dtype, device=self.device,
-                                                    flags=_native.FLAG_HARD_INF if self.HARD_INF else 0)
+                                                    flags=(_native.FLAG_HARD_INF if self.HARD_INF else 0)
+                                                    | (_native.FLAG_F32_FEEDBACK if self.F32_FEEDBACK else 0))
         else:
+            if self.F32_FEEDBACK:
+                raise NotImplementedError("f32_feedback: the fused tier only (this problem runs on the table tier)")
             g, s = self.grid_sys, self.sys
             self._p = _native.Problem(g.x_level, g.u_level, s.x_lb, s.x_ub, s.u_lb, s.u_ub, g.dt, dtype=self.dtype,
                                       dynamics_id=_native.DYN_TABLE, cost=None, device=self.device,
@@ -514,10 +528,10 @@ class DynamicProgramming2DRectBivariateSpline(DynamicProgrammingWithLookUpTable)
 
     INTERPOLATION = "bicubic"
 
-    def __init__(self, grid_sys, cost_function, final_time=0, dtype="float64", device=0, comm=None):
+    def __init__(self, grid_sys, cost_function, final_time=0, dtype="float64", device=0, comm=None, f32_feedback=None):
         if grid_sys.sys.n != 2:
             raise NotImplementedError                   # discretizer.py:599-610
-        super().__init__(grid_sys, cost_function, final_time, dtype=dtype, device=device, comm=comm)
+        super().__init__(grid_sys, cost_function, final_time, dtype=dtype, device=device, comm=comm, f32_feedback=f32_feedback)
 
     @property
     def J_interpol(self):

@@ -61,6 +61,32 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(pvi_desc), offsetof(p
     assert [int(v) for v in out] == mine
 
 
+def test_flag_values_match_the_header_and_feedback_refusals_need_no_device():
+    """pvi_desc.flags: the binding's constants are the header's; the float32 error-feedback mode (PVI_FLAG_F32_FEEDBACK) is
+    refused by the class surface where no kernel implements it -- float64, 2-D grids, sharded engines -- before any device
+    call."""
+    import re
+    import numpy as np
+    from pyro_amd import _native, configs
+    from pyro_amd.planning import dynamicprogramming as DP
+    hdr = open(os.path.join(ROOT, "include", "pyrovi.h")).read()
+    flags = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define PVI_FLAG_(\w+) (\d+)", hdr)}
+    assert flags == {"EXT_J_SLACK": _native.FLAG_EXT_J_SLACK, "HARD_INF": _native.FLAG_HARD_INF, "F32_FEEDBACK": _native.FLAG_F32_FEEDBACK}
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        c4 = configs.build("cartpole:5,5,5,5:3:float32")
+        c2 = configs.build("pendulum:9,9:3:float32")
+    for cfg, dt in ((c4, "float64"), (c2, "float32")):
+        with pytest.raises(NotImplementedError):
+            DP.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype=dt, f32_feedback=True)
+
+    class Comm:                         # never reached
+        def engine(self, dp):
+            raise AssertionError
+    with pytest.raises(NotImplementedError):
+        DP.DynamicProgrammingWithLookUpTable(c4["grid_sys"], c4["cf"], dtype="float32", comm=Comm(), f32_feedback=True)
+
+
 def test_no_cpu_fallback_without_device():
     """Creating a problem without a HIP device must fail loudly (no silent CPU path)."""
     from pyro_amd import _native

@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 4, error-feedback storage: drift curves on the GPU
+cd /root/repo; mkdir -p gpurun_out
+L=gpurun_out/r04_feedback.log; : > $L
+timeout 600 python tools/tools_drift_fb.py cartpole:31,31,31,31:21:float32 600 50 >> $L 2>&1
+timeout 1500 python tools/tools_drift_fb.py c3 2000 100 >> $L 2>&1
+cat $L
