@@ -210,6 +210,9 @@ def norm_kernel(name):
     return n.replace(" ", "")
 
 
+F32_FEEDBACK = False          # --f32-feedback: the float32 accuracy mode of 4-D grids (PVI_FLAG_F32_FEEDBACK, k_sweep_lean4fb)
+
+
 def check_counters(ctr, desc):
     """The committed PMC passes were taken with ONE kernel (template instantiation: recorded with them as `kernel`, the
     name the kernel trace printed) and one variant of its launch (tile shape, window layout ...: `kernel_path`);
@@ -245,7 +248,7 @@ def measure(name, steps, warmup, keep_handle=False):
     g = cfg["grid_sys"]
     t0 = time.perf_counter()
     with contextlib.redirect_stdout(io.StringIO()):
-        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, cfg["cf"], dtype=cfg["dtype"])
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, cfg["cf"], dtype=cfg["dtype"], f32_feedback=F32_FEEDBACK)
     p = dp._p
     p.synchronize()
     setup_ms = (time.perf_counter() - t0) * 1e3       # pvi_create (lean set-up, tile tuning) + J0 = h(x)
@@ -271,7 +274,7 @@ def measure(name, steps, warmup, keep_handle=False):
     timed = steps * batches
     kern_ms = kern_ms_sum / timed
 
-    alg_bytes = N * (2 * w + pbytes)
+    alg_bytes = N * (2 * w + pbytes + (8 if F32_FEEDBACK else 0))      # error-feedback storage: one residual per node, read and written
     desc = p.describe()
     tok = dict(t.split("=", 1) for t in desc.split() if "=" in t)
     ctr, ctr_err = check_counters(load_counters(cfg["name"]), desc)
@@ -291,7 +294,8 @@ def measure(name, steps, warmup, keep_handle=False):
         "ms_per_step": elapsed / timed * 1e3, "sweeps_per_sec": timed / elapsed, "setup_ms": setup_ms,
         "dtype": dt_name,
         "config": {"workload": "%s: %s" % (cfg["name"], cfg["description"]), "nodes": N, "actions": A,
-                   "cells_per_sweep": N * A, "dt": g.dt, "alpha": 1.0, "parallelism": "1 GPU"},
+                   "cells_per_sweep": N * A, "dt": g.dt, "alpha": 1.0, "parallelism": "1 GPU",
+                   **({"f32_feedback": True} if F32_FEEDBACK else {})},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": ctr.get("hbm_bytes_per_launch"),
                      "traffic_source": ctr.get("source") if ctr.get("hbm_bytes_per_launch") else None,
@@ -589,6 +593,8 @@ def main():
                     help="solve the workload to tol 0.1 in float32 and float64 and report the J* difference "
                          "(default: on for the default run, off with --workload)")
     ap.add_argument("--no-converged", dest="converged", action="store_false")
+    ap.add_argument("--f32-feedback", action="store_true",
+                    help="with --workload <4-D float32 workload>: error-feedback storage of J (k_sweep_lean4fb)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or os.environ.get("PVI_FORCE_PARALLEL"):
@@ -597,6 +603,11 @@ def main():
     args.with_secondary = args.workload is None and not args.no_cpu and not args.no_secondary   # the default driver run
     if args.converged is None:
         args.converged = args.with_secondary
+    if args.f32_feedback:
+        if args.workload is None:
+            ap.error("--f32-feedback goes with --workload (the default line is the plain float32 production path)")
+        global F32_FEEDBACK
+        F32_FEEDBACK = True
     args.workload = args.workload or "c3"
     big = args.workload in ("c3", "c4", "c5", "c5d")
     args.steps = args.steps if args.steps is not None else (20 if big else 2000)

@@ -44,8 +44,8 @@ extern "C" {
                                   after sweep; on BASELINE configs[2] the iterates drift to 1.5e-5 of max J around sweep
                                   1 500 before the contraction pulls them back (J* itself: 2e-6).  With this flag every node
                                   keeps the rounding residual of its own stored value (one more float per node, private to
-                                  the node): the backup of the chosen action is re-evaluated in float64 from the float32
-                                  window, the residual of the previous sweep is added, the sum is stored as float32 and the
+                                  the node): the backup of the chosen action is re-evaluated in float64 (float64
+                                  dynamics, the float32 window values), the residual of the previous sweep is added, the sum is stored as float32 and the
                                   new residual kept -- first-order noise shaping: roundings no longer add up over the
                                   sweeps.  What the gathers read stays one float32 per node.  pvi_create fails with
                                   PVI_EINVAL when the handle does not take that sweep (other dtype / dimension / a window
