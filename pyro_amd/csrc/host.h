@@ -82,6 +82,7 @@ struct Lean4P {
                             // [7] some node's cell range does not fit `box`
     const char4* box;       // per owned node: the velocity cells its actions reach, relative to (iv0, iv1) -- set-up only
     float* jlo;             // [owned] PVI_FLAG_F32_FEEDBACK: rounding residual of the stored J of every node (NULL: plain storage)
+    double alpha64;         // ... and the discount factor of the launch unrounded (the sweep's own `alpha` is its float32 value)
 };
 
 // =================================================================================================

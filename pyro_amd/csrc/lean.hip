@@ -2,6 +2,7 @@
 // 4-D grids (k_sweep_lean4, sweep_lean4.inc), the plain-gather k_sweep_fast, their set-up (per-node coefficient tables, tilings,
 // timed candidates, launch schedules) and launchers.  One of the three translation units of libpyrovi (pyrovi.hip, f64.hip,
 // lean.hip); see core.h / host.h.
+#include <chrono>
 #include "core.h"
 #include "host.h"
 
@@ -828,6 +829,56 @@ static int lean4_setup(pvi_problem* h) {
         for (auto& e : tev) HIPCHK(hipEventCreate(&e));
     float best_ms = 1e30f;
     int best = -1;
+    SweepCtl sc;
+    memset(&sc, 0, sizeof(sc));
+    sc.ctrl = h->ctrl;
+    sc.slot = h->slots;
+    sc.result = h->results;
+    sc.tol = -1.0;
+    auto probe_sweep = [&]() -> int {
+        hipLaunchKernelGGL(k_reset_stats, 1, STAT_WORDS, 0, h->stream, h->slots, STAT_WORDS);
+        hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, h->stream, h->ctrl);
+        return h->pi_size == 1 ? launch_lean4_t<unsigned char>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc, true)
+                               : launch_lean4_t<unsigned short>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc, true);
+    };
+    // one warm-up and five timed sweeps of the tiling lean4_try has just set up: the median, or (hopeless) the warm-up's time
+    auto time_reps = [&](float& ms, bool may_give_up) -> int {
+        bool hopeless = false;
+        for (int rep = 0; rep < 6 && !hopeless; ++rep) {
+            HIPCHK(hipEventRecord(tev[rep], h->stream));
+            const int r = probe_sweep();
+            if (r) return r;
+            if (rep == 0) {  // (the warm-up sweep of a shape far off the best: not worth five more)
+                float warm = 0.f;
+                HIPCHK(hipEventRecord(tev[6], h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                HIPCHK(hipEventElapsedTime(&warm, tev[0], tev[6]));
+                if (may_give_up && best >= 0 && warm > 1.6f * best_ms) {
+                    hopeless = true;
+                    ms = warm;
+                }
+            }
+        }
+        if (!hopeless) {
+            HIPCHK(hipEventRecord(tev[6], h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            float t[5];
+            for (int i = 0; i < 5; ++i) HIPCHK(hipEventElapsedTime(&t[i], tev[1 + i], tev[i + 2 <= 5 ? i + 2 : 6]));
+            std::sort(t, t + 5);
+            ms = t[2];
+        }
+        return PVI_OK;
+    };
+    auto note = [&](const char* tag, const Lean4Cand& c, float ms) {
+        // (milliseconds of the timed rows scaled to the slab: comparable with a whole sweep)
+        const float full = ms * (float)rows / (float)sub_rows;
+        const size_t at = strlen(h->lean4_cands);
+        if (c.wmax < V1)
+            snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, "%s%s%d/%d/%d:%.2f", at ? "," : "", tag, c.cap, c.w, c.wmax, full);
+        else
+            snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, "%s%s%d/%d:%.2f", at ? "," : "", tag, c.cap, c.w, full);
+    };
+    int first = -1;  // the first candidate that fits: timed on a device that may still be ramping its clocks
     for (size_t ci = 0; ci < cands.size(); ++ci) {
         int narrower = 0;
         rc = lean4_try(h, hpt0, cands[ci].cap, cands[ci].w, cands[ci].wmax, budget, &narrower, tune ? sub_r0 : 0,
@@ -838,56 +889,48 @@ static int lean4_setup(pvi_problem* h) {
             best = (int)ci;
             break;
         }
-        float ms = 0.f;
-        SweepCtl sc;
-        memset(&sc, 0, sizeof(sc));
-        sc.ctrl = h->ctrl;
-        sc.slot = h->slots;
-        sc.result = h->results;
-        sc.tol = -1.0;
-        bool hopeless = false;
-        for (int rep = 0; rep < 6 && rc == 0 && !hopeless; ++rep) {  // one warm-up, five timed
-            HIPCHK(hipEventRecord(tev[rep], h->stream));
-            hipLaunchKernelGGL(k_reset_stats, 1, STAT_WORDS, 0, h->stream, h->slots, STAT_WORDS);
-            hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, h->stream, h->ctrl);
-            rc = h->pi_size == 1 ? launch_lean4_t<unsigned char>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc, true)
-                                 : launch_lean4_t<unsigned short>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc, true);
-            if (rc) return rc;
-            if (rep == 0) {  // (the warm-up sweep of a shape far off the best: not worth five more)
-                float warm = 0.f;
-                HIPCHK(hipEventRecord(tev[6], h->stream));
+        if (first < 0) {
+            // The first candidate used to be timed on a cold device (a create right after process start: 6 x 0.3 ms of work):
+            // 19/512 on C3 read 3.25 ms instead of 2.8, 5/256 displaced it at 3.04 and the sweep ran 2.94 ms instead of 2.78
+            // (profiles/r04_autotune_cold_start.log).  Now the device sweeps this candidate for 25 ms before anything is timed ...
+            first = (int)ci;
+            const auto w0 = std::chrono::steady_clock::now();
+            while (std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() < 0.025) {
+                for (int k = 0; k < 8; ++k)
+                    if ((rc = probe_sweep())) return rc;
                 HIPCHK(hipStreamSynchronize(h->stream));
-                HIPCHK(hipEventElapsedTime(&warm, tev[0], tev[6]));
-                if (best >= 0 && warm > 1.6f * best_ms) {
-                    hopeless = true;
-                    ms = warm;
-                }
             }
         }
-        if (rc) return rc;
-        if (!hopeless) {
-            HIPCHK(hipEventRecord(tev[6], h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
-            float t[5];
-            for (int i = 0; i < 5; ++i) HIPCHK(hipEventElapsedTime(&t[i], tev[1 + i], tev[i + 2 <= 5 ? i + 2 : 6]));
-            std::sort(t, t + 5);
-            ms = t[2];
-        }
-        {
-            // (milliseconds of the timed rows scaled to the slab: comparable with a whole sweep)
-            const float full = ms * (float)rows / (float)sub_rows;
-            const size_t at = strlen(h->lean4_cands);
-            if (cands[ci].wmax < V1)
-                snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, ",%d/%d/%d:%.2f", cands[ci].cap, cands[ci].w, cands[ci].wmax, full);
-            else
-                snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, "%s%d/%d:%.2f", at ? "," : "", cands[ci].cap, cands[ci].w, full);
-        }
+        float ms = 0.f;
+        if ((rc = time_reps(ms, true))) return rc;
+        note("", cands[ci], ms);
         // (a narrower twin of a shape that is in the running: one more workgroup per CU may pay for the extra window halo)
         if (narrower && cands[ci].wmax == V1 && ms < 1.1f * best_ms && cands.size() < 48)
             cands.push_back({cands[ci].cap, cands[ci].w, narrower});
         if (ms < 0.95f * best_ms) {  // a later candidate must win by 5 %: within the timing noise the choice stays put, so the
             best_ms = ms;            // shape (and with it the committed counter passes) is the same from run to run
             best = (int)ci;
+        }
+    }
+    if (tune && best >= 0 && first >= 0 && best != first) {
+        // ... and a candidate that displaced the first one must beat it again, by the same 5 %, when both are timed back to back at
+        // the end (first, winner, first: the lower of the first one's two medians counts)
+        float f1 = 0.f, w = 0.f, f2 = 0.f;
+        const Lean4Cand cf = cands[(size_t)first], cw = cands[(size_t)best];
+        rc = lean4_try(h, hpt0, cf.cap, cf.w, cf.wmax, budget, nullptr, sub_r0, sub_rows);
+        if (rc == 0) rc = time_reps(f1, false);
+        if (rc == 0) rc = lean4_try(h, hpt0, cw.cap, cw.w, cw.wmax, budget, nullptr, sub_r0, sub_rows);
+        if (rc == 0) rc = time_reps(w, false);
+        if (rc == 0) rc = lean4_try(h, hpt0, cf.cap, cf.w, cf.wmax, budget, nullptr, sub_r0, sub_rows);
+        if (rc == 0) rc = time_reps(f2, false);
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            note("again:", cf, std::min(f1, f2));
+            note("again:", cw, w);
+            if (!(w < 0.95f * std::min(f1, f2))) {
+                best = first;
+                best_ms = std::min(f1, f2);
+            }
         }
     }
     if (best < 0) return give_up(h->lean_why[0] ? h->lean_why : "no tile shape fits the LDS budget");

@@ -2088,7 +2088,10 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         return PVI_OK;
     }
     if constexpr (sizeof(REAL) == 4) {  // the float32 production families (lean.hip)
-        if (h->lean4_ok && !h->force_exact) return launch_lean4(h, Jin, Jout, (float)alpha, st, sc);
+        if (h->lean4_ok && !h->force_exact) {
+            h->L4.alpha64 = alpha;  // (read by the error-feedback epilogue only)
+            return launch_lean4(h, Jin, Jout, (float)alpha, st, sc);
+        }
         if (h->lean_ok && !h->force_exact) return launch_lean2(h, Jin, Jout, (float)alpha, st, sc);
         if (h->fast_ok && !is_node_dyn(h->d.dynamics_id) && !h->force_exact) return launch_fast(h, Jin, Jout, (float)alpha, st, sc);
     }

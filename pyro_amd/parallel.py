@@ -365,8 +365,10 @@ class RcclValueIteration:
     Construction is collective (pvi_shard_create: the ranks agree on the halo width and on success)."""
 
     def __init__(self, grid_sys, cost_function, rank, world, comm_id=None, dtype="float32", device=0, halo=None,
-                 overlap=True, transport=None, hard_inf=False, tables=None):
-        """`tables`: dict(u_levels, u_lb, u_ub, build) for table-tier problems whose tables are NOT the reference's
+                 overlap=True, transport=None, hard_inf=False, tables=None, f32_feedback=False):
+        """`f32_feedback`: error-feedback storage of a float32 J (4-D fused tier; every piece of the slab keeps the residuals
+        of its own rows -- PVI_FLAG_F32_FEEDBACK; bit-identical to the single-GPU handle).
+        `tables`: dict(u_levels, u_lb, u_ub, build) for table-tier problems whose tables are NOT the reference's
         x_next / G look-up tables of the grid's own action set -- policy evaluation: one action per node, the controller's
         (PolicyEvaluator*).  build(lo, hi) -> (x_next [nodes, A, n], G [nodes, A], ok [nodes, A] | None) of this rank's nodes."""
         from pyro_amd import _native
@@ -389,11 +391,14 @@ class RcclValueIteration:
                 halo = halo_rows(grid_sys) if mech else -halo_rows(grid_sys, (r0, r1), device=device)
             self.shard = grid_sys._shard_problem(self.rank, self.world, int(halo), comm_id=comm_id, overlap=overlap,
                                                  cost=cost, dtype=dtype, device=device, transport=transport,
-                                                 flags=_native.FLAG_HARD_INF if hard_inf else 0)
+                                                 flags=(_native.FLAG_HARD_INF if hard_inf else 0)
+                                                 | (_native.FLAG_F32_FEEDBACK if f32_feedback else 0))
             self.halo = self.shard.halo
             self.rows = self.shard.rows
             self.shard.terminal_cost()
             return
+        if f32_feedback:
+            raise NotImplementedError("f32_feedback: the fused tier only (this problem runs on the table tier)")
         # table tier (arbitrary Python sys.f / cf.g): every rank builds the reference's look-up tables for ITS rows only
         # (the O(N*A) host loops of discretizer.py:342-376 and dynamicprogramming.py:517-553, split over the ranks) and
         # the sweeps run sharded like the fused ones
@@ -540,7 +545,8 @@ class _LibraryEngine:
     def __init__(self, dp, comm, transport, allgather):
         self.vi = RcclValueIteration(dp.grid_sys, dp.cf, comm.rank, comm.world, comm_id=getattr(comm, "comm_id", None),
                                      dtype=dp.dtype, device=dp.device, overlap=comm.overlap, transport=transport,
-                                     hard_inf=dp.HARD_INF, tables=dp.__dict__.get("_shard_tables"))
+                                     hard_inf=dp.HARD_INF, tables=dp.__dict__.get("_shard_tables"),
+                                     f32_feedback=bool(getattr(dp, "F32_FEEDBACK", False)))
         self.shard, self.tier, self.rows = self.vi.shard, self.vi.tier, self.vi.rows
         self.world, self._allgather = comm.world, allgather
         self.plane = self.shard.plane
@@ -590,6 +596,8 @@ class _TorchEngine:
             # (the Python-driven schedule has no table tier: RcclComm / TransportComm shard the look-up tables)
             raise NotImplementedError("TorchDistComm drives the fused tier only (in-kernel dynamics and cost); use RcclComm "
                                       "or TransportComm for systems / costs that need look-up tables")
+        if getattr(dp, "F32_FEEDBACK", False):
+            raise NotImplementedError("f32_feedback: sharded through the library (RcclComm / TransportComm), not the Python-driven slabs")
         self.vi = ShardedValueIteration(dp.grid_sys, dp.cf, comm.dist, dtype=dp.dtype, device=dp.device,
                                         slab_factory=comm.slab_factory, overlap=comm.overlap, hard_inf=bool(dp.HARD_INF))
         self.tier, self.rows, self.world = "fused", self.vi.rows, comm.world

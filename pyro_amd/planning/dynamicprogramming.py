@@ -133,9 +133,10 @@ class DynamicProgramming:
         if self.comm is not None:
             if self.INTERPOLATION != "linear":
                 raise NotImplementedError("the spline fit couples every row of the grid: single-GPU only")
-            if self.F32_FEEDBACK:
-                raise NotImplementedError("f32_feedback: single-GPU engines only")
-            self._p = self.comm.engine(self)
+            if self.F32_FEEDBACK and (self.dtype != np.float32 or self.sys.n != 4):
+                raise NotImplementedError("f32_feedback is the float32 storage mode of the 4-D window sweep (dtype %s, n = %d)"
+                                          % (self.dtype, self.sys.n))
+            self._p = self.comm.engine(self)        # (the library's sharded engines carry the flag; the Python-driven one refuses)
             self.tier = self._p.tier
             return
         dd = device_dynamics_of(self.sys)

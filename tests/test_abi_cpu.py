@@ -63,7 +63,7 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(pvi_desc), offsetof(p
 
 def test_flag_values_match_the_header_and_feedback_refusals_need_no_device():
     """pvi_desc.flags: the binding's constants are the header's; the float32 error-feedback mode (PVI_FLAG_F32_FEEDBACK) is
-    refused by the class surface where no kernel implements it -- float64, 2-D grids, sharded engines -- before any device
+    refused by the class surface where no kernel implements it -- float64, 2-D grids, also sharded -- before any device
     call."""
     import re
     import numpy as np
@@ -80,11 +80,13 @@ def test_flag_values_match_the_header_and_feedback_refusals_need_no_device():
         with pytest.raises(NotImplementedError):
             DP.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype=dt, f32_feedback=True)
 
-    class Comm:                         # never reached
+    class Comm:                         # never reached: the refusal comes before the engine is built
         def engine(self, dp):
             raise AssertionError
     with pytest.raises(NotImplementedError):
-        DP.DynamicProgrammingWithLookUpTable(c4["grid_sys"], c4["cf"], dtype="float32", comm=Comm(), f32_feedback=True)
+        DP.DynamicProgrammingWithLookUpTable(c4["grid_sys"], c4["cf"], dtype="float64", comm=Comm(), f32_feedback=True)
+    with pytest.raises(NotImplementedError):
+        DP.DynamicProgrammingWithLookUpTable(c2["grid_sys"], c2["cf"], dtype="float32", comm=Comm(), f32_feedback=True)
 
 
 def test_no_cpu_fallback_without_device():

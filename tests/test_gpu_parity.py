@@ -2354,7 +2354,7 @@ with contextlib.redirect_stdout(io.StringIO()):
         from table_case import table_case
         cfg = table_case()
     else:
-        cfg = configs.build(case.split(":", 1)[1] if case.startswith("halo-mismatch:") else case)
+        cfg = configs.build(case.split(":", 1)[1] if case.startswith(("halo-mismatch:", "fb:")) else case)
 if case.startswith("halo-mismatch:"):
     # one width for the whole grid: ranks that pass different widths must ALL be refused (no hang, no wrong rows)
     try:
@@ -2368,7 +2368,7 @@ if case.startswith("halo-mismatch:"):
         sys.exit(0)
     raise SystemExit("a per-rank halo width was accepted")
 vi = parallel.RcclValueIteration(cfg["grid_sys"], cfg["cf"], rank, world, dtype=cfg["dtype"], overlap=bool(overlap),
-                                 transport=(sendrecv, max3))
+                                 transport=(sendrecv, max3), f32_feedback=case.startswith("fb:"))
 st5, n5 = vi.run(5, 1.0, -1.0)
 st, n = vi.run(400, 1.0, float(sys.argv[7]))
 J, pi = vi.owned()
@@ -2383,6 +2383,8 @@ print("TRANSPORT-RANK-OK", rank)
 @pytest.mark.parametrize("case,world,overlap,tol", [("python-system", 3, True, 0.5),
                                                     ("cartpole:21,21,21,21:7:float32", 2, True, -1.0),
                                                     ("cartpole:21,21,21,21:7:float32", 3, True, 0.5),
+                                                    # error-feedback storage: every piece of a slab keeps the residuals of its rows
+                                                    ("fb:cartpole:21,21,21,21:7:float32", 3, True, -1.0),
                                                     ("pendulum:101,101:11:float64", 2, False, 0.5),
                                                     ("pendulum:101,101:11:float32", 4, True, -1.0),
                                                     ("halo-mismatch:pendulum:41,41:5:float32", 2, True, -1.0)])
@@ -2426,10 +2428,14 @@ def test_c_shard_schedule_with_caller_transport_on_one_gpu(tmp_path, case, world
         assert dp.tier == "table" and "table" in str(parts[0]["desc"])
         h = dp._p
     else:
+        from pyro_amd import _native
         with contextlib.redirect_stdout(io.StringIO()):
-            cfg = configs.build(case)
-            h = cfg["grid_sys"]._device_problem(cost=cfg["cf"].device_cost(), dtype=cfg["dtype"])
+            cfg = configs.build(case[3:] if case.startswith("fb:") else case)
+            h = cfg["grid_sys"]._device_problem(cost=cfg["cf"].device_cost(), dtype=cfg["dtype"],
+                                                flags=_native.FLAG_F32_FEEDBACK if case.startswith("fb:") else 0)
         h.terminal_cost()
+        if case.startswith("fb:"):
+            assert "feedback=1" in h.describe()
     st5, _ = h.sweep(5, 1.0, -1.0)
     st, n = h.sweep(400, 1.0, tol)
     assert np.array_equal(np.concatenate([p["J"] for p in parts]), h.get_J())
