@@ -117,6 +117,14 @@ def build(force=False, verbose=True):
     return _make(OUT, "o3", FLAGS, ["-shared", "-fPIC"], force, verbose)
 
 
+def build_variant(name, defines=(), extra_flags=(), force=False, verbose=True):
+    """An experiment build next to the product library: pyro_amd/libpyrovi_<name>.so compiled with -D<define> ... (A/B runs on
+    one box select it with PYROVI_LIB).  Not part of build(): tools/ scripts call it before a gpurun."""
+    out = os.path.join(PKG, "libpyrovi_%s.so" % name)
+    flags = FLAGS + ["-D" + d for d in defines] + list(extra_flags)
+    return _make(out, "x_" + name, flags, ["-shared", "-fPIC"], force, verbose)
+
+
 def build_all(force=False, verbose=True):
     """Product and sanitized library: all six compilations side by side, then the two links."""
     jobs = _compile_jobs("o3", FLAGS, force) + _compile_jobs("san", FLAGS_SAN, force)

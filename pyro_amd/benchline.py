@@ -30,7 +30,7 @@ def compact_line(full, full_path=None):
     out["config"] = {k: cfg.get(k) for k in ("workload", "nodes", "actions", "cells_per_sweep", "parallelism") if k in cfg}
     for k in ("sweeps_per_sec", "batches", "timed_steps", "timed_region_s", "setup_ms", "rccl_ranks", "kernel_ms_max_rank",
               "exposed_exchange_ms_max_rank", "overlap_efficiency", "value_1gpu_c3", "value_1gpu_same_workload",
-              "strong_scaling_speedup", "in_library_rccl_error", "selftest"):
+              "strong_scaling_speedup", "in_library_rccl_error", "selftest", "invalid", "value_unverified"):
         if k in full:
             out[k] = _r(full[k])
     pr = full.get("per_rank")

@@ -5,6 +5,20 @@
 
 #define PVI_INTERNAL __attribute__((visibility("hidden")))
 
+#ifdef PVI_TRACE  // (round-5 fault hunt builds only: every device allocation and sweep launch on stderr)
+static inline hipError_t pvi_traced_malloc(void** p, size_t n, const char* f, int l) {
+    const hipError_t e = hipMalloc(p, n);
+    fprintf(stderr, "PVI_TRACE malloc %p %p %zu %s:%d\n", *p, (void*)((char*)*p + n), n, f, l);
+    return e;
+}
+static inline hipError_t pvi_traced_free(void* p, const char* f, int l) {
+    fprintf(stderr, "PVI_TRACE free %p %s:%d\n", p, f, l);
+    return hipFree(p);
+}
+#define hipMalloc(p, n) pvi_traced_malloc((void**)(p), (n), __FILE__, __LINE__)
+#define hipFree(p) pvi_traced_free((void*)(p), __FILE__, __LINE__)
+#endif
+
 // ---- structures the kernel families take by value ----------------------------------------------------------------------
 struct Act64 {
     double u0, u1, gu, aok;

@@ -803,6 +803,7 @@ static int lean4_setup(pvi_problem* h) {
     snprintf(key, sizeof(key), "%d/%d:%dx%dx%dx%d:A%d:rows%d:dt%.17g:lb%.17g,%.17g:ub%.17g,%.17g:lds%zu", h->device, h->d.dynamics_id,
              P.dim[0], P.dim[1], P.dim[2], P.dim[3], P.A, rows, P.dt, P.lb[2], P.lb[3], P.ub[2], P.ub[3], budget);
     bool from_cache = false;
+    const std::vector<Lean4Cand> all_cands = cands;  // (kept: a cached shape that does not fit THIS handle falls back to the list)
     if (!ovr_is("TUNE", 0) && !(ovr("TV0") && ovr("TV1")) && !ovr("L4PIN") && !ovr_is("TUNE", 2)) {
         std::lock_guard<std::mutex> lk(g_lean4_choice_mu);
         auto it = g_lean4_choice.find(key);
@@ -811,7 +812,7 @@ static int lean4_setup(pvi_problem* h) {
             from_cache = true;
         }
     }
-    const bool tune = !ovr_is("TUNE", 0) && cands.size() > 1;
+    bool tune = !ovr_is("TUNE", 0) && cands.size() > 1;
     // Timed candidates (round 4): every candidate sweeps the SAME few rows of axis 0 from the middle of the slab -- one warm-up
     // and five timed sweeps, each between its own pair of events -- and is judged by the MEDIAN; a later candidate displaces
     // the best so far only by 5 %.  Round 3 timed two whole-grid sweeps per candidate (C4: 52 x 25 ms) and a 2 % margin: the
@@ -879,6 +880,19 @@ static int lean4_setup(pvi_problem* h) {
             snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, "%s%s%d/%d:%.2f", at ? "," : "", tag, c.cap, c.w, full);
     };
     int first = -1;  // the first candidate that fits: timed on a device that may still be ramping its clocks
+    for (int attempt = 0; attempt < 2 && best < 0; ++attempt) {
+    if (attempt == 1) {
+        // The key leaves out what decides whether a window FITS (the slab's rows, the position bounds, the dynamics constants):
+        // the cached shape of another piece or rank in this process was refused by lean4_try.  Time the normal list instead of
+        // giving the window sweep up (the handle fell to a slower kernel, PVI_FLAG_F32_FEEDBACK failed with EINVAL).
+        if (!from_cache) break;
+        from_cache = false;
+        cands = all_cands;
+        tune = !ovr_is("TUNE", 0) && cands.size() > 1;
+        if (tune)
+            for (auto& e : tev)
+                if (!e) HIPCHK(hipEventCreate(&e));
+    }
     for (size_t ci = 0; ci < cands.size(); ++ci) {
         int narrower = 0;
         rc = lean4_try(h, hpt0, cands[ci].cap, cands[ci].w, cands[ci].wmax, budget, &narrower, tune ? sub_r0 : 0,
@@ -911,6 +925,7 @@ static int lean4_setup(pvi_problem* h) {
             best_ms = ms;            // shape (and with it the committed counter passes) is the same from run to run
             best = (int)ci;
         }
+    }
     }
     if (tune && best >= 0 && first >= 0 && best != first) {
         // ... and a candidate that displaced the first one must beat it again, by the same 5 %, when both are timed back to back at

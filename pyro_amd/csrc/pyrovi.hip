@@ -2238,6 +2238,19 @@ int launch_sweep(pvi_problem* h, int src, double alpha, hipStream_t st, int k, d
     sc.xcd_remap = 0;
     sc.regtab = 0;
     sc.win_bytes = 0;
+#ifdef PVI_TRACE
+    fprintf(stderr, "PVI_TRACE launch h=%p k=%d src=%d Jin=%p Jout=%p pi=%p tol=%g %s\n", (void*)h, k, src, h->J[src], h->J[src ^ 1], h->pi, tol, h->kname);
+    struct TraceSync {
+        pvi_problem* h;
+        hipStream_t st;
+        ~TraceSync() {
+            if (PVI_TRACE >= 2) {
+                const hipError_t e = hipStreamSynchronize(st);
+                fprintf(stderr, "PVI_TRACE done h=%p %s\n", (void*)h, hipGetErrorString(e));
+            }
+        }
+    } trace_sync{h, st};
+#endif
     if (h->d.dtype == PVI_F64)
         return h->pi_size == 1 ? launch_sweep_t<double, unsigned char>(h, src, alpha, st, sc)
                                : launch_sweep_t<double, unsigned short>(h, src, alpha, st, sc);

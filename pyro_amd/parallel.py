@@ -82,9 +82,11 @@ def _rows_for_reach(d):
     whose lower corner is floor(d) rows away and the interpolation reads that row and the next: floor(d) + 1 rows (also when
     d is a whole number: the upper corner then carries weight 0 but is still read).  Rounds 1-3 used ceil(d) + 1, one row
     more than needed whenever d is not whole (C4: d = 3.75 -> 5 rows instead of 4, 20 % more exchange traffic; VERDICT r3
-    weak #8).  The small relative guard keeps a d that is whole up to rounding on the safe side; the library reports
-    PVI_EHALO if a gather ever leaves the stored rows."""
-    return int(math.floor(d * (1.0 + 1e-12) + 1e-9)) + 1
+    weak #8).  The guard of 2e-6 cells keeps a d that is whole up to rounding on the safe side -- also for kernels that form
+    x_next in float32 (an ulp of a ten-cell displacement is 1e-6 cells): it costs a row only when d lies within
+    2e-6 below a whole number.  The library reports PVI_EHALO if a gather ever leaves the stored rows (the LDS-window sweeps
+    refuse the handle at set-up instead: "halo too small", sweep_lean4.inc k_lean4_node)."""
+    return int(math.floor(d * (1.0 + 1e-12) + 2e-6)) + 1
 
 
 def _xnext_of_rows(grid_sys, rows, device=0):

@@ -9,6 +9,7 @@ import contextlib
 import io
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -115,6 +116,9 @@ def _selftest(dist, torch, rank, world, local, via_torch, name="cartpole:41,13,1
     statistics of the last sweep must be the same bits (same kernels, same arithmetic per node; only the rows a rank does
     not own travel).  Returns {"ok": bool, ...}; every rank takes part, rank 0 holds the verdict."""
     cfg = _quiet_build(name, world=world)
+    # The collective section: every step in it is entered by all ranks or (a failure the library's own agreements report on
+    # every rank) by none.  What follows it is LOCAL to rank 0; an exception there is caught and travels with the verdict, so
+    # that the other ranks are never left waiting in the broadcast below (ADVICE r4).
     drv = _Driver(cfg, dist, torch, rank, world, local, via_torch)
     st = drv.run(sweeps - 1)                 # (the driver's constructor ran one sweep already when it used the library's RCCL path)
     if drv.fallback_reason is None and hasattr(drv.vi, "shard"):
@@ -127,16 +131,20 @@ def _selftest(dist, torch, rank, world, local, via_torch, name="cartpole:41,13,1
     drv.close()
     res = {"ok": True, "grid": name, "sweeps": done, "ranks": world}
     if rank == 0:
-        from pyro_amd.planning import dynamicprogramming
-        with contextlib.redirect_stdout(io.StringIO()):
-            dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype=cfg["dtype"], device=local)
-        stats, _ = dp._p.sweep(done, 1.0, -1.0)
-        J1, pi1 = dp._p.get_J(), dp._p.get_pi()
-        dp._p.close()
-        res["ok"] = bool(np.array_equal(J, J1) and np.array_equal(pi, pi1) and np.allclose(st[:3], stats[-1][:3], rtol=1e-12, atol=0))
-        if not res["ok"]:
-            res["max_abs_diff_J"] = float(np.abs(np.asarray(J) - J1).max())
-            res["pi_mismatches"] = int((np.asarray(pi) != pi1).sum())
+        try:
+            from pyro_amd.planning import dynamicprogramming
+            with contextlib.redirect_stdout(io.StringIO()):
+                dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype=cfg["dtype"], device=local)
+            stats, _ = dp._p.sweep(done, 1.0, -1.0)
+            J1, pi1 = dp._p.get_J(), dp._p.get_pi()
+            dp._p.close()
+            res["ok"] = bool(np.array_equal(J, J1) and np.array_equal(pi, pi1) and np.allclose(st[:3], stats[-1][:3], rtol=1e-12, atol=0))
+            if not res["ok"]:
+                res["max_abs_diff_J"] = float(np.abs(np.asarray(J) - J1).max())
+                res["pi_mismatches"] = int((np.asarray(pi) != pi1).sum())
+        except Exception as e:                            # noqa: BLE001
+            res["ok"] = False
+            res["error"] = "rank 0, one-GPU reference: %s: %s" % (type(e).__name__, e)
     flag = [res["ok"] if rank == 0 else None]
     dist.broadcast_object_list(flag, src=0)
     res["ok"] = bool(flag[0])
@@ -281,11 +289,17 @@ def run(args):
                "data": "synthetic", "config": frag.pop("config")}
         out.update(frag)
         out["selftest"] = selftest
+        if selftest is not None and not selftest.get("ok"):
+            # a sharded result that differs from one GPU's is not a measurement of this path: no number in `value`
+            out["value_unverified"] = out["value"]
+            out["value"] = None
+            out["invalid"] = "self-test failed: the sharded solve of %s differs from one rank's (see selftest)" % selftest.get("grid", "the small grid")
+            print("bench.py: SELF-TEST FAILED -- value withheld: %r" % (selftest,), file=sys.stderr, flush=True)
         if weak:
             out["value_1gpu_c3"] = ref                # one rank's share of the work, alone on one GPU (N = 1 line)
         else:
             out["value_1gpu_same_workload"] = ref
-            out["strong_scaling_speedup"] = out["value"] / ref if ref else None
+            out["strong_scaling_speedup"] = out["value"] / ref if ref and out["value"] else None
     if args.workload is None and not args.no_secondary:
         # BASELINE configs[3] over the same ranks: strong scaling.  A secondary line must not take the headline down,
         # and the ranks must leave it TOGETHER: whatever one rank caught, all of them agree on before going on.

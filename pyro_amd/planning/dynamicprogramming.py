@@ -105,8 +105,8 @@ class DynamicProgramming:
           'linear'  -- every tier (default);
           'nearest' -- RegularGridInterpolator(method='nearest'): the TABLE tier implements it (the interval and fraction of
                        every cell are fixed when the tables are packed).  Assigning it rebuilds the engine on the table
-                       tier from the reference's look-up tables and restarts from the terminal cost, as setting it before
-                       the first sweep does in the reference; a sharded engine raises;
+                       tier from the reference's look-up tables and carries the current cost-to-go (J, J_next, pi, k) over:
+                       the new interpolant applies from the next sweep on, as in the reference; a sharded engine raises;
           'bicubic' -- only as the class DynamicProgramming2DRectBivariateSpline;
         anything else ('cubic', 'slinear', 'quintic', 'pchip') raises instead of silently computing with another interpolant."""
         if value not in self._INTERPOLATIONS:
@@ -241,11 +241,14 @@ class DynamicProgramming:
         """A new engine for the current interpol_method, carrying the current cost-to-go over: the reference builds its
         interpolant from J_next with the CURRENT method at the start of every sweep (dynamicprogramming.py:186-189), so a
         change of method between sweeps applies from the next sweep on."""
-        J = self.J.copy()
+        J, pi = self.J.copy(), self.pi.copy()
+        J_next = self.J_next.copy()         # (the fresh handle's second buffer is zero: keep the host copy until the next sweep)
         self._p.close()
         self.__dict__.pop("_G", None)
         self._make_engine()
         self.J = J
+        self._host["pi"] = pi
+        self._host["J_next"] = J_next
 
     # ------------------------------------------------------------------ reference API
     def evaluate_terminal_cost(self):

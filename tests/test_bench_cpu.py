@@ -101,7 +101,7 @@ def test_counters_are_tied_to_the_kernel_name():
     # C5 / C5d: the sparse patch walk and the dense patch walk, not set-up's slowest candidate
     assert bench.norm_kernel(ctr["c5"]["kernel"]) == "k_sweep64<3,unsignedchar,true,true,true>"
     assert bench.norm_kernel(ctr["c5d"]["kernel"]) == "k_sweep64<3,unsignedchar,true,true,false>"
-    c = dict(ctr["c5"], kernel_path="path=exact-f64v2 mapping=patch8x8 sparse=1")
+    c = dict(ctr["c5"], kernel_path="path=exact-f64v2 mapping=patch8x8 sparse=1", csrc_hash=bench.kernel_source_hash())
     good = "path=exact-f64v2 kernel=k_sweep64<3,unsignedchar,true,true,true> mapping=patch8x8 off32=1 sparse=1 inbox=0.1 note="
     kept, err = bench.check_counters(c, good)
     assert kept and err is None
@@ -109,3 +109,30 @@ def test_counters_are_tied_to_the_kernel_name():
     assert not kept and "kernel:" in err
     kept, err = bench.check_counters(c, good.replace(" kernel=k_sweep64<3,unsignedchar,true,true,true>", ""))
     assert not kept and "not reported" in err
+
+
+def test_counters_are_tied_to_the_kernel_sources(tmp_path, monkeypatch):
+    """a kernel BODY edited under the same template name must invalidate the committed PMC
+    passes.  The digest stores a hash of pyro_amd/csrc/* + include/pyrovi.h; check_counters recomputes it."""
+    import shutil
+    bench = _bench()
+    from pyro_amd import _build
+    h0 = bench.kernel_source_hash()
+    assert len(h0) == 16 and h0 == bench.kernel_source_hash()
+    desc = "path=lean kernel=k_sweep_lean4<2,unsignedchar> tile=19x51 win=1 note="
+    c = {"kernel": "void k_sweep_lean4<2, unsigned char>(DevP, Lean4P)", "kernel_path": "path=lean tile=19x51 win=1",
+         "source": "profiles/x.json", "csrc_hash": h0, "hbm_bytes_per_launch": 1.0}
+    kept, err = bench.check_counters(c, desc)
+    assert kept and err is None
+    kept, err = bench.check_counters(dict(c, csrc_hash=None), desc)          # counters from before the hash existed
+    assert not kept and "not recorded" in err
+    # edit a kernel body in a copy of the tree: same kernel name, same variant tokens -- the counters must go
+    csrc = tmp_path / "csrc"
+    shutil.copytree(_build.CSRC, csrc)
+    with open(csrc / "sweep_lean4.inc", "a") as f:
+        f.write("// edited\n")
+    monkeypatch.setattr(_build, "CSRC", str(csrc))
+    h1 = bench.kernel_source_hash()
+    assert h1 != h0
+    kept, err = bench.check_counters(c, desc)
+    assert not kept and "sources:" in err and h0 in err and h1 in err

@@ -49,7 +49,11 @@ try:
     path = [l for l in open('$OUT/p1.log') if l.startswith('nodes ')][-1].split(' ', 2)[2].strip()
 except Exception as e:
     print('no kernel path in the log:', e)
-json.dump({"workload": "$W", "kernel_path": path, "kernels": keep}, open('/root/repo/gpurun_out/counters_$W.json', 'w'), indent=1)
+import sys
+sys.path.insert(0, '/root/repo')
+import bench
+# (the sources of the library the passes ran on: bench.py drops the counters once a kernel file changes)
+json.dump({"workload": "$W", "kernel_path": path, "csrc_hash": bench.kernel_source_hash(), "kernels": keep}, open('/root/repo/gpurun_out/counters_$W.json', 'w'), indent=1)
 for k, v in keep.items():
     if 'sweep' in k: print(k, json.dumps(v))
 PY
