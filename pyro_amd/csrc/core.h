@@ -492,7 +492,10 @@ __device__ __forceinline__ int f32_key(float f) {
 __device__ __forceinline__ float f32_unkey(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_imax_step(int v) {
-    return max(v, __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false));
+    // (`old` = the identity of the maximum: lanes the control leaves without a source take INT_MIN and keep their own value, and
+    //  the compiler folds move + maximum into ONE v_max_i32_dpp -- with old = v it kept v_mov_b32_dpp + v_max_i32: 36 instead of
+    //  18 vector instructions for the three statistics of a wave)
+    return max(v, __builtin_amdgcn_update_dpp((int)0x80000000, v, CTRL, ROW_MASK, 0xf, false));
 }
 __device__ __forceinline__ int wave_max_key(int v) {
     v = dpp_imax_step<0x111, 0xf>(v);
@@ -503,12 +506,27 @@ __device__ __forceinline__ int wave_max_key(int v) {
     v = dpp_imax_step<0x143, 0xc>(v);
     return __builtin_amdgcn_readlane(v, 63);
 }
+// three at once, step by step: the steps of one reduction depend on each other through a DPP read (two wait states behind the
+// write), three independent chains fill each other's slots (the sequential form compiled to 18 v_max_i32_dpp with an s_nop
+// behind each)
+__device__ __forceinline__ void wave_max_key3(int& a, int& b, int& c) {
+#define PVI_STEP3(CTRL, MASK)          \
+    a = dpp_imax_step<CTRL, MASK>(a);  \
+    b = dpp_imax_step<CTRL, MASK>(b);  \
+    c = dpp_imax_step<CTRL, MASK>(c);
+    PVI_STEP3(0x111, 0xf) PVI_STEP3(0x112, 0xf) PVI_STEP3(0x114, 0xf) PVI_STEP3(0x118, 0xf) PVI_STEP3(0x142, 0xa) PVI_STEP3(0x143, 0xc)
+#undef PVI_STEP3
+    a = __builtin_amdgcn_readlane(a, 63);
+    b = __builtin_amdgcn_readlane(b, 63);
+    c = __builtin_amdgcn_readlane(c, 63);
+}
 // `red`: 48 ints of LDS scratch.  WAIT: the publishing threads consume the atomics' return values, i.e. they have been
 // performed when the function returns (needed by the in-kernel ticket of sweep_finish); without it they are fire and forget.
 template <bool WAIT = true>
 __device__ inline void block_stats_f32_at(int* red, float j, float dmax, float ndmin, unsigned long long* slot) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    const int kj = wave_max_key(f32_key(j)), kd = wave_max_key(f32_key(dmax)), kn = wave_max_key(f32_key(ndmin));
+    int kj = f32_key(j), kd = f32_key(dmax), kn = f32_key(ndmin);
+    wave_max_key3(kj, kd, kn);
     if (lane == 0) {
         red[wave] = kj;
         red[16 + wave] = kd;

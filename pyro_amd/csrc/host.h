@@ -95,6 +95,8 @@ struct Lean4P {
     int* summary;           // [0] max window rows (pair planes x p1 x j2), [1] longest row, [3] error bits, [4] max pair planes,
                             // [7] some node's cell range does not fit `box`
     const char4* box;       // per owned node: the velocity cells its actions reach, relative to (iv0, iv1) -- set-up only
+    const unsigned* vmask;  // [owned] bit a: the cell of (node, action a) lands in the box -- the reference's float64 test, decided at
+                            // set-up (A <= 32; NULL: the sweep clamps and compares the cell index instead, sweep_lean4.inc L4_CLAMP)
     float* jlo;             // [owned] PVI_FLAG_F32_FEEDBACK: rounding residual of the stored J of every node (NULL: plain storage)
     double alpha64;         // ... and the discount factor of the launch unrounded (the sweep's own `alpha` is its float32 value)
 };

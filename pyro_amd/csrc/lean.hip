@@ -320,7 +320,7 @@ static int lean_try(pvi_problem* h, int tv0_t, int tv1_t, int lds_budget_floats)
 // =====================================================================================================================
 
 template <typename PI_T>
-static int launch_lean4_t(pvi_problem* h, const float* Jin, float* Jout, float alpha, hipStream_t st, SweepCtl sc, bool probe = false) {
+static int launch_lean4_t(pvi_problem* h, const float* Jin, float* Jout, float alpha, hipStream_t st, SweepCtl sc) {
     const Lean4P& L = h->L4;
     sc.nblocks = h->lean4_grid;
     sc.split_finish = 1;
@@ -333,16 +333,28 @@ static int launch_lean4_t(pvi_problem* h, const float* Jin, float* Jout, float a
         hipLaunchKernelGGL(kfn, dim3(h->lean4_grid), dim3(h->lean4_block), h->lean4_lds, st, h->P, L, Jin, Jout, pi, alpha, \
                            sc, (const float*)L.ptab, (const Lean4Tile*)h->lean4_tiles);                                \
     }
-#define L4(DYN)                                   \
-    if (probe)                                    \
-        L4K((k_sweep_lean4_probe<DYN, PI_T>))     \
-    else if (L.jlo) {                             \
-        set_kname(h, "k_sweep_lean4fb", (int)DYN, tname<PI_T>()); \
-        L4K((k_sweep_lean4fb<DYN, PI_T>))         \
-    } else {                                      \
-        set_kname(h, "k_sweep_lean4", (int)DYN, tname<PI_T>()); \
-        L4K((k_sweep_lean4<DYN, PI_T>))           \
+#define L4V(DYN, GXN, VM)                                                              \
+    if (L.jlo) {                                                                       \
+        set_kname(h, "k_sweep_lean4fb", (int)DYN, tname<PI_T>(), (bool)GXN, (bool)VM); \
+        L4K((k_sweep_lean4fb<DYN, PI_T, GXN, VM>))                                     \
+    } else {                                                                           \
+        set_kname(h, "k_sweep_lean4", (int)DYN, tname<PI_T>(), (bool)GXN, (bool)VM);   \
+        L4K((k_sweep_lean4<DYN, PI_T, GXN, VM>))                                       \
     }
+// (validity bits exist for A <= 32 only: no such instantiation with 16-bit action ids)
+#define L4G(DYN, GXN)                             \
+    if constexpr (sizeof(PI_T) == 1) {            \
+        if (L.vmask)                              \
+            L4V(DYN, GXN, true)                   \
+        else                                      \
+            L4V(DYN, GXN, false)                  \
+    } else                                        \
+        L4V(DYN, GXN, false)
+#define L4(DYN)            \
+    if (L.gx)              \
+        L4G(DYN, true)     \
+    else                   \
+        L4G(DYN, false)
     switch (h->d.dynamics_id) {
         case PVI_DYN_CARTPOLE: L4(PVI_DYN_CARTPOLE) break;
         case PVI_DYN_NODE_2x1: L4(PVI_DYN_NODE_2x1) break;
@@ -350,6 +362,8 @@ static int launch_lean4_t(pvi_problem* h, const float* Jin, float* Jout, float a
         default: L4(PVI_DYN_TWOLINK) break;
     }
 #undef L4
+#undef L4G
+#undef L4V
 #undef L4K
     hipLaunchKernelGGL(k_sweep_finish, 1, STAT_SHARDS, 0, st, sc);
     HIPCHK(hipGetLastError());
@@ -399,23 +413,28 @@ static void lean4_row_tiles(const std::vector<int2>& pt0, int i0, int V0, int V1
 // XCD x sweeps ITS chunk of axis 1 for every owned row of axis 0 in turn (bands of the row's tile list outermost, so that
 // the planes of three consecutive axis-0 rows over the chunk fit its L2): the axis-0 planes a tile gathers from were
 // fetched for the previous row a moment ago.  Lists are interleaved into physical order and padded to equal length.
-static void lean4_schedule(int R, int N1, int ntr, int nbands, std::vector<unsigned>& out, int r0 = 0) {
+static void lean4_schedule(int R, int N1, int ntr, int nbands, std::vector<unsigned>& out, int r0 = 0, const int* cnt = nullptr) {
     // Round 4: an XCD's share of a row is a contiguous EIGHTH of the row's (axis-1 index, tile) list -- not a whole number of
     // axis-1 indices.  Splitting by index gave 13, 13, 12, 13, ... of C3's 101 to the XCDs: the lists were padded to the
     // longest with empty workgroups and five XCDs idled 8 % of every row (the plain order, which balances by construction,
     // ran 2.90 ms against 3.10 ms with the same tiles; profiles/r04_launch_order.log).
+    // Round 5: `cnt[r]` = the tiles row r really has.  The tile lists of the rows differ in length (a corner step that falls on a
+    // level lands a row earlier or later: C3 21.06 tiles per plane on average, 23 at most) and tile ids are dense over the
+    // LONGEST list; rounds 3-4 launched a workgroup for every id -- 8.4 % of C3's 235 128 workgroups loaded a descriptor that said
+    // "nothing here" and left.  They are no longer scheduled.
     std::vector<std::vector<unsigned>> lists(8);
+    std::vector<unsigned> row;
     for (int b = 0; b < nbands; ++b) {
-        const int k0 = (int)((long long)ntr * b / nbands), k1 = (int)((long long)ntr * (b + 1) / nbands), kb = k1 - k0;
-        const long long E = (long long)N1 * kb;  // entries of one row of axis 0 in this band: i1-major, tile-minor
-        for (int r = r0; r < r0 + R; ++r)  // (r0, R: the rows of a timed candidate; the whole slab otherwise)
-            for (int x = 0; x < 8; ++x) {
-                const long long e0 = E * x / 8, e1 = E * (x + 1) / 8;
-                for (long long e = e0; e < e1; ++e) {
-                    const int i1 = (int)(e / kb), k = k0 + (int)(e - (long long)i1 * kb);
-                    lists[x].push_back((unsigned)((long long)(r * N1 + i1) * ntr + k));
-                }
-            }
+        const int k0 = (int)((long long)ntr * b / nbands), k1 = (int)((long long)ntr * (b + 1) / nbands);
+        for (int r = r0; r < r0 + R; ++r) {  // (r0, R: the rows of a timed candidate; the whole slab otherwise)
+            const int kend = cnt ? std::min(k1, cnt[r]) : k1;
+            row.clear();                     // entries of one row of axis 0 in this band: i1-major, tile-minor
+            for (int i1 = 0; i1 < N1; ++i1)
+                for (int k = k0; k < kend; ++k) row.push_back((unsigned)((long long)(r * N1 + i1) * ntr + k));
+            const long long E = (long long)row.size();
+            for (int x = 0; x < 8; ++x)
+                for (long long e = E * x / 8; e < E * (x + 1) / 8; ++e) lists[x].push_back(row[(size_t)e]);
+        }
     }
     size_t mx = 0;
     for (auto& l : lists) mx = std::max(mx, l.size());
@@ -523,10 +542,12 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
     std::vector<unsigned> sched;
     // (sub_rows: a timed candidate sweeps a few rows of axis 0 from the middle of the slab -- the tiling is the same for every
     //  row, so a tenth of the grid ranks the candidates at a tenth of the cost; window boxes and pitch are those of the slab)
+    std::vector<int> cnt((size_t)rows);
+    for (int r = 0; r < rows; ++r) cnt[(size_t)r] = (int)per[(size_t)r].size();
     if (sub_rows > 0 && sub_rows < rows && !ovr_is("NO_XCD", 1))
-        lean4_schedule(sub_rows, P.dim[1], ntr, nbands, sched, sub_r0);
+        lean4_schedule(sub_rows, P.dim[1], ntr, nbands, sched, sub_r0, cnt.data());
     else
-        lean4_schedule(rows, P.dim[1], ntr, ovr_is("NO_XCD", 1) ? 1 : nbands, sched);
+        lean4_schedule(rows, P.dim[1], ntr, ovr_is("NO_XCD", 1) ? 1 : nbands, sched, 0, cnt.data());
     if (ovr_is("NO_XCD", 1)) {  // plain order (experiments, tests): tile ids ascending
         sched.resize((size_t)ntiles);
         for (long long t = 0; t < ntiles; ++t) sched[(size_t)t] = (unsigned)t;
@@ -580,7 +601,8 @@ static int lean4_setup(pvi_problem* h) {
     Lean4P& L = h->L4;
     memset(&L, 0, sizeof(L));
     h->lean4_ok = false;
-    if (!h->fast_ok || P.dof != 2 || ovr("NO_LEAN") || ovr_is("WIN", 0) || h->stored >= 0x7fffffffLL) return PVI_OK;
+    // (fewer than 2^30 stored nodes: byte offsets into J fit 32 bits -- sweep_lean4.inc ld32; C4 on one GPU has 5.2e8)
+    if (!h->fast_ok || P.dof != 2 || ovr("NO_LEAN") || ovr_is("WIN", 0) || h->stored >= (1LL << 30)) return PVI_OK;
     if (!(h->own_J || (h->d.flags & PVI_FLAG_EXT_J_SLACK))) return PVI_OK;  // the 16-byte window loads may run 12 bytes past a row
     if (P.strd[0] * 16 >= (1LL << 31)) return PVI_OK;  // the window fill addresses planes by 32-bit byte offsets from the window origin
     const int rows = P.row_end - P.row_begin;
@@ -601,6 +623,11 @@ static int lean4_setup(pvi_problem* h) {
     if ((rc = dev_alloc(h, (size_t)2 * h->owned, &tsp_node))) return rc;
     L.pt0 = pt0;
     L.pt1 = pt1;
+    if (P.A <= 32 && !ovr_is("VMASK", 0)) {  // validity of every cell, one bit per action (sweep_lean4.inc L4_MASK)
+        unsigned* vm = nullptr;
+        if ((rc = dev_alloc(h, (size_t)h->owned, &vm))) return rc;
+        L.vmask = vm;
+    }
     // g_x: a sum of per-axis terms when Q is diagonal (then no per-node array); TABLES=0 keeps the per-node arrays
     const bool want_tables = !ovr_is("TABLES", 0);
     bool diag = want_tables;
@@ -678,7 +705,7 @@ static int lean4_setup(pvi_problem* h) {
     auto give_up = [&](const char* why) {
         snprintf(h->lean_why, sizeof(h->lean_why), "%s", why);
         dev_release(h, L.flag); dev_release(h, pt0); dev_release(h, pt1); dev_release(h, L.summary); dev_release(h, L.ptab);
-        dev_release(h, tsp_node); dev_release(h, gx_node);
+        dev_release(h, tsp_node); dev_release(h, gx_node); dev_release(h, (void*)L.vmask);
         if (L.tsp && L.tsp != tsp_node) dev_release(h, (void*)L.tsp);
         if (L.tlist) dev_release(h, (void*)L.tlist);
         if (L.win) dev_release(h, L.win);
@@ -839,8 +866,8 @@ static int lean4_setup(pvi_problem* h) {
     auto probe_sweep = [&]() -> int {
         hipLaunchKernelGGL(k_reset_stats, 1, STAT_WORDS, 0, h->stream, h->slots, STAT_WORDS);
         hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, h->stream, h->ctrl);
-        return h->pi_size == 1 ? launch_lean4_t<unsigned char>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc, true)
-                               : launch_lean4_t<unsigned short>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc, true);
+        return h->pi_size == 1 ? launch_lean4_t<unsigned char>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc)
+                               : launch_lean4_t<unsigned short>(h, (const float*)h->J[h->cur], (float*)h->J[h->cur ^ 1], 1.f, h->stream, sc);
     };
     // one warm-up and five timed sweeps of the tiling lean4_try has just set up: the median, or (hopeless) the warm-up's time
     auto time_reps = [&](float& ms, bool may_give_up) -> int {

@@ -1328,6 +1328,7 @@ static const char* const OVERRIDE_KEYS[] = {
     "XCD3",        // 0: float32 3-D sweep in plain block order instead of an eighth of axis 1 per XCD
     "JWIN",        // 0: the register-table sweeps gather J from memory instead of the workgroup's LDS window
     "REGTAB",      // 0: the multi-sweep launch of 2-D grids recomputes the per-action cells every sweep (fence-based barrier)
+    "VMASK",       // 0: the 4-D float32 window sweep clamps and compares cell indices instead of reading set-up's validity bits
     "MULTI",       // 0: one launch per sweep also where a batch could run as ONE multi-sweep launch (k_sweep64m)
 };
 static std::vector<std::pair<std::string, std::string>> g_overrides;

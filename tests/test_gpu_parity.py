@@ -753,7 +753,8 @@ _FULL = {
 
 @pytest.mark.parametrize("name", list(_FULL))
 def test_full_size_sampled_against_c_oracle(name):
-    """BASELINE configs[2], [3] (on one GPU) and [4] at FULL size: J_{k+1} = T J_k for k in {1, 3} is compared with
+    """BASELINE configs[2], [3] (on one GPU) and [4] at FULL size: J_{k+1} = T J_k for k in {1, 3} and at depth (k = 200
+    for the float32 cart-pole grids, 20 for the float64 two-link arm) is compared with
     the oracle's C twin on >= 2e5 sampled nodes, starting from the GPU's own J_k (so every production-size code
     path -- 16-byte window DMA, tuned tile shapes, XCD remap with ~1e6 tiles, int32 offsets at 5e8 nodes -- meets
     the oracle), pi by the float64 Q-regret of the GPU's action."""
@@ -784,7 +785,11 @@ def test_full_size_sampled_against_c_oracle(name):
     assert sum(b - a for a, b in blocks) >= 200000
     h.terminal_cost()
     done = 0
-    for k in (1, 3):
+    # k = 1, 3: a cost bowl with INF cliffs; then a DEVELOPED cost-to-go (VERDICT r4 weak #1 ii): depth 200 for the cart-pole
+    # grids (the frontier of finite J has crossed the grid, the interpolant is smooth and steep in turns), 20 for the two-link
+    # arm (float64, 15-40 ms per sweep) -- one backup of the GPU's own deep J against the C twin on the same sampled nodes
+    deep = 200 if f32 else 20
+    for k in (1, 3, deep):
         h.sweep(k - done, 1.0, -1.0)
         Jk = h.get_J()
         stats, _ = h.sweep(1, 1.0, -1.0)

@@ -1,0 +1,14 @@
+#!/bin/bash
+cd /root/repo; mkdir -p gpurun_out; L=gpurun_out/r05_c.log; : > $L
+for rep in 1 2 3; do
+ for w in c3 c4; do
+  n=200; [ $w = c4 ] && n=40
+  for ov in "" "VMASK=0"; do
+   echo "== $w [$ov]" >> $L
+   timeout 300 python tools/tools_time.py $w $n $ov 2>&1 | grep -E "TIME" | cut -c1-120 >> $L
+  done
+  echo "== $w [base]" >> $L
+  PYROVI_LIB=/root/repo/pyro_amd/libpyrovi_base.so timeout 300 python tools/tools_time.py $w $n 2>&1 | grep -E "TIME" | cut -c1-120 >> $L
+ done
+done
+paste - - < $L | awk '{print $2,$3,$(NF-1)}'
