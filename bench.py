@@ -236,7 +236,7 @@ def check_counters(ctr, desc):
     line says why, loudly."""
     if not ctr:
         return {}, None
-    keys = ("path", "tile", "choice", "win", "tables", "stage", "mapping", "sparse", "npt", "lsplit")
+    keys = ("path", "tile", "choice", "win", "tables", "stage", "vmask", "mapping", "sparse", "npt", "lsplit")
     a = dict(t.split("=", 1) for t in str(ctr.get("kernel_path", "")).split() if "=" in t)
     b = dict(t.split("=", 1) for t in desc.split() if "=" in t)
     diff = []

@@ -718,7 +718,14 @@ static int lean4_setup(pvi_problem* h) {
     // ---- the axes the displacement does not depend on -> compact table ---------------------------------------------------
     const long long full[4] = {P.plane, (long long)P.dim[2] * P.dim[3], P.dim[3], 1};
     int inv = 0;
-    if (want_tables) {
+    // A closed form knows which state axes its acceleration depends on: the cart-pole's is a function of (theta, dtheta) and the
+    // input only (cartpole.py:369-437: H, C, g depend on q[1] and dq[1]; no damping term) -- axes 0 and 2 drop out.  The kernel
+    // that FINDS the invariant axes (every node against the node at index 0 of each axis: 66 GB of cache traffic, 93 ms of C4's
+    // create) runs for the dynamics that do not declare them, and with TABLES=2 (the variants test holds the declaration to it).
+    const int declared = h->d.dynamics_id == PVI_DYN_CARTPOLE ? 0x5 : -1;
+    if (want_tables && declared >= 0 && !ovr_is("TABLES", 2)) {
+        inv = declared;
+    } else if (want_tables) {
         const int all = 0xf;
         HIPCHK(hipMemcpyAsync(L.summary + 6, &all, sizeof(int), hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(k_lean4_invariance, grid_for(h->owned), 256, 0, h->stream, P, L, (const float2*)tsp_node);

@@ -100,9 +100,16 @@ class MechanicalSystem(system.ContinuousDynamicSystem):
         return self._NODE_IDS[key], ()
 
     def device_trig(self, x_level):
-        """(a0 [N, dof], Bn [Nq, dof, m]) over the grid levels, C order (last axis fastest).  O(N) calls of the model
-        terms; large grids are split over the host cores (pyro_amd.planning.discretizer.host_parallel_rows)."""
+        """(a0 [N, dof], Bn [Nq, dof, m]) over the grid levels, C order (last axis fastest).  A class whose STOCK model has
+        a vectorised form (`_trig_vectorized`: NumPy array arithmetic over whole axes -- MountainCar, the two-link family
+        incl. Acrobot) uses it: no Python call per node.  Any other system: O(N) calls of its own model terms; large grids
+        are split over the host cores (pyro_amd.planning.discretizer.host_parallel_rows)."""
         from pyro_amd.planning.discretizer import host_parallel_rows
+        vec = getattr(self, "_trig_vectorized", None)
+        if vec is not None:
+            out = vec(x_level)
+            if out is not None:
+                return out
         dof = self.dof
         nq = int(np.prod([len(l) for l in x_level[:dof]]))
         nv = int(np.prod([len(l) for l in x_level[dof:]]))

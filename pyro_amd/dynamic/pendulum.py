@@ -126,6 +126,46 @@ class _TwoLinkTerms:
         return np.sin(q0), np.cos(q1), np.sin(q1), np.sin(q0[:, None] + q1[None, :])
 
 
+    # ---- per-node tables of the generic mechanical tier (a subclass with another actuator matrix: Acrobot) by array
+    # arithmetic over the grid axes instead of one Python call per node (round 5)
+    def _trig_vectorized(self, x_level):
+        """a0 = inv(H)(-C dq - g - d), Bn = inv(H) B over the 4-D grid with H, C, g, d of this class on whole axes; inv(H)
+        by adjugate / determinant like the closed-form kernel (the per-node loop calls LAPACK: an ulp apart, the known
+        limit of DESIGN.md section 2).  None when a model term other than B is overridden."""
+        owner = next((c for c in type(self).__mro__ if c.__dict__.get("_STOCK_OWNER") is c), None)
+        if owner is None or not self.stock_model(owner, tuple(t for t in self._MODEL_TERMS if t != "B")):
+            return None
+        q0, q1, v0, v1 = (np.asarray(l, dtype=float) for l in x_level)
+        c2, s2 = np.cos(q1), np.sin(q1)
+        H01 = self.m2 * self.lc2 ** 2 + self.m2 * self.l1 * self.lc2 * c2 + self.I2
+        H00 = (self.m1 * self.lc1 ** 2 + self.I1
+               + self.m2 * (self.l1 ** 2 + self.lc2 ** 2 + 2 * self.l1 * self.lc2 * c2) + self.I2)
+        H11 = self.m2 * self.lc2 ** 2 + self.I2
+        det = H00 * H11 - H01 * H01
+        i00, i01, i11 = H11 / det, -H01 / det, H00 / det                   # [n1]
+        h = self.m2 * self.l1 * self.lc2 * s2                              # [n1]
+        g1 = (self.m1 * self.lc1 + self.m2 * self.l1) * self.gravity
+        g2 = self.m2 * self.lc2 * self.gravity
+        s1 = np.sin(q0)[:, None]
+        s12 = np.sin(q0[:, None] + q1[None, :])
+        G0, G1 = -g1 * s1 - g2 * s12, -g2 * s12                            # [n0, n1]
+        V0, V1 = v0[:, None], v1[None, :]                                  # [n2, 1], [1, n3]
+        hh = h[None, :, None, None]
+        # C dq = [-h dq1 dq0 - h (dq0 + dq1) dq1, h dq0 dq0]
+        Cdq0 = (-hh * V1) * V0 + (-hh * (V0 + V1)) * V1
+        Cdq1 = (hh * V0) * V0 + 0.0 * V1
+        r0 = ((0.0 - Cdq0) - G0[:, :, None, None]) - self.d1 * V0
+        r1 = ((0.0 - Cdq1) - G1[:, :, None, None]) - self.d2 * V1
+        I00, I01, I11 = (a[None, :, None, None] for a in (i00, i01, i11))
+        a0 = np.stack([I00 * r0 + I01 * r1, I01 * r0 + I11 * r1], axis=-1)
+        B = np.asarray(self.B(np.zeros(2)), dtype=float)                   # (constant actuator matrices only)
+        if not all(np.array_equal(np.asarray(self.B(np.array([a, b]))), B) for a, b in ((0.3, -1.1), (2.0, 0.7))):
+            return None
+        inv = np.stack([np.stack([i00, i01], -1), np.stack([i01, i11], -1)], -2)   # [n1, 2, 2]
+        Bn = np.broadcast_to((inv @ B)[None], (len(q0),) + (len(q1), 2, B.shape[1])).reshape(-1, 2, B.shape[1])
+        return a0.reshape(-1, 2), np.ascontiguousarray(Bn)
+
+
 class DoublePendulum(_TwoLinkTerms, mechanical.MechanicalSystem):
     """Two unit links, torques at both joints (pendulum.py:340-378)."""
 
@@ -148,8 +188,8 @@ DoublePendulum._STOCK_OWNER = DoublePendulum
 
 class Acrobot(DoublePendulum):
     """Double pendulum with a single motor at the elbow (pendulum.py:699-735): B = [[0], [1]], |tau| <= 10.
-    Under-actuated, so it has no closed-form kernel; value iteration runs through the per-node tables of
-    MechanicalSystem.device_trig (PVI_DYN_NODE_2x1)."""
+    Under-actuated: value iteration runs through the per-node tables of the generic mechanical tier (PVI_DYN_NODE_2x1),
+    filled by array arithmetic over the grid axes (_TwoLinkTerms._trig_vectorized) -- no Python call per node."""
 
     def __init__(self):
         mechanical.MechanicalSystem.__init__(self, dof=2, actuators=1)

@@ -412,10 +412,13 @@ def test_f32_kernel_variants_agree(name, variants):
                      # round 4: other bands of the launch order (the persistent and quad-window kernels of this round were
                      # measured, lost and removed: DESIGN.md 4.2b)
                      ("lean_bands2", {"PVI_WIN": "1", "PVI_BANDS": "2"}),
+                     # round 5: the invariant axes of the displacement FOUND by the kernel instead of declared by the closed form
+                     # (TABLES=2), cell validity by clamp-and-compare instead of set-up's bit per action (VMASK=0)
+                     ("lean_tab2", {"PVI_WIN": "1", "PVI_TABLES": "2"}), ("lean_clamp", {"PVI_WIN": "1", "PVI_VMASK": "0"}),
                      ("fast", {"PVI_NO_LEAN": "1"}),
                      ("exact32", {"PVI_NO_FAST": "1"})]:
         for k in ("PVI_LSPLIT", "PVI_NO_LEAN", "PVI_NO_FAST", "PVI_NPT", "PVI_WIN", "PVI_TABLES", "PVI_NO_XCD", "PVI_TV0", "PVI_TV1",
-                  "PVI_BANDS"):
+                  "PVI_BANDS", "PVI_VMASK"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -430,7 +433,7 @@ def test_f32_kernel_variants_agree(name, variants):
         tok = dict(t.split("=", 1) for t in outs["lean"][2].split() if "=" in t)
         assert tok.get("choice", "-") != "-", outs["lean"][2]
         for k in ("PVI_LSPLIT", "PVI_NO_LEAN", "PVI_NO_FAST", "PVI_NPT", "PVI_WIN", "PVI_TABLES", "PVI_NO_XCD", "PVI_TV0", "PVI_TV1",
-                  "PVI_BANDS"):
+                  "PVI_BANDS", "PVI_VMASK"):
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setenv("PVI_L4PIN", tok["choice"])
         h = native_problem(p, dtype="float32")
@@ -464,10 +467,13 @@ def test_f32_kernel_variants_agree(name, variants):
     if four_d:
         # ... while the round-3 kernel splits every operand into integer + fraction in float64 at set-up and takes the arm too.
         # Whatever the coefficient tables, the launch order or the tile shape: the same bits.
-        for tag in ("lean", "lean_win1", "lean_tab0", "lean_tab1", "lean_noxcd", "lean_shape", "lean_bands2"):
+        for tag in ("lean", "lean_win1", "lean_tab0", "lean_tab1", "lean_noxcd", "lean_shape", "lean_bands2", "lean_tab2", "lean_clamp"):
             assert path_of(outs[tag][2]) == "path=lean" and "win=1" in outs[tag][2], (tag, outs[tag][2])
             assert np.array_equal(outs[tag][0], outs["lean_win1"][0]) and np.array_equal(outs[tag][1], outs["lean_win1"][1]), (tag, outs[tag][2])
         assert "tables=0" in outs["lean_tab0"][2] and "gx=node" in outs["lean_tab0"][2], outs["lean_tab0"][2]
+        tabs = lambda d: dict(t.split("=", 1) for t in d.split() if "=" in t)["tables"]
+        assert tabs(outs["lean_tab2"][2]) == tabs(outs["lean"][2]), (outs["lean_tab2"][2], outs["lean"][2])   # declared == found
+        assert "vmask=1" in outs["lean"][2] and "vmask=0" in outs["lean_clamp"][2], (outs["lean"][2], outs["lean_clamp"][2])
         assert "tile=3x" in outs["lean_shape"][2], outs["lean_shape"][2]       # (columns are evened out over the tiles)
         assert "kernel=k_sweep_lean4<" in outs["lean"][2], outs["lean"][2]
         # its split displacement is the more accurate float32 form: at least as close to the float64 oracle as the others
