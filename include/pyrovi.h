@@ -247,6 +247,11 @@ int pvi_plan_plane_tiles(int32_t V0, int32_t V1, const int32_t* corner0, int32_t
    ((r * n1 + i1) * tiles_per_plane + t) of physical block k, 0xffffffff = padding; block k runs on XCD k % 8, XCD x sweeps
    its chunk of axis 1 for every row in turn.  Returns the number of blocks (a multiple of 8), writing at most `max_blocks`. */
 int64_t pvi_plan_schedule(int32_t rows, int32_t n1, int32_t tiles_per_plane, int32_t bands, uint32_t* out, int64_t max_blocks);
+/* ... with tile lists of different lengths per row of axis 0 (a corner step that falls on a level lands a row earlier or later):
+   counts[r] <= tiles_per_plane = the tiles row r really has; ids t >= counts[r] are NOT scheduled (rounds 3-4 launched a
+   workgroup for each of them: 8.4 % of the workgroups of BASELINE configs[2]).  counts == NULL: every row has tiles_per_plane. */
+int64_t pvi_plan_schedule_rows(int32_t rows, int32_t n1, int32_t tiles_per_plane, int32_t bands, const int32_t* counts, uint32_t* out,
+                               int64_t max_blocks);
 
 /* ---- tables (tier B and reference attributes) ---------------------------------------------- */
 /* compute_xnext_table / compute_action_set_table / compute_cost_lookuptable for rows

@@ -84,6 +84,7 @@ SYMBOLS = {
     "pvi_plan_plane_tiles": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32,
                                        C.POINTER(C.c_int32), C.c_int32]),
     "pvi_plan_schedule": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.c_int64]),
+    "pvi_plan_schedule_rows": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int64]),
     "pvi_build_tables": (C.c_int, [_h, C.c_int32, C.c_int32, _dp, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), _dp]),
     "pvi_set_tables": (C.c_int, [_h, _dp, _dp, C.POINTER(C.c_uint8)]),
     "pvi_policy_tables": (C.c_int, [_h, C.c_int32, _dp, _dp, _dp, C.POINTER(C.c_uint8), _dp]),
@@ -486,6 +487,18 @@ def plan_schedule(rows, n1, tiles_per_plane, bands):
         check(int(n))
     out = np.zeros(n, dtype=np.uint32)
     lib().pvi_plan_schedule(int(rows), int(n1), int(tiles_per_plane), int(bands), out.ctypes.data_as(C.POINTER(C.c_uint32)), n)
+    return out
+
+
+def plan_schedule_rows(n1, tiles_per_plane, bands, counts):
+    """Host-only diagnostic (pvi_plan_schedule_rows): the launch order when row r of axis 0 has counts[r] tiles."""
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    cp = counts.ctypes.data_as(C.POINTER(C.c_int32))
+    n = lib().pvi_plan_schedule_rows(len(counts), int(n1), int(tiles_per_plane), int(bands), cp, None, 0)
+    if n < 0:
+        check(int(n))
+    out = np.zeros(n, dtype=np.uint32)
+    lib().pvi_plan_schedule_rows(len(counts), int(n1), int(tiles_per_plane), int(bands), cp, out.ctypes.data_as(C.POINTER(C.c_uint32)), n)
     return out
 
 

@@ -596,6 +596,20 @@ extern "C" int64_t pvi_plan_schedule(int32_t rows, int32_t n1, int32_t tiles_per
     return (int64_t)sched.size();
 }
 
+extern "C" int64_t pvi_plan_schedule_rows(int32_t rows, int32_t n1, int32_t tiles_per_plane, int32_t bands, const int32_t* counts,
+                                          uint32_t* out, int64_t max_blocks) {
+    if (rows < 1 || n1 < 1 || tiles_per_plane < 1 || bands < 1 || bands > tiles_per_plane || (!out && max_blocks > 0) || max_blocks < 0)
+        return fail(PVI_EINVAL, "pvi_plan_schedule_rows: bad argument");
+    if ((long long)rows * n1 * tiles_per_plane >= 0x7fffffffLL / 8) return fail(PVI_EINVAL, "pvi_plan_schedule_rows: too many tiles");
+    if (counts)
+        for (int r = 0; r < rows; ++r)
+            if (counts[r] < 0 || counts[r] > tiles_per_plane) return fail(PVI_EINVAL, "pvi_plan_schedule_rows: counts[%d] = %d", r, counts[r]);
+    std::vector<unsigned> sched;
+    lean4_schedule(rows, n1, tiles_per_plane, bands, sched, 0, counts);
+    for (size_t k = 0; k < sched.size() && (long long)k < max_blocks; ++k) out[k] = sched[k];
+    return (int64_t)sched.size();
+}
+
 static int lean4_setup(pvi_problem* h) {
     const DevP& P = h->P;
     Lean4P& L = h->L4;

@@ -112,7 +112,7 @@ class HipSlab:
     boundary kernels -> [halo exchange || interior kernel]: the rows the neighbours wait for are produced first."""
 
     def __init__(self, grid_sys, cost, dtype, rows, halo, device, split=False, has_lower=False, has_upper=False,
-                 hard_inf=False):
+                 hard_inf=False, f32_feedback=False):
         import torch
         from pyro_amd import _native
         self.torch = torch
@@ -148,7 +148,12 @@ class HipSlab:
             return grid_sys._device_problem(
                 cost=cost, dtype=dtype, rows=(a, b), halo=(a - self.store_rows[0], self.store_rows[1] - b), device=device,
                 ext_J=[t.data_ptr() for t in self.J], ext_pi=self.pi.data_ptr() + (a - r0) * self.plane * self.pi.element_size(),
-                flags=_native.FLAG_EXT_J_SLACK | (_native.FLAG_HARD_INF if hard_inf else 0))
+                flags=_native.FLAG_EXT_J_SLACK | (_native.FLAG_HARD_INF if hard_inf else 0)
+                | (_native.FLAG_F32_FEEDBACK if f32_feedback else 0))
+        # error-feedback storage (PVI_FLAG_F32_FEEDBACK): every piece keeps the residuals of ITS rows -- private to a node, so
+        # nothing about them is exchanged; the library refuses the flag on a piece that does not take the 4-D window sweep
+        self.fb = bool(f32_feedback)
+        self.pieces = pieces
         self.handles = [make(pc) for pc in pieces]
         self.n_boundary = len(self.boundary)
         self.p = self.handles[-1]
@@ -163,7 +168,10 @@ class HipSlab:
         self.cstream = torch.cuda.Stream(device=self.dev)      # halo traffic of the overlapped schedule
 
     def terminal_cost(self):
-        self.handles[0].terminal_cost()                 # every handle stores the whole slab: one fill is enough
+        # every handle stores the whole slab: one fill is enough -- unless the pieces keep residuals, which only a handle's
+        # own pvi_terminal_cost clears
+        for h in (self.handles if self.fb else self.handles[:1]):
+            h.terminal_cost()
         self.torch.cuda.synchronize(self.dev)
 
     def _launch(self, handles, alpha):
@@ -200,6 +208,10 @@ class HipSlab:
         t = self.torch.as_tensor(np.ascontiguousarray(J), dtype=self.J[0].dtype).to(self.dev)
         self.rows_view(self.rows[0], self.rows[1] - self.rows[0]).copy_(t)
         self.torch.cuda.synchronize(self.dev)
+        if self.fb:     # a cost-to-go from the host restarts the residuals (pvi_set_J clears the ones of the handle it is called on)
+            J = np.ascontiguousarray(J, dtype=float).ravel()
+            for (a, b), h in zip(self.pieces, self.handles):
+                h.set_J(J[(a - self.rows[0]) * self.plane:(b - self.rows[0]) * self.plane], a, b - a)
 
     def owned_pi(self):
         pi = self.pi.cpu().numpy()
@@ -215,7 +227,7 @@ class ShardedValueIteration:
     """Drives one slab per rank; `dist` is torch.distributed (already initialised)."""
 
     def __init__(self, grid_sys, cost_function, dist, dtype="float32", device=0, slab_factory=None, halo=None,
-                 overlap=True, hard_inf=False):
+                 overlap=True, hard_inf=False, f32_feedback=False):
         import torch
         self.torch, self.dist = torch, dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
@@ -243,9 +255,12 @@ class ShardedValueIteration:
         self.overlap = bool(overlap) and slab_factory is None and self.p2p and self.world > 1
         if slab_factory is None:
             self.slab = HipSlab(grid_sys, cost, dtype, self.rows, store_halo, device, split=self.overlap,
-                                has_lower=self.rank > 0, has_upper=self.rank < self.world - 1, hard_inf=hard_inf)
+                                has_lower=self.rank > 0, has_upper=self.rank < self.world - 1, hard_inf=hard_inf,
+                                f32_feedback=f32_feedback)
         else:
             import inspect
+            if f32_feedback:
+                raise NotImplementedError("f32_feedback: a storage mode of the library's 4-D float32 window sweep (this slab back end is not the library)")
             kw = {"hard_inf": True} if hard_inf else {}
             if hard_inf and "hard_inf" not in inspect.signature(slab_factory).parameters:
                 raise NotImplementedError("this slab back end has no base-class (exactly-INF) recursion")
@@ -598,10 +613,9 @@ class _TorchEngine:
             # (the Python-driven schedule has no table tier: RcclComm / TransportComm shard the look-up tables)
             raise NotImplementedError("TorchDistComm drives the fused tier only (in-kernel dynamics and cost); use RcclComm "
                                       "or TransportComm for systems / costs that need look-up tables")
-        if getattr(dp, "F32_FEEDBACK", False):
-            raise NotImplementedError("f32_feedback: sharded through the library (RcclComm / TransportComm), not the Python-driven slabs")
         self.vi = ShardedValueIteration(dp.grid_sys, dp.cf, comm.dist, dtype=dp.dtype, device=dp.device,
-                                        slab_factory=comm.slab_factory, overlap=comm.overlap, hard_inf=bool(dp.HARD_INF))
+                                        slab_factory=comm.slab_factory, overlap=comm.overlap, hard_inf=bool(dp.HARD_INF),
+                                        f32_feedback=bool(getattr(dp, "F32_FEEDBACK", False)))
         self.tier, self.rows, self.world = "fused", self.vi.rows, comm.world
         self.dynamics_id = None
 

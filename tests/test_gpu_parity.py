@@ -1270,7 +1270,7 @@ rank, out = int(sys.argv[1]), sys.argv[2]
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d", rank=rank, world_size=%d)
 with contextlib.redirect_stdout(io.StringIO()):
     cfg = configs.build("%s")
-vi = parallel.ShardedValueIteration(cfg["grid_sys"], cfg["cf"], dist, dtype="float32", device=0, overlap=%s)
+vi = parallel.ShardedValueIteration(cfg["grid_sys"], cfg["cf"], dist, dtype="float32", device=0, overlap=%s, f32_feedback=%s)
 stats = [vi.sweep(1.0) for _ in range(4)]
 last = vi.run(3, 1.0, -1.0)
 J, pi = vi.gather()
@@ -1282,11 +1282,14 @@ print("WORLD2-OK", rank)
 """
 
 
-@pytest.mark.parametrize("case,world,overlap", [("cartpole:21,21,21,21:7:float32", 2, True),
-                                                ("cartpole:21,21,21,21:7:float32", 2, False),
-                                                ("pendulum:101,101:11:float32", 2, True),
-                                                ("cartpole:21,21,21,21:7:float32", 3, True)])
-def test_two_ranks_share_one_gpu(tmp_path, case, world, overlap):
+@pytest.mark.parametrize("case,world,overlap,fb", [("cartpole:21,21,21,21:7:float32", 2, True, False),
+                                                   ("cartpole:21,21,21,21:7:float32", 2, False, False),
+                                                   ("pendulum:101,101:11:float32", 2, True, False),
+                                                   ("cartpole:21,21,21,21:7:float32", 3, True, False),
+                                                   # round 5: error-feedback storage over the Python-driven slabs (every piece keeps the
+                                                   # residuals of its rows; nothing about them is exchanged)
+                                                   ("cartpole:21,21,21,21:7:float32", 3, True, True)])
+def test_two_ranks_share_one_gpu(tmp_path, case, world, overlap, fb):
     """The sharded driver with the product HipSlab on real hardware: two processes (both on GPU 0), halo rows moved
     by a gloo process group through host staging, statistics all-reduced -- must equal the single-handle result
     bit for bit (same kernels, same arithmetic per node).  overlap=True is the boundary-first schedule: separate
@@ -1300,7 +1303,7 @@ def test_two_ranks_share_one_gpu(tmp_path, case, world, overlap):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "res.npz")
-    code = _WORLD2 % (ROOT, port, world, case, overlap)
+    code = _WORLD2 % (ROOT, port, world, case, overlap, fb)
     procs = [subprocess.Popen([sys.executable, "-c", code, str(r), out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
     logs = [p.communicate(timeout=900)[0] for p in procs]
@@ -1310,7 +1313,7 @@ def test_two_ranks_share_one_gpu(tmp_path, case, world, overlap):
     from pyro_amd.planning import dynamicprogramming
     with contextlib.redirect_stdout(io.StringIO()):
         cfg = configs.build(case)
-        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype="float32")
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype="float32", f32_feedback=fb)
     stats, _ = dp._p.sweep(7, 1.0, -1.0)
     assert np.array_equal(r["J"], dp._p.get_J()) and np.array_equal(r["pi"], dp._p.get_pi())
     np.testing.assert_allclose(r["stats"][:4], stats[:4], rtol=1e-12)
