@@ -66,6 +66,8 @@ struct LeanP {
     float guard;
     int lds_floats;      // floats of one window buffer
     int RS;              // LDS row pitch in dwords, 32k+1
+    float* jlo;          // [owned] PVI_FLAG_F32_FEEDBACK on a 2-D grid: rounding residual of the stored J (NULL: plain storage)
+    double alpha64;      // ... and the discount factor of the launch unrounded
 };
 
 struct Lean4P {
@@ -287,6 +289,9 @@ static int dev_alloc(pvi_problem* h, size_t n, T** out) {
     *out = (T*)p;
     return PVI_OK;
 }
+
+// the residuals of error-feedback storage (PVI_FLAG_F32_FEEDBACK): the 4-D window sweep's or the 2-D one's, or NULL
+static inline float*& jlo_of(pvi_problem* h) { return h->lean4_ok ? h->L4.jlo : h->LP.jlo; }
 
 static inline void dev_release(pvi_problem* h, void* p) {
     if (!p) return;

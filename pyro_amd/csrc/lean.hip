@@ -1158,6 +1158,7 @@ int lean_setup(pvi_problem* h) {
     // round of resident waves instead of two) but leave less to overlap; which wins depends on the action count
     // (2001^2 x 21: 67.7 -> 59.1 us with two, 1001^2 x 51: 35.4 -> 37.5 us), so both run a few timed sweeps here and
     // the faster stays.  Results do not depend on it (same arithmetic per node).  PVI_NPT fixes it, PVI_TUNE=0 keeps 1.
+    const bool fb2 = (h->d.flags & PVI_FLAG_F32_FEEDBACK) != 0;   // error-feedback storage: the one-node-per-thread forms only
     if (DOF == 1 && ls == 0 && !ovr("NPT") && h->owned >= (1 << 17) && !(ovr("TUNE") && !atoi(ovr("TUNE")))) {
         // (clocks ramp up during the first sweeps after a create: the candidates alternate, two rounds of 40 timed
         //  sweeps behind 20 untimed ones each, and a candidate is judged by its faster round)
@@ -1166,6 +1167,7 @@ int lean_setup(pvi_problem* h) {
         float best_of[4] = {0.f, 1e30f, 1e30f, 1e30f};
         for (int round = 0; round < 2; ++round)
             for (int cand = 1; cand <= 3; ++cand) {
+                if (fb2 && cand == 2) continue;
                 L.npt = cand == 2 ? 2 : 1;
                 rowmul = cand == 3 ? 2 : 1;
                 h->lean_ok = false;
@@ -1246,6 +1248,33 @@ static int launch_lean2_t(pvi_problem* h, const float* Jin, float* Jout, float a
                            sc);                                                                                     \
         if (sc.split_finish == 1) hipLaunchKernelGGL(k_sweep_finish, 1, STAT_SHARDS, 0, st, sc);                    \
     }
+#define LEANFB(DYN, U)                                                                                               \
+    {                                                                                                               \
+        auto kfn = k_sweep_leanfb<DYN, PI_T, U>;                                                                    \
+        set_kname(h, "k_sweep_leanfb", (int)DYN, tname<PI_T>(), (bool)U);                                           \
+        if (!h->lean_lds_attr && h->lean_lds > 48 * 1024) {                                                         \
+            HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PVI_LDS_MAX)); \
+            h->lean_lds_attr = true;                                                                                \
+        }                                                                                                           \
+        hipLaunchKernelGGL(kfn, h->lean_grid, h->lean_block, h->lean_lds, st, h->P, h->LP, h->F.act, h->LP.actc, Jin, Jout, pi, al, \
+                           sc);                                                                                     \
+        if (sc.split_finish == 1) hipLaunchKernelGGL(k_sweep_finish, 1, STAT_SHARDS, 0, st, sc);                    \
+    }
+            if (h->LP.jlo) {  // error-feedback storage (2-D grids, one input; pvi_create admits no other handle)
+                if (h->d.dynamics_id == PVI_DYN_PENDULUM) {
+                    if (h->LP.lsplit == 0)
+                        LEANFB(PVI_DYN_PENDULUM, true)
+                    else
+                        LEANFB(PVI_DYN_PENDULUM, false)
+                } else {
+                    if (h->LP.lsplit == 0)
+                        LEANFB(PVI_DYN_NODE_1x1, true)
+                    else
+                        LEANFB(PVI_DYN_NODE_1x1, false)
+                }
+                HIPCHK(hipGetLastError());
+                return PVI_OK;
+            }
 #define LEAN(DYN)                                                  \
     if (h->LP.lsplit == 0) {                                       \
         if (h->LP.RS == 64)                          \
@@ -1276,6 +1305,7 @@ static int launch_lean2_t(pvi_problem* h, const float* Jin, float* Jout, float a
 #undef LEAN
 #undef LEAN3
 #undef LEAN4
+#undef LEANFB
             HIPCHK(hipGetLastError());
             return PVI_OK;
         }

@@ -1716,10 +1716,13 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
 #undef HCHK
     if ((rc = lean_setup(h))) return bail(rc);
     if (d->flags & PVI_FLAG_F32_FEEDBACK) {
-        // error-feedback storage: one residual per owned node, private to the node (sweep_lean4.inc lean4_feedback)
-        if (!h->lean4_ok)
-            return bail(fail(PVI_EINVAL, "PVI_FLAG_F32_FEEDBACK needs the float32 window sweep of 4-D grids; this handle does not take it (%s)",
-                             d->dtype != PVI_F32 ? "dtype is not float32" : d->n != 4 ? "not a 4-D grid" : h->lean_why[0] ? h->lean_why : "no window set-up"));
+        // error-feedback storage: one residual per owned node, private to the node (sweep_lean4.inc lean4_feedback for the 4-D
+        // window sweep; sweep_lean.inc lean_feedback for the 2-D one: one-input systems, one node per thread)
+        const bool lean2_fb = h->lean_ok && !h->lean4_ok && d->n == 2 && d->m == 1 && h->LP.npt == 1 &&
+                              (d->dynamics_id == PVI_DYN_PENDULUM || d->dynamics_id == PVI_DYN_NODE_1x1);
+        if (!h->lean4_ok && !lean2_fb)
+            return bail(fail(PVI_EINVAL, "PVI_FLAG_F32_FEEDBACK needs a float32 LDS-window sweep (4-D grids, or 2-D grids with one input); this handle does not take one (%s)",
+                             d->dtype != PVI_F32 ? "dtype is not float32" : (d->n != 4 && d->n != 2) ? "a 3-D grid" : h->lean_why[0] ? h->lean_why : "no window set-up"));
         float* lo = nullptr;
         if ((rc = dev_alloc(h, (size_t)h->owned, &lo))) return bail(rc);
         rc = [&]() -> int {
@@ -1728,7 +1731,7 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
             return PVI_OK;
         }();
         if (rc) return bail(rc);
-        h->L4.jlo = lo;
+        jlo_of(h) = lo;
     }
     if (d->dtype == PVI_F32 && is_dyn3(d->dynamics_id) && A <= 64 && !ovr("NO_FAST")) {
         // fast3: the validity of every cell of an explicit system, once (sweep_lean.inc's idea applied to the obstacle tests)
@@ -1902,11 +1905,11 @@ static int describe_impl(pvi_handle h, char* buf, int32_t n) {
                  h->L4.jlo ? 1 : 0, h->L4.vmask ? 1 : 0, h->lean4_choice, h->L4.ntr, h->lean4_bands, h->lean4_cands[0] ? h->lean4_cands : "-", h->lean_why);
         return PVI_OK;
     }
-    snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d npt=%d reach=%d opmag=%d sparse=%d win=0 tables=0 note=%s",
+    snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d npt=%d reach=%d opmag=%d sparse=%d win=0 tables=0 feedback=%d note=%s",
              path, h->LP.TV0, h->LP.TV1, h->lean_grid.x, h->lean_grid.y, h->lean_grid.z, h->lean_block, h->lean_pw1,
              h->lean_lds, h->lean_ok ? h->LP.lsplit : h->F.lsplit, h->LP.tb_tile, h->lean_ok ? h->LP.dma16 : 0,
              h->lean_ok ? h->LP.npt : 1, h->lean_reach, h->lean_opmag,
-             (h->d.dtype == PVI_F32 && h->sparse64 && h->vmask) ? 1 : 0, h->lean_why);
+             (h->d.dtype == PVI_F32 && h->sparse64 && h->vmask) ? 1 : 0, (h->lean_ok && h->LP.jlo) ? 1 : 0, h->lean_why);
     return PVI_OK;
 }
 
@@ -1929,7 +1932,7 @@ static int terminal_cost_t(pvi_problem* h) {
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(h->pi, 0, (size_t)h->owned * h->pi_size, h->stream));
-    if (h->L4.jlo) HIPCHK(hipMemsetAsync(h->L4.jlo, 0, (size_t)h->owned * sizeof(float), h->stream));  // a new J: no residuals
+    if (jlo_of(h)) HIPCHK(hipMemsetAsync(jlo_of(h), 0, (size_t)h->owned * sizeof(float), h->stream));  // a new J: no residuals
     HIPCHK(hipStreamSynchronize(h->stream));
     return PVI_OK;
 }
@@ -1973,7 +1976,7 @@ extern "C" int pvi_set_J(pvi_handle h, const double* Jr, int32_t row0, int32_t n
     if (rc) return rc;
     HIPCHK(hipSetDevice(h->device));
     const long long n = (long long)nrows * h->plane, off = (long long)(row0 - h->P.store_begin) * h->plane;
-    if (h->L4.jlo) HIPCHK(hipMemsetAsync(h->L4.jlo, 0, (size_t)h->owned * sizeof(float), h->stream));  // a new J: no residuals
+    if (jlo_of(h)) HIPCHK(hipMemsetAsync(jlo_of(h), 0, (size_t)h->owned * sizeof(float), h->stream));  // a new J: no residuals
     if (h->d.dtype == PVI_F64) {
         HIPCHK(hipMemcpyAsync((double*)h->J[h->cur] + off, Jr, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
     } else {
@@ -2093,7 +2096,10 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
             h->L4.alpha64 = alpha;  // (read by the error-feedback epilogue only)
             return launch_lean4(h, Jin, Jout, (float)alpha, st, sc);
         }
-        if (h->lean_ok && !h->force_exact) return launch_lean2(h, Jin, Jout, (float)alpha, st, sc);
+        if (h->lean_ok && !h->force_exact) {
+            h->LP.alpha64 = alpha;
+            return launch_lean2(h, Jin, Jout, (float)alpha, st, sc);
+        }
         if (h->fast_ok && !is_node_dyn(h->d.dynamics_id) && !h->force_exact) return launch_fast(h, Jin, Jout, (float)alpha, st, sc);
     }
     int nlev_all = 0;
@@ -2412,10 +2418,10 @@ extern "C" int pvi_self_check(pvi_handle h, double alpha, double* max_rel_diff, 
         //     form of the window sweep runs, which leaves the residuals alone.)
         hipLaunchKernelGGL(k_reset_stats, 1, STAT_WORDS, 0, h->stream, h->slots, STAT_WORDS);
         hipLaunchKernelGGL(k_begin_batch, 1, 1, 0, h->stream, h->ctrl);
-        float* const lo_keep = h->L4.jlo;
-        h->L4.jlo = nullptr;
+        float* const lo_keep = jlo_of(h);
+        jlo_of(h) = nullptr;
         int r = launch_sweep(h, h->cur, alpha, h->stream, 0, -1.0);
-        h->L4.jlo = lo_keep;
+        jlo_of(h) = lo_keep;
         if (r) return r;
         // (2) the plain-gather kernel (float64 dynamics, no windows, no set-up tables) into scratch buffers
         void* Ja = h->J[h->cur ^ 1];

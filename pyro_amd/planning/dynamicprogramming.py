@@ -127,16 +127,22 @@ class DynamicProgramming:
                                           "interpolant they were built with)" % value)
             self._rebuild_engine()
 
+    def _feedback_applies(self):
+        """Error-feedback storage exists where a float32 LDS-window sweep exists: 4-D grids (k_sweep_lean4fb) and 2-D grids of
+        one-input mechanical systems (k_sweep_leanfb: the pendulum family and the per-node-table tier, e.g. MountainCar).  The
+        library itself refuses the flag on a handle that does not take such a sweep (PVI_EINVAL)."""
+        return self.dtype == np.float32 and (self.sys.n == 4 or (self.sys.n == 2 and self.sys.m == 1 and getattr(self.sys, "dof", None) == 1))
+
     def _make_engine(self):
         self._host = {}             # cached downloads: 'J', 'pi', 'J_next'
         self._dirty = False         # host J newer than the device copy
         if self.comm is not None:
             if self.INTERPOLATION != "linear":
                 raise NotImplementedError("the spline fit couples every row of the grid: single-GPU only")
-            if self.F32_FEEDBACK and (self.dtype != np.float32 or self.sys.n != 4):
-                raise NotImplementedError("f32_feedback is the float32 storage mode of the 4-D window sweep (dtype %s, n = %d)"
-                                          % (self.dtype, self.sys.n))
-            self._p = self.comm.engine(self)        # (the library's sharded engines carry the flag; the Python-driven one refuses)
+            if self.F32_FEEDBACK and not self._feedback_applies():
+                raise NotImplementedError("f32_feedback is the float32 storage mode of the LDS-window sweeps: 4-D grids, and 2-D grids "
+                                          "with one input (dtype %s, n = %d, m = %d)" % (self.dtype, self.sys.n, self.sys.m))
+            self._p = self.comm.engine(self)        # (every sharded engine carries the flag to the pieces of its slabs)
             self.tier = self._p.tier
             return
         dd = device_dynamics_of(self.sys)
@@ -150,9 +156,9 @@ class DynamicProgramming:
         if self.tier == "fused":
             # (base class: an invalid cell costs exactly INF; the same as INF + alpha*0 unless the system rejects
             #  states inside the grid box, i.e. obstacles)
-            if self.F32_FEEDBACK and (self.dtype != np.float32 or self.sys.n != 4):
-                raise NotImplementedError("f32_feedback is the float32 storage mode of the 4-D window sweep (dtype %s, n = %d)"
-                                          % (self.dtype, self.sys.n))
+            if self.F32_FEEDBACK and not self._feedback_applies():
+                raise NotImplementedError("f32_feedback is the float32 storage mode of the LDS-window sweeps: 4-D grids, and 2-D grids "
+                                          "with one input (dtype %s, n = %d, m = %d)" % (self.dtype, self.sys.n, self.sys.m))
             self._p = self.grid_sys._device_problem(cost=cost, dtype=self.dtype, device=self.device,
                                                     flags=(_native.FLAG_HARD_INF if self.HARD_INF else 0)
                                                     | (_native.FLAG_F32_FEEDBACK if self.F32_FEEDBACK else 0))

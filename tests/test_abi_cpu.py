@@ -63,8 +63,8 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(pvi_desc), offsetof(p
 
 def test_flag_values_match_the_header_and_feedback_refusals_need_no_device():
     """pvi_desc.flags: the binding's constants are the header's; the float32 error-feedback mode (PVI_FLAG_F32_FEEDBACK) is
-    refused by the class surface where no kernel implements it -- float64, 2-D grids, also sharded -- before any device
-    call."""
+    refused by the class surface where no kernel implements it -- float64, systems that are not one- or two-degree-of-freedom
+    mechanical (a two-input 2-D robot), also sharded -- before any device call."""
     import re
     import numpy as np
     from pyro_amd import _native, configs
@@ -76,9 +76,17 @@ def test_flag_values_match_the_header_and_feedback_refusals_need_no_device():
     with contextlib.redirect_stdout(io.StringIO()):
         c4 = configs.build("cartpole:5,5,5,5:3:float32")
         c2 = configs.build("pendulum:9,9:3:float32")
-    for cfg, dt in ((c4, "float64"), (c2, "float32")):
+    # (round 5: 2-D grids of one-input systems have the mode too -- k_sweep_leanfb; float64 and everything else is refused)
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import vehicle_steering
+    from pyro_amd.planning import discretizer
+    with contextlib.redirect_stdout(io.StringIO()):
+        rob = vehicle_steering.HolonomicMobileRobot()
+        grob = discretizer.GridDynamicSystem(rob, [7, 7], [3, 3])
+        crob = costfunction.QuadraticCostFunction.from_sys(rob)
+    for g_, cf_, dt in ((c4["grid_sys"], c4["cf"], "float64"), (c2["grid_sys"], c2["cf"], "float64"), (grob, crob, "float32")):
         with pytest.raises(NotImplementedError):
-            DP.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype=dt, f32_feedback=True)
+            DP.DynamicProgrammingWithLookUpTable(g_, cf_, dtype=dt, f32_feedback=True)
 
     class Comm:                         # never reached: the refusal comes before the engine is built
         def engine(self, dp):
@@ -86,7 +94,7 @@ def test_flag_values_match_the_header_and_feedback_refusals_need_no_device():
     with pytest.raises(NotImplementedError):
         DP.DynamicProgrammingWithLookUpTable(c4["grid_sys"], c4["cf"], dtype="float64", comm=Comm(), f32_feedback=True)
     with pytest.raises(NotImplementedError):
-        DP.DynamicProgrammingWithLookUpTable(c2["grid_sys"], c2["cf"], dtype="float32", comm=Comm(), f32_feedback=True)
+        DP.DynamicProgrammingWithLookUpTable(grob, crob, dtype="float32", comm=Comm(), f32_feedback=True)
 
 
 def test_no_cpu_fallback_without_device():
