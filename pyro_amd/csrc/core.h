@@ -409,6 +409,29 @@ __device__ inline float interp_f32(const float* __restrict__ J, const long long*
     return v[0];
 }
 
+// ... the same gathers of a float32 J combined in float64 (error-feedback epilogues: the chosen action's backup once per node)
+template <int N>
+__device__ inline double interp_f32_in_f64(const float* __restrict__ J, const long long* strd, long long base, const double* y) {
+    double v[1 << N];
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+#pragma unroll
+    for (int pair = 0; pair < (1 << (N - 1)); ++pair) {
+        long long off = base;
+#pragma unroll
+        for (int d = 0; d < N - 1; ++d) off += ((pair >> (N - 2 - d)) & 1) ? strd[d] : 0;
+        const f2u r = *(const f2u*)(J + off);
+        v[2 * pair] = (double)r.x;
+        v[2 * pair + 1] = (double)r.y;
+    }
+#pragma unroll
+    for (int d = N - 1; d >= 0; --d) {
+        const int half = 1 << d;
+#pragma unroll
+        for (int k = 0; k < half; ++k) v[k] = __builtin_fma(y[d], v[2 * k + 1] - v[2 * k], v[2 * k]);
+    }
+    return v[0];
+}
+
 template <typename REAL, int N>
 struct Interp;
 template <int N>

@@ -224,6 +224,7 @@ struct pvi_problem {
     int patch64 = -1;         // 4-D wave mapping of k_sweep64: 1 = 8 x 8 velocity patches, 0 = consecutive nodes (timed at set-up)
     size_t levr_bytes = 0;
     const unsigned long long* okmask3 = nullptr;  // fast3: validity of every (node, action) cell of an explicit system
+    float* jlo = nullptr;     // [owned] PVI_FLAG_F32_FEEDBACK: rounding residual of the stored float32 J of every node
     const double* roll_params = nullptr;  // constants of the continuous closed form (pvi_set_rollout_params)
     SplineP SP;               // bicubic-spline interpolation mode (sweep_spline.inc)
     bool spline = false;
@@ -290,8 +291,9 @@ static int dev_alloc(pvi_problem* h, size_t n, T** out) {
     return PVI_OK;
 }
 
-// the residuals of error-feedback storage (PVI_FLAG_F32_FEEDBACK): the 4-D window sweep's or the 2-D one's, or NULL
-static inline float*& jlo_of(pvi_problem* h) { return h->lean4_ok ? h->L4.jlo : h->LP.jlo; }
+// the residuals of error-feedback storage (PVI_FLAG_F32_FEEDBACK) belong to the handle (pvi_problem::jlo); the parameter blocks
+// of the window sweeps get the pointer at every launch (launch_sweep_t)
+static inline float*& jlo_of(pvi_problem* h) { return h->jlo; }
 
 static inline void dev_release(pvi_problem* h, void* p) {
     if (!p) return;

@@ -493,7 +493,8 @@ __global__ __launch_bounds__(256) void k_mask3(DevP P, unsigned long long* __res
 template <int DYN, typename PI_T>
 __global__ __launch_bounds__(256) void k_sweep3_fast(DevP P, const float* __restrict__ Jin, float* __restrict__ Jout, PI_T* __restrict__ pi,
                                                      float alpha, SweepCtl sc, const double* __restrict__ utab,
-                                                     const double* __restrict__ gutab, const unsigned long long* __restrict__ okmask) {
+                                                     const double* __restrict__ gutab, const unsigned long long* __restrict__ okmask,
+                                                     float* __restrict__ jlo, double alpha64) {
     using D = Dyn3<DYN>;
     constexpr int N = D::N, M = D::M;
     if (sc.ctrl->done) return;
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(256) void k_sweep3_fast(DevP P, const float* __rest
         const unsigned long long okm = okmask[o];
         D dyn;
         dyn.init(P, idx, x);
-        double xn[N], u0[M];
+        double xn[N], u0[M], y64[N];
         float y[N];
         int ci[N];
         bool inb_fix = true;
@@ -557,7 +558,8 @@ __global__ __launch_bounds__(256) void k_sweep3_fast(DevP P, const float* __rest
                     inb_fix = inb_fix && !(xn[d] < P.glo[d]) && !(xn[d] > P.ghi[d]);
                     double l0, l1;
                     ci[d] = find_interval_lv(P.lev[d], P.dim[d], P.glo[d], P.inv_step[d], xn[d], l0, l1);
-                    y[d] = (float)((xn[d] - l0) / (l1 - l0));
+                    y64[d] = (xn[d] - l0) / (l1 - l0);
+                    y[d] = (float)y64[d];
                 }
             }
         }
@@ -608,6 +610,49 @@ __global__ __launch_bounds__(256) void k_sweep3_fast(DevP P, const float* __rest
                 best = q;
                 arg = a;
             }
+        }
+        if (jlo) {
+            // Error-feedback storage (PVI_FLAG_F32_FEEDBACK): the backup of the chosen action once more, the
+            // float32 gathers combined in float64 with the unrounded fractions and cost, plus the residual of the node's last
+            // store; what this store drops is the next residual.  (An action the base class rejects costs INF exactly.)
+            const float lo_old = jlo[o];
+            float lo_new = 0.f;
+            const bool ok = (okm >> arg) & 1ull;
+            if (!(P.hard_inf && !ok)) {
+                double u[M], fa[N];
+#pragma unroll
+                for (int k = 0; k < M; ++k) u[k] = utab[arg * M + k];
+                dyn.f(P, x, u, arg, fa);
+                bool inb = inb_fix;
+#pragma unroll
+                for (int d = 0; d < N; ++d) {
+                    if ((D::UDEP >> d) & 1) {
+                        xn[d] = fa[d] * P.dt + x[d];
+                        inb = inb && !(xn[d] < P.glo[d]) && !(xn[d] > P.ghi[d]);
+                        const double t = (xn[d] - P.glo[d]) * P.inv_step[d];
+                        double fl = floor(t);
+                        fl = fl < 0.0 ? 0.0 : (fl > (double)(P.dim[d] - 2) ? (double)(P.dim[d] - 2) : fl);
+                        ci[d] = (int)fl;
+                        y64[d] = t - fl;
+                    }
+                }
+                double Jn = 0.0;
+                if (inb) {
+                    long long b = 0;
+#pragma unroll
+                    for (int d = 0; d < N; ++d) {
+                        int c = ci[d];
+                        if (d == 0) c = min(max(c, P.store_begin), P.store_end - 2) - P.store_begin;
+                        b += c * P.strd[d];
+                    }
+                    Jn = interp_f32_in_f64<N>(Jin, P.strd, b, y64);
+                }
+                const double g = on_target ? 0.0 : (node_bad ? P.INF : (gx + gutab[arg]));
+                const double t = __builtin_fma(alpha64, Jn, ok ? g * P.dt : P.INF) + (double)lo_old;
+                best = (float)t;
+                if (t < INFINITY && t > -INFINITY) lo_new = (float)(t - (double)best);
+            }
+            jlo[o] = lo_new;
         }
         Jout[self] = best;
         pi[o] = (PI_T)arg;
@@ -1720,9 +1765,10 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
         // window sweep; sweep_lean.inc lean_feedback for the 2-D one: one-input systems, one node per thread)
         const bool lean2_fb = h->lean_ok && !h->lean4_ok && d->n == 2 && d->m == 1 && h->LP.npt == 1 &&
                               (d->dynamics_id == PVI_DYN_PENDULUM || d->dynamics_id == PVI_DYN_NODE_1x1);
-        if (!h->lean4_ok && !lean2_fb)
-            return bail(fail(PVI_EINVAL, "PVI_FLAG_F32_FEEDBACK needs a float32 LDS-window sweep (4-D grids, or 2-D grids with one input); this handle does not take one (%s)",
-                             d->dtype != PVI_F32 ? "dtype is not float32" : (d->n != 4 && d->n != 2) ? "a 3-D grid" : h->lean_why[0] ? h->lean_why : "no window set-up"));
+        const bool fast3_fb = d->dtype == PVI_F32 && is_dyn3(d->dynamics_id) && A <= 64 && !ovr("NO_FAST");   // (k_sweep3_fast, set up below)
+        if (!h->lean4_ok && !lean2_fb && !fast3_fb)
+            return bail(fail(PVI_EINVAL, "PVI_FLAG_F32_FEEDBACK needs a float32 production sweep (4-D grids, 2-D grids with one input, or an explicit system with at most 64 actions); this handle does not take one (%s)",
+                             d->dtype != PVI_F32 ? "dtype is not float32" : h->lean_why[0] ? h->lean_why : "no window set-up"));
         float* lo = nullptr;
         if ((rc = dev_alloc(h, (size_t)h->owned, &lo))) return bail(rc);
         rc = [&]() -> int {
@@ -1902,14 +1948,14 @@ static int describe_impl(pvi_handle h, char* buf, int32_t n) {
         snprintf(buf, (size_t)n, "path=lean tile=%dx%d grid=%ux1x1 block=%d pw1=%d lds_bytes=%zu lsplit=0 tb_tile=1 dma16=0 npt=1 "
                  "reach=0 opmag=0 sparse=0 win=1 tables=%d ptab=%d gx=%s stage=%d feedback=%d vmask=%d choice=%s tiles_per_plane=%d bands=%d cands=%s note=%s", h->L4.TV0, h->L4.TV1,
                  h->lean4_grid, h->lean4_block, h->L4.RS, h->lean4_lds, h->lean4_tables, h->lean4_ptab_inv, h->L4.gx ? "node" : "axes", h->lean4_stage,
-                 h->L4.jlo ? 1 : 0, h->L4.vmask ? 1 : 0, h->lean4_choice, h->L4.ntr, h->lean4_bands, h->lean4_cands[0] ? h->lean4_cands : "-", h->lean_why);
+                 h->jlo ? 1 : 0, h->L4.vmask ? 1 : 0, h->lean4_choice, h->L4.ntr, h->lean4_bands, h->lean4_cands[0] ? h->lean4_cands : "-", h->lean_why);
         return PVI_OK;
     }
     snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d npt=%d reach=%d opmag=%d sparse=%d win=0 tables=0 feedback=%d note=%s",
              path, h->LP.TV0, h->LP.TV1, h->lean_grid.x, h->lean_grid.y, h->lean_grid.z, h->lean_block, h->lean_pw1,
              h->lean_lds, h->lean_ok ? h->LP.lsplit : h->F.lsplit, h->LP.tb_tile, h->lean_ok ? h->LP.dma16 : 0,
              h->lean_ok ? h->LP.npt : 1, h->lean_reach, h->lean_opmag,
-             (h->d.dtype == PVI_F32 && h->sparse64 && h->vmask) ? 1 : 0, (h->lean_ok && h->LP.jlo) ? 1 : 0, h->lean_why);
+             (h->d.dtype == PVI_F32 && h->sparse64 && h->vmask) ? 1 : 0, h->jlo ? 1 : 0, h->lean_why);
     return PVI_OK;
 }
 
@@ -2092,6 +2138,8 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
         return PVI_OK;
     }
     if constexpr (sizeof(REAL) == 4) {  // the float32 production families (lean.hip)
+        h->L4.jlo = h->lean4_ok ? h->jlo : nullptr;   // (error-feedback residuals: the handle's, NULL during a self check)
+        h->LP.jlo = h->lean_ok && !h->lean4_ok ? h->jlo : nullptr;
         if (h->lean4_ok && !h->force_exact) {
             h->L4.alpha64 = alpha;  // (read by the error-feedback epilogue only)
             return launch_lean4(h, Jin, Jout, (float)alpha, st, sc);
@@ -2141,7 +2189,7 @@ static int launch_sweep_t(pvi_problem* h, int src, double alpha, hipStream_t st,
 #define FAST3(DYN)                                                                                                  \
     set_kname(h, "k_sweep3_fast", (int)DYN, tname<PI_T>());                                                         \
     hipLaunchKernelGGL((k_sweep3_fast<DYN, PI_T>), g3, 256, 0, st, h->P, Jin, Jout, pi, (float)alpha, sc, h->P.utab, h->P.gu, \
-                       h->okmask3)
+                       h->okmask3, h->jlo, (double)alpha)
             switch (h->d.dynamics_id) {
                 case PVI_DYN_HELICOPTER: FAST3(PVI_DYN_HELICOPTER); break;
                 case PVI_DYN_KINCAR: FAST3(PVI_DYN_KINCAR); break;

@@ -128,10 +128,16 @@ class DynamicProgramming:
             self._rebuild_engine()
 
     def _feedback_applies(self):
-        """Error-feedback storage exists where a float32 LDS-window sweep exists: 4-D grids (k_sweep_lean4fb) and 2-D grids of
-        one-input mechanical systems (k_sweep_leanfb: the pendulum family and the per-node-table tier, e.g. MountainCar).  The
-        library itself refuses the flag on a handle that does not take such a sweep (PVI_EINVAL)."""
-        return self.dtype == np.float32 and (self.sys.n == 4 or (self.sys.n == 2 and self.sys.m == 1 and getattr(self.sys, "dof", None) == 1))
+        """Error-feedback storage exists where a float32 production sweep exists: 4-D grids (k_sweep_lean4fb), 2-D grids of
+        one-input mechanical systems (k_sweep_leanfb: the pendulum family and the per-node-table tier, e.g. MountainCar) and the
+        explicit systems (k_sweep3_fast).  The library itself refuses the flag on a handle that does not take such a sweep
+        (PVI_EINVAL)."""
+        if self.dtype != np.float32:
+            return False
+        mech = getattr(self.sys, "dof", None)
+        if mech is not None:        # mechanical systems: the LDS-window sweeps
+            return self.sys.n == 4 or (self.sys.n == 2 and self.sys.m == 1)
+        return True                 # explicit systems: k_sweep3_fast (the library refuses where that sweep does not apply)
 
     def _make_engine(self):
         self._host = {}             # cached downloads: 'J', 'pi', 'J_next'

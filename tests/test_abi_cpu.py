@@ -76,15 +76,14 @@ def test_flag_values_match_the_header_and_feedback_refusals_need_no_device():
     with contextlib.redirect_stdout(io.StringIO()):
         c4 = configs.build("cartpole:5,5,5,5:3:float32")
         c2 = configs.build("pendulum:9,9:3:float32")
-    # (round 5: 2-D grids of one-input systems have the mode too -- k_sweep_leanfb; float64 and everything else is refused)
-    from pyro_amd.analysis import costfunction
-    from pyro_amd.dynamic import vehicle_steering
-    from pyro_amd.planning import discretizer
+    # (round 5: 2-D grids of one-input systems and the explicit systems have the mode too -- k_sweep_leanfb, k_sweep3_fast;
+    #  float64 is refused, and so is the table tier: a system whose f is arbitrary Python)
+    import table_case
     with contextlib.redirect_stdout(io.StringIO()):
-        rob = vehicle_steering.HolonomicMobileRobot()
-        grob = discretizer.GridDynamicSystem(rob, [7, 7], [3, 3])
-        crob = costfunction.QuadraticCostFunction.from_sys(rob)
-    for g_, cf_, dt in ((c4["grid_sys"], c4["cf"], "float64"), (c2["grid_sys"], c2["cf"], "float64"), (grob, crob, "float32")):
+        tc = table_case.table_case()
+    with pytest.raises(NotImplementedError):
+        DP.DynamicProgrammingWithLookUpTable(tc["grid_sys"], tc["cf"], dtype="float32", f32_feedback=True)
+    for g_, cf_, dt in ((c4["grid_sys"], c4["cf"], "float64"), (c2["grid_sys"], c2["cf"], "float64")):
         with pytest.raises(NotImplementedError):
             DP.DynamicProgrammingWithLookUpTable(g_, cf_, dtype=dt, f32_feedback=True)
 
@@ -94,7 +93,7 @@ def test_flag_values_match_the_header_and_feedback_refusals_need_no_device():
     with pytest.raises(NotImplementedError):
         DP.DynamicProgrammingWithLookUpTable(c4["grid_sys"], c4["cf"], dtype="float64", comm=Comm(), f32_feedback=True)
     with pytest.raises(NotImplementedError):
-        DP.DynamicProgrammingWithLookUpTable(grob, crob, dtype="float32", comm=Comm(), f32_feedback=True)
+        DP.DynamicProgrammingWithLookUpTable(c2["grid_sys"], c2["cf"], dtype="float64", comm=Comm(), f32_feedback=True)
 
 
 def test_no_cpu_fallback_without_device():

@@ -922,16 +922,19 @@ def test_f32_error_feedback_storage_small():
     dfb._p.sweep(20, 1.0, -1.0)
     d32b._p.sweep(20, 1.0, -1.0)
     assert np.array_equal(dfb._p.get_J(), d32b._p.get_J())
-    # (v) refusals: float64 (class surface), and the library itself on a handle without an LDS-window float32 sweep (the n = 3
-    #     helicopter: plain gathers)
+    # (v) refusals: float64 and the table tier (class surface), and the library itself on a handle without a float32 production
+    #     sweep (the n = 3 helicopter with its mask sweep switched off: the plain float64-dynamics kernel)
     with pytest.raises(NotImplementedError):
         make("float64", True)
+    import table_case
     with contextlib.redirect_stdout(io.StringIO()):
+        tc = table_case.table_case()
         h3 = configs.build("h3s")
     with pytest.raises(NotImplementedError):
-        DP.DynamicProgrammingWithLookUpTable(h3["grid_sys"], h3["cf"], dtype="float32", f32_feedback=True)
-    with pytest.raises(_native.NativeError) as ei:
-        h3["grid_sys"]._device_problem(cost=DP.device_cost_of(h3["cf"], h3["sys"]), dtype="float32", flags=_native.FLAG_F32_FEEDBACK)
+        DP.DynamicProgrammingWithLookUpTable(tc["grid_sys"], tc["cf"], dtype="float32", f32_feedback=True)
+    with _native.overrides(NO_FAST="1"):
+        with pytest.raises(_native.NativeError) as ei:
+            h3["grid_sys"]._device_problem(cost=DP.device_cost_of(h3["cf"], h3["sys"]), dtype="float32", flags=_native.FLAG_F32_FEEDBACK)
     assert "PVI_FLAG_F32_FEEDBACK" in str(ei.value)
 
 
@@ -983,6 +986,41 @@ def test_f32_error_feedback_storage_on_2d_grids(name, sweeps, every):
     fresh = make("float32", True)
     fresh._p.sweep(40, 1.0, -1.0)
     assert np.array_equal(dfb._p.get_J(), fresh._p.get_J()) and np.array_equal(dfb._p.get_pi(), fresh._p.get_pi())
+
+
+def test_f32_error_feedback_storage_of_an_explicit_system():
+    """... and for the n = 3 systems (k_sweep3_fast: the reference's helicopter demo on a 101 x 101 x 201 grid, obstacles and
+    domain-check cost): every checkpoint within 1e-6 of float64, no worse than plain float32 storage, a restart clears the
+    residuals."""
+    from pyro_amd import configs
+    from pyro_amd.planning import dynamicprogramming as DP
+    with contextlib.redirect_stdout(io.StringIO()):
+        s, g, cf, _ = configs._helicopter((101, 101, 201), (11,), "float32")
+
+    def make(dt, fb=False):
+        with contextlib.redirect_stdout(io.StringIO()):
+            dp = DP.DynamicProgrammingWithLookUpTable(g, cf, dtype=dt, f32_feedback=fb)
+        dp.save_time_history = False
+        dp.verbose = False
+        return dp
+    d64, d32, dfb = make("float64"), make("float32"), make("float32", True)
+    assert "path=fast3" in dfb._p.describe() and "feedback=1" in dfb._p.describe() and "feedback=0" in d32._p.describe(), dfb._p.describe()
+    worst_fb = worst_plain = 0.0
+    for k in range(4):
+        for dp in (d64, d32, dfb):
+            dp._p.sweep(100, 1.0, -1.0)
+        J64 = d64._p.get_J()
+        m = np.abs(J64).max()
+        e_fb, e_plain = np.abs(dfb._p.get_J() - J64).max() / m, np.abs(d32._p.get_J() - J64).max() / m
+        worst_fb, worst_plain = max(worst_fb, e_fb), max(worst_plain, e_plain)
+        print("helicopter after %d sweeps: feedback %.3e plain %.3e" % (100 * (k + 1), e_fb, e_plain))
+        assert e_fb <= 1e-6, (k, e_fb)
+    assert worst_fb <= worst_plain * 1.05 + 1e-9
+    dfb.evaluate_terminal_cost()
+    dfb._p.sweep(30, 1.0, -1.0)
+    fresh = make("float32", True)
+    fresh._p.sweep(30, 1.0, -1.0)
+    assert np.array_equal(dfb._p.get_J(), fresh._p.get_J())
 
 
 def test_f32_error_feedback_storage_through_the_node_table_tier():
