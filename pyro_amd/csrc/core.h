@@ -595,6 +595,22 @@ __device__ inline void block_max3_store(double j, double dmax, double ndmin, dou
     }
 }
 
+#define MULTI_MAX_WG 512  // workgroups of a multi-sweep launch (statistics records per set)
+
+// The same barrier for data that is published WRITE-THROUGH (sc1 stores: they leave the XCD's L2 for memory) and read with
+// sc1 loads (which bypass the CU's L1): no L2 write-back, no invalidate -- the two fences are 1.7 us each
+// (MI355X_MICROARCH.md, inter-workgroup visibility: producer "sc1 payload -> asm vmcnt(0) -> flag", consumer "sc1 loads may
+// replace the acquire only when the producer stored sc1").  Every thread waits for its own stores to have left.
+__device__ __forceinline__ void grid_barrier_wt(unsigned* counter, unsigned target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+}
+
 __device__ inline void block_stats(double j, double dmax, double ndmin, unsigned long long* slot) {
     __shared__ double red[3][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;

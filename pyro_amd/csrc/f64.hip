@@ -122,22 +122,6 @@ __device__ __forceinline__ void fold_records(double a0, double a1, double a2, do
     __syncthreads();
 }
 
-#define MULTI_MAX_WG 512  // workgroups of a multi-sweep launch (statistics records per set)
-
-// The same barrier for data that is published WRITE-THROUGH (sc1 stores: they leave the XCD's L2 for memory) and read with
-// sc1 loads (which bypass the CU's L1): no L2 write-back, no invalidate -- the two fences are 1.7 us each
-// (MI355X_MICROARCH.md, inter-workgroup visibility: producer "sc1 payload -> asm vmcnt(0) -> flag", consumer "sc1 loads may
-// replace the acquire only when the producer stored sc1").  Every thread waits for its own stores to have left.
-__device__ __forceinline__ void grid_barrier_wt(unsigned* counter, unsigned target) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-    }
-    __syncthreads();
-}
-
 // MULTI (round 4): the device form of the driver loops dynamicprogramming.py:265-314 for grids whose
 // workgroups are all resident.  ONE launch runs up to `nsweeps` backups: everything of a node that does not change between
 // sweeps (coordinates, position row, weights, dynamics prologue) stays in its thread's registers, J ping-pongs between the

@@ -228,6 +228,7 @@ struct pvi_problem {
     const double* roll_params = nullptr;  // constants of the continuous closed form (pvi_set_rollout_params)
     SplineP SP;               // bicubic-spline interpolation mode (sweep_spline.inc)
     bool spline = false;
+    int multi32 = -1;         // multi-sweep launch of the 2-D float32 sweep (k_sweep_leanm): -1 not decided, 0 no, 1 yes
     int multi64 = -1;         // multi-sweep launch of the float64 sweep (k_sweep64m): -1 not decided, 0 no, 1 yes
     char multi_why[96] = "";
     int multi_rtm = 0;            // ... 1 / 2: in its register-table form, narrow / wide (2-D grids, <= 12 / 24 actions, <= 64 / 512 workgroups)
@@ -313,5 +314,7 @@ PVI_INTERNAL int launch_fast(pvi_problem* h, const float* Jin, float* Jout, floa
 // f64.hip: float64 second form (k_sweep64, k_sweep64m) and the validity masks of the sparse walks
 PVI_INTERNAL int launch_f64v2(pvi_problem* h, const double* Jin, double* Jout, double alpha, hipStream_t st, SweepCtl sc);
 PVI_INTERNAL int launch_valid_mask(pvi_problem* h, uint4* vm, unsigned long long* cnt);
+PVI_INTERNAL bool multi32_applies(pvi_problem* h);   // lean.hip: k_sweep_leanm
+PVI_INTERNAL int launch_multi32(pvi_problem* h, int src, double alpha, double tol, int nsweeps);
 PVI_INTERNAL bool multi64_applies(pvi_problem* h);
 PVI_INTERNAL int launch_multi64(pvi_problem* h, int src, double alpha, double tol, int nsweeps);

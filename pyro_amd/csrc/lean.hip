@@ -1311,6 +1311,70 @@ static int launch_lean2_t(pvi_problem* h, const float* Jin, float* Jout, float a
         }
     }
 }
+// ---- multi-sweep launch of the 2-D float32 sweep (sweep_lean.inc k_sweep_leanm) ---------------------------------------------
+template <typename PI_T>
+static const void* multi32_kernel(int dyn, bool uniform) {
+    if (dyn == PVI_DYN_PENDULUM)
+        return uniform ? (const void*)k_sweep_leanm<PVI_DYN_PENDULUM, PI_T, true> : (const void*)k_sweep_leanm<PVI_DYN_PENDULUM, PI_T, false>;
+    if (dyn == PVI_DYN_NODE_1x1)
+        return uniform ? (const void*)k_sweep_leanm<PVI_DYN_NODE_1x1, PI_T, true> : (const void*)k_sweep_leanm<PVI_DYN_NODE_1x1, PI_T, false>;
+    return nullptr;
+}
+static const void* multi32_kernel_of(pvi_problem* h) {
+    const bool uniform = h->LP.lsplit == 0;
+    return h->pi_size == 1 ? multi32_kernel<unsigned char>(h->d.dynamics_id, uniform) : multi32_kernel<unsigned short>(h->d.dynamics_id, uniform);
+}
+// Where it applies: the 2-D LDS-window sweep of a one-input system, one node per thread, plain storage, whole grid, and every
+// workgroup of the sweep resident at once (at most MULTI_MAX_WG: each reads every workgroup's statistics record behind the
+// barrier).  C2' (201 x 201 x 201, 158 workgroups) takes it; C2 (1001 x 1001: 2 016 workgroups) does not fit the device at once
+// and keeps one launch per sweep with the deferred fold.  pvi_override("MULTI", "0") keeps one launch per sweep.
+bool multi32_applies(pvi_problem* h) {
+    if (h->multi32 >= 0) return h->multi32 == 1 && !h->jlo && !h->force_exact;
+    h->multi32 = 0;
+    auto no = [&](const char* why) {
+        snprintf(h->multi_why, sizeof(h->multi_why), "%s", why);
+        return false;
+    };
+    if (ovr_is("MULTI", 0)) return no("MULTI=0");
+    if (h->d.dtype != PVI_F32 || !h->lean_ok || h->lean4_ok || h->spline || h->P.dof != 1 || h->d.m != 1 || h->LP.npt != 1)
+        return no("not the 2-D float32 window sweep with one node per thread");
+    if (h->P.store_begin != 0 || h->P.store_end != h->P.dim[0] || h->P.row_begin != 0 || h->P.row_end != h->P.dim[0]) return no("a slab");
+    const void* kfn = multi32_kernel_of(h);
+    if (!kfn) return no("dynamics");
+    if (h->lean_grid.y != 1 || h->lean_grid.z != 1 || h->lean_grid.x > (unsigned)MULTI_MAX_WG) return no("more than 512 workgroups");
+    int coop = 0, per_cu = 0, ncu = 0;
+    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, h->device) != hipSuccess || !coop) return no("no cooperative launch");
+    if (h->lean_lds > 48 * 1024 && hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PVI_LDS_MAX) != hipSuccess) return no("LDS attribute");
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, (int)h->lean_block, h->lean_lds) != hipSuccess) return no("occupancy query");
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) return no("device query");
+    if ((long long)h->lean_grid.x > (long long)per_cu * ncu) return no("more workgroups than are resident");
+    h->multi32 = 1;
+    return !h->jlo && !h->force_exact;
+}
+int launch_multi32(pvi_problem* h, int src, double alpha, double tol, int nsweeps) {
+    SweepCtl sc;
+    memset(&sc, 0, sizeof(sc));
+    sc.ctrl = h->ctrl;
+    sc.slot = h->slots;
+    sc.result = h->results;
+    sc.tol = tol;
+    sc.nblocks = h->lean_grid.x;
+    const void* kfn = multi32_kernel_of(h);
+    DevP P = h->P;
+    LeanP LP = h->LP;
+    LP.jlo = nullptr;
+    const float4* actp = h->F.act;
+    const float* actc = h->LP.actc;
+    float* J0 = (float*)h->J[src];
+    float* J1 = (float*)h->J[src ^ 1];
+    void* pi = h->pi;
+    float al = (float)alpha;
+    void* args[] = {&P, &LP, &actp, &actc, &J0, &J1, &pi, &al, &sc, &nsweeps};
+    set_kname(h, "k_sweep_leanm", (int)h->d.dynamics_id, h->pi_size == 1 ? tname<unsigned char>() : tname<unsigned short>(), h->LP.lsplit == 0);
+    HIPCHK(hipLaunchCooperativeKernel(kfn, h->lean_grid, dim3(h->lean_block), args, (unsigned)h->lean_lds, h->stream));
+    return PVI_OK;
+}
+
 int launch_lean2(pvi_problem* h, const float* Jin, float* Jout, float alpha, hipStream_t st, SweepCtl sc) {
     return h->pi_size == 1 ? launch_lean2_t<unsigned char>(h, Jin, Jout, alpha, st, sc) : launch_lean2_t<unsigned short>(h, Jin, Jout, alpha, st, sc);
 }

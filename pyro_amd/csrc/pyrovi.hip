@@ -1951,11 +1951,11 @@ static int describe_impl(pvi_handle h, char* buf, int32_t n) {
                  h->jlo ? 1 : 0, h->L4.vmask ? 1 : 0, h->lean4_choice, h->L4.ntr, h->lean4_bands, h->lean4_cands[0] ? h->lean4_cands : "-", h->lean_why);
         return PVI_OK;
     }
-    snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d npt=%d reach=%d opmag=%d sparse=%d win=0 tables=0 feedback=%d note=%s",
+    snprintf(buf, (size_t)n, "path=%s tile=%dx%d grid=%ux%ux%u block=%d pw1=%d lds_bytes=%zu lsplit=%d tb_tile=%d dma16=%d npt=%d reach=%d opmag=%d sparse=%d win=0 tables=0 feedback=%d multi=%d note=%s",
              path, h->LP.TV0, h->LP.TV1, h->lean_grid.x, h->lean_grid.y, h->lean_grid.z, h->lean_block, h->lean_pw1,
              h->lean_lds, h->lean_ok ? h->LP.lsplit : h->F.lsplit, h->LP.tb_tile, h->lean_ok ? h->LP.dma16 : 0,
              h->lean_ok ? h->LP.npt : 1, h->lean_reach, h->lean_opmag,
-             (h->d.dtype == PVI_F32 && h->sparse64 && h->vmask) ? 1 : 0, h->jlo ? 1 : 0, h->lean_why);
+             (h->d.dtype == PVI_F32 && h->sparse64 && h->vmask) ? 1 : 0, h->jlo ? 1 : 0, h->multi32 == 1 ? 1 : 0, h->lean_why);
     return PVI_OK;
 }
 
@@ -2332,6 +2332,9 @@ extern "C" int pvi_sweep(pvi_handle h, int32_t max_sweeps, double alpha, double 
         int src = h->cur;
         if (multi64_applies(h)) {  // ONE launch for the batch: grid barriers between the sweeps, the stop test on the device
             int rc = launch_multi64(h, src, alpha, tol, nb);
+            if (rc) return rc;
+        } else if (multi32_applies(h)) {  // ... the 2-D float32 window sweep likewise (k_sweep_leanm)
+            int rc = launch_multi32(h, src, alpha, tol, nb);
             if (rc) return rc;
         } else {
             // 2-D float32 LDS-window sweep: deferred fold -- sweep k folds sweep k - 1, one k_sweep_finish for the batch's last
