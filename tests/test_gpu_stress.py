@@ -155,9 +155,10 @@ def test_multi_sweep_launch_of_the_2d_float32_sweep_is_bit_identical(name):
     J, pi, every sweep's statistics and the stop sweep are the same bits -- fixed counts in odd batch sizes, then a tolerance
     stop in the middle of a batch, then a restart."""
     from pyro_amd import _native
-    m = _dp(name)._p
-    sm, nm = m.sweep(1, 1.0, -1.0)
-    with _native.overrides(MULTI="0"):                        # (the form of a handle's batches is decided at its first sweep)
+    with _native.overrides(MULTI32="1"):                      # (the form of a handle's batches is decided at its first sweep)
+        m = _dp(name)._p
+        sm, nm = m.sweep(1, 1.0, -1.0)
+    with _native.overrides(MULTI="0"):
         s = _dp(name)._p
         ss, ns = s.sweep(1, 1.0, -1.0)
     assert "multi=1" in m.describe() and "kernel=k_sweep_leanm<" in m.describe(), m.describe()
