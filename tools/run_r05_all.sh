@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 5, ONE call for a GPU window of unknown length: (1) the code written while the boxes were closed, safest first
+# (tools/run_r05_validate.sh), (2) the whole GPU suite, (3) the round's profiles and counters (tools/tools_profile.sh).
+# Every stage under its own timeout; the summaries land in gpurun_out/ as each stage ends.
+cd /root/repo; mkdir -p gpurun_out
+bash tools/run_r05_validate.sh > gpurun_out/r05_validate.out 2>&1; tail -8 gpurun_out/r05_validate.out
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/r05_gputests.log 2>&1; echo "suite rc=$? :: $(tail -1 gpurun_out/r05_gputests.log)"
+PVI_ROUND=r05 timeout 2400 bash tools/tools_profile.sh > gpurun_out/r05_profile.out 2>&1; tail -5 gpurun_out/r05_profile.out
