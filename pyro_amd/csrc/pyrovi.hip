@@ -650,7 +650,7 @@ __global__ __launch_bounds__(256) void k_sweep3_fast(DevP P, const float* __rest
                 const double g = on_target ? 0.0 : (node_bad ? P.INF : (gx + gutab[arg]));
                 const double t = __builtin_fma(alpha64, Jn, ok ? g * P.dt : P.INF) + (double)lo_old;
                 best = (float)t;
-                if (t < INFINITY && t > -INFINITY) lo_new = (float)(t - (double)best);
+                if (best < INFINITY && best > -INFINITY) lo_new = (float)(t - (double)best);   // (an INF beyond float32 leaves no residual)
             }
             jlo[o] = lo_new;
         }

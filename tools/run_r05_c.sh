@@ -7,6 +7,8 @@ for rep in 1 2 3; do
    echo "== $w [$ov]" >> $L
    timeout 300 python tools/tools_time.py $w $n $ov 2>&1 | grep -E "TIME" | cut -c1-120 >> $L
   done
+  echo "== $w [ablate-uniform]" >> $L
+  PYROVI_LIB=/root/repo/pyro_amd/libpyrovi_ablate.so timeout 300 python tools/tools_time.py $w $n 2>&1 | grep -E "TIME" | cut -c1-120 >> $L
   echo "== $w [base]" >> $L
   PYROVI_LIB=/root/repo/pyro_amd/libpyrovi_base.so timeout 300 python tools/tools_time.py $w $n 2>&1 | grep -E "TIME" | cut -c1-120 >> $L
  done
