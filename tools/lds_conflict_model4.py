@@ -8,6 +8,12 @@ cycle per group when no two DISTINCT slots of the group fall on the same pair of
  * the row pitch:  a fixed multiple of 4 >= window width, a multiple of 32, or congruent to ncols modulo 32
 and reports cycles x waves (the LDS time of the tile's action loop, relative).
 
+Round 5 adds the TRANSPOSED lane map (`model_t`): on the cart-pole the displacement of a node does not depend on its index along
+axis 2 (cartpole.py:369-437: the acceleration is a function of theta, dtheta and the input), so lanes that run along axis 2
+-- window stored with axis 2 fastest -- all shift by the same amount and a 32-lane group that lies in ONE window column reads 32
+consecutive slots: no conflict at any pitch.  Groups that straddle two columns are conflict-free when the column pitch is
+congruent to the tile's rows modulo 32.  Not built: the model says what the layout would buy.
+
     python tools/lds_conflict_model4.py
 """
 import numpy as np
@@ -92,6 +98,44 @@ def model(rows, ncols, lane_w, pitch, samples=60, seed=1):
     return cyc / instr, waves * 64 / nodes, cyc / nodes * 64 / A, lds
 
 
+def model_t(rows, ncols, pitch, samples=60, seed=1):
+    """lanes along axis 2 (lane s -> column s / rows, row s % rows); LDS slot = window column * pitch + window row;
+    pitch(window rows, tile rows) -> slots per window column"""
+    rng = np.random.default_rng(seed)
+    cyc = instr = waves = nodes = 0
+    lds = 0
+    for _ in range(samples):
+        i1 = rng.integers(0, N)
+        t2 = rng.integers(0, (N + rows - 1) // rows) * rows
+        t3 = rng.integers(0, (N + ncols - 1) // ncols) * ncols
+        r2, r3 = np.arange(t2, min(N, t2 + rows)), np.arange(t3, min(N, t3 + ncols))
+        f2, f3, inb = cells(i1, r2, r3)
+        if not inb.any():
+            continue
+        lo2, lo3 = f2[inb].min(), f3[inb].min()
+        ps = pitch(f2[inb].max() + 2 - lo2, len(r2))
+        lds = max(lds, (f3[inb].max() + 2 - lo3) * ps * 8)
+        slot = ((f3 - lo3) * ps + (f2 - lo2)).reshape(len(r2) * len(r3), A)
+        live = inb.reshape(len(r2) * len(r3), A)
+        n2, n3 = len(r2), len(r3)
+        lane_node = np.full(((n2 * n3 + 63) // 64) * 64, -1)
+        lane_node[:n2 * n3] = (np.arange(n2)[None, :] * n3 + np.arange(n3)[:, None]).reshape(-1)   # column-major over the tile
+        nodes += n2 * n3
+        for wv in range(len(lane_node) // 64):
+            ids = lane_node[wv * 64:(wv + 1) * 64]
+            ok = ids >= 0
+            if not ok.any():
+                continue
+            waves += 1
+            for a in range(A):
+                lv = ok & live[np.maximum(ids, 0), a]
+                if not lv.any():
+                    continue
+                cyc += group_cycles(slot[np.maximum(ids, 0), a], lv)
+                instr += 1
+    return cyc / instr, waves * 64 / nodes, cyc / nodes * 64 / A, lds
+
+
 if __name__ == "__main__":
     mul4 = lambda w, n: max(4, (w + 3) // 4 * 4)
     mul32 = lambda w, n: (w + 31) // 32 * 32
@@ -112,4 +156,17 @@ if __name__ == "__main__":
         ("15x34 dense, pitch = ncols mod 32", 15, 34, 0, cong),
     ]:
         c, l, t, b = model(rows, ncols, lw, pitch)
+        print("%-44s %8.2f %8.2f %10.2f %8d" % (name, c, l, t, b))
+    odd = lambda w, n: w | 1
+    congt = lambda w, n: next(r for r in range(w, w + 33) if r % 32 == n % 32)
+    for name, rows, ncols, pitch in [
+        ("T 10x51, pitch odd", 10, 51, odd),
+        ("T 10x51, pitch = rows mod 32", 10, 51, congt),
+        ("T 19x26, pitch odd", 19, 26, odd),
+        ("T 19x26, pitch = rows mod 32", 19, 26, congt),
+        ("T 16x32, pitch = rows mod 32", 16, 32, congt),
+        ("T 32x16, pitch odd (a group = one column)", 32, 16, odd),
+        ("T 34x15, pitch = rows mod 32", 34, 15, congt),
+    ]:
+        c, l, t, b = model_t(rows, ncols, pitch)
         print("%-44s %8.2f %8.2f %10.2f %8d" % (name, c, l, t, b))
