@@ -6,3 +6,4 @@ cd /root/repo; mkdir -p gpurun_out
 bash tools/run_r05_validate.sh > gpurun_out/r05_validate.out 2>&1; tail -8 gpurun_out/r05_validate.out
 timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/r05_gputests.log 2>&1; echo "suite rc=$? :: $(tail -1 gpurun_out/r05_gputests.log)"
 PVI_ROUND=r05 timeout 2400 bash tools/tools_profile.sh > gpurun_out/r05_profile.out 2>&1; tail -5 gpurun_out/r05_profile.out
+timeout 900 bash tools/run_writecal.sh > gpurun_out/r05_writecal.out 2>&1; tail -12 gpurun_out/r05_writecal.out
