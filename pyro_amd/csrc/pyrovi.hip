@@ -1822,7 +1822,6 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
             if ((r = dev_alloc(h, (size_t)h->owned, &vm))) return r;
             if ((r = dev_alloc(h, 1, &cnt))) return r;
             HIPCHK(hipMemsetAsync(cnt, 0, sizeof(*cnt), h->stream));
-            const unsigned gm = grid_for(h->owned);
             if ((r = launch_valid_mask(h, vm, cnt))) return r;  // (f64.hip)
             HIPCHK(hipGetLastError());
             unsigned long long inside = 0;
