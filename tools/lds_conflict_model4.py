@@ -170,3 +170,18 @@ if __name__ == "__main__":
     ]:
         c, l, t, b = model_t(rows, ncols, pitch)
         print("%-44s %8.2f %8.2f %10.2f %8d" % (name, c, l, t, b))
+    # the cart-pole with q = (theta, x) (tools/tools_swapped_cartpole.py): tile rows run along dtheta, lanes along dx -- TODAY'S kernel and
+    # lane map, the displacement now the same for every lane of a tile row
+    reference_order = cells
+    def cells_swapped(i1, r2, r3):
+        f2, f3, inb = reference_order(i1, r3, r2)
+        return f3.transpose(1, 0, 2), f2.transpose(1, 0, 2), inb.transpose(1, 0, 2)
+    globals()["cells"] = cells_swapped
+    for name, rows, ncols, pitch in [
+        ("swapped q: 10x51, pitch = ncols mod 32", 10, 51, cong),
+        ("swapped q: 19x26, pitch = ncols mod 32", 19, 26, cong),
+        ("swapped q: 15x34, pitch = ncols mod 32", 15, 34, cong),
+        ("swapped q: 10x51, pitch mult of 4", 10, 51, mul4),
+    ]:
+        c, l, t, b = model(rows, ncols, 0, pitch)
+        print("%-44s %8.2f %8.2f %10.2f %8d" % (name, c, l, t, b))
