@@ -93,7 +93,7 @@ struct Lean4P {
     float* ptab;            // [owned position nodes][ngroups][24]: Pf0[4] Pf1[4] off[4] gudt[4] Pi0[4] Pi1[4]
     int ngroups;            // ceil(A / 4)
     int pcs[2];             // strides (in position nodes) of ptab over (owned row of axis 0, axis 1): 0 = does not depend on it
-    int RS;                 // slots (8 bytes) per window row: >= longest row rounded up to 4, congruent to TV1 modulo 32
+    int RS;                 // slots (8 bytes) per window row: the longest window row of the tiling rounded up to 4
     int* summary;           // [0] max window rows (pair planes x p1 x j2), [1] longest row, [3] error bits, [4] max pair planes,
                             // [7] some node's cell range does not fit `box`
     const char4* box;       // per owned node: the velocity cells its actions reach, relative to (iv0, iv1) -- set-up only

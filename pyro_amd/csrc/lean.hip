@@ -508,6 +508,8 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
     // all of them; tools/ldsgather.hip: a row wrap or a displacement step inside a wave costs a ds_read_b64 4.3 -> 5.0 clk at
     // worst, whatever the pitch -- the 4.4 clk of the conflict-free read is what counts.)
     int rs = std::max(4, (summary[1] + 3) & ~3);
+    if (ovr_is("RS_CONG", 1) && !(tv1 & 1))   // experiments: the pitch congruent to the (even) width of the widest tile modulo 32; 16-byte
+        while ((rs - tv1) & 31) rs += 2;       // fill stores need an even pitch
     size_t lds = (size_t)std::max(summary[0], 1) * (size_t)rs * 8 + 256;
     if (narrower) {  // the widest tile whose window lets as many workgroups onto a CU as the register budget does (24 waves)
         *narrower = 0;

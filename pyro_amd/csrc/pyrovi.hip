@@ -1374,6 +1374,7 @@ static const char* const OVERRIDE_KEYS[] = {
     "JWIN",        // 0: the register-table sweeps gather J from memory instead of the workgroup's LDS window
     "REGTAB",      // 0: the multi-sweep launch of 2-D grids recomputes the per-action cells every sweep (fence-based barrier)
     "VMASK",       // 0: the 4-D float32 window sweep clamps and compares cell indices instead of reading set-up's validity bits
+    "RS_CONG",     // 1: 4-D float32 window sweep, row pitch congruent to the widest tile's (even) width modulo 32 (bank experiments)
     "MULTI32",     // 1: batches of the 2-D float32 window sweep as one cooperative launch (k_sweep_leanm; opt-in until measured)
     "MULTI",       // 0: one launch per sweep also where a batch could run as ONE multi-sweep launch (k_sweep64m)
 };

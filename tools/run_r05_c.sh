@@ -17,5 +17,10 @@ paste - - < $L | awk '{print $2,$3,$(NF-1)}'
 # the cart-pole with its coordinates swapped (lanes along the axis the displacement does not depend on): tools/tools_swapped_cartpole.py
 S=gpurun_out/r05_swapped.log; : > $S
 timeout 300 python tools/tools_swapped_cartpole.py 31 21 20 check 2>&1 | grep -E "TIME|J after|nodes" | cut -c1-400 >> $S
-for rep in 1 2; do timeout 600 python tools/tools_swapped_cartpole.py 101 21 200 2>&1 | grep -E "TIME|nodes" | cut -c1-400 >> $S; done
+for rep in 1 2; do
+  timeout 600 python tools/tools_swapped_cartpole.py 101 21 200 2>&1 | grep -E "TIME|nodes" | cut -c1-400 >> $S
+  # (both orders with one pinned tiling of even width, the pitch as today and congruent to the width modulo 32)
+  timeout 600 python tools/tools_swapped_cartpole.py 101 21 200 TV0=15 TV1=34 2>&1 | grep -E "TIME|nodes" | cut -c1-400 >> $S
+  timeout 600 python tools/tools_swapped_cartpole.py 101 21 200 TV0=15 TV1=34 RS_CONG=1 2>&1 | grep -E "TIME|nodes" | cut -c1-400 >> $S
+done
 grep -E "TIME|J after" $S
