@@ -738,7 +738,7 @@ static int lean4_setup(pvi_problem* h) {
     // input only (cartpole.py:369-437: H, C, g depend on q[1] and dq[1]; no damping term) -- axes 0 and 2 drop out.  The kernel
     // that FINDS the invariant axes (every node against the node at index 0 of each axis: 66 GB of cache traffic, 93 ms of C4's
     // create) runs for the dynamics that do not declare them, and with TABLES=2 (the variants test holds the declaration to it).
-    const int declared = h->d.dynamics_id == PVI_DYN_CARTPOLE ? 0x5 : -1;
+    const int declared = h->d.dynamics_id == PVI_DYN_CARTPOLE ? (h->d.dyn_params[5] != 0.0 ? 0xA : 0x5) : -1;   // (q = (theta, x): axes 1 and 3)
     if (want_tables && declared >= 0 && !ovr_is("TABLES", 2)) {
         inv = declared;
     } else if (want_tables) {

@@ -1146,7 +1146,7 @@ __global__ void k_eval_f(const double* __restrict__ c16, long long B, const doub
     for (int d = 0; d < N; ++d) x[d] = X[b * N + d];
 #pragma unroll
     for (int k = 0; k < M; ++k) u[k] = U[b * M + k];
-    D::trig_from_state(x, tr);
+    dyn_trig_from_state<DYN>(c, x, tr);
     D dyn;
     dyn.init(c, x, tr);
     dyn.accel(u, acc);
@@ -1212,7 +1212,7 @@ struct RollMech {
     __device__ static void f(const DevP& P, const double*, const double* x, const double* u, double* dx) {
         constexpr int DOF = Dyn<DYN>::DOF;
         double tr[8], acc[DOF];
-        Dyn<DYN>::trig_from_state(x, tr);
+        dyn_trig_from_state<DYN>(P.c, x, tr);
         Dyn<DYN> dyn;
         dyn.init(P.c, x, tr);
         dyn.accel(u, acc);
@@ -1697,7 +1697,8 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
     if (d->dynamics_id == PVI_DYN_PENDULUM) {
         if ((rc = table(0, 0, fsin))) return bail(rc);
     } else if (d->dynamics_id == PVI_DYN_CARTPOLE) {
-        if ((rc = table(0, 1, fcos)) || (rc = table(1, 1, fsin))) return bail(rc);
+        const int th = d->dyn_params[5] != 0.0 ? 0 : 1;   // (the angle's axis: core.h Dyn<PVI_DYN_CARTPOLE>::swapped)
+        if ((rc = table(0, th, fcos)) || (rc = table(1, th, fsin))) return bail(rc);
     } else if (d->dynamics_id == PVI_DYN_TWOLINK) {
         if ((rc = table(0, 0, fsin)) || (rc = table(1, 1, fcos)) || (rc = table(2, 1, fsin))) return bail(rc);
         std::vector<double> t((size_t)d->x_dim[0] * d->x_dim[1]);

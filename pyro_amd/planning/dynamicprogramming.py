@@ -70,9 +70,18 @@ class DynamicProgramming:
                                     # within ~2e-7 of the float64 ones over thousands of sweeps (plain float32 storage: up to
                                     # 1.5e-5 mid-solve on BASELINE configs[2]; INTEGRATION.md, accuracy contract)
 
-    def __init__(self, grid_sys, cost_function, final_time=0, dtype="float64", device=0, comm=None, f32_feedback=None):
+    INTERNAL_ORDER = "reference"    # "swapped": the cart-pole in float32 with q = (theta, x) inside the engine -- the lanes of the 4-D
+                                    # window sweep then run along the axis the displacement does not depend on; J and pi keep the
+                                    # reference's node order at this surface (pyro_amd/planning/permuted.py; opt-in, round 5)
+
+    def __init__(self, grid_sys, cost_function, final_time=0, dtype="float64", device=0, comm=None, f32_feedback=None,
+                 internal_order=None):
         if f32_feedback is not None:
             self.F32_FEEDBACK = bool(f32_feedback)
+        if internal_order is not None:
+            if internal_order not in ("reference", "swapped"):
+                raise ValueError("internal_order: 'reference' or 'swapped'")
+            self.INTERNAL_ORDER = internal_order
         self.grid_sys, self.sys = grid_sys, grid_sys.sys
         self.cf, self.tf = cost_function, final_time
         self.alpha = 1.0
@@ -142,6 +151,8 @@ class DynamicProgramming:
     def _make_engine(self):
         self._host = {}             # cached downloads: 'J', 'pi', 'J_next'
         self._dirty = False         # host J newer than the device copy
+        if self.INTERNAL_ORDER == "swapped" and (self.comm is not None or self.INTERPOLATION != "linear"):
+            raise NotImplementedError("internal_order='swapped': one GPU, linear interpolation")
         if self.comm is not None:
             if self.INTERPOLATION != "linear":
                 raise NotImplementedError("the spline fit couples every row of the grid: single-GPU only")
@@ -165,10 +176,19 @@ class DynamicProgramming:
             if self.F32_FEEDBACK and not self._feedback_applies():
                 raise NotImplementedError("f32_feedback is the float32 storage mode of the LDS-window sweeps: 4-D grids, and 2-D grids "
                                           "with one input (dtype %s, n = %d, m = %d)" % (self.dtype, self.sys.n, self.sys.m))
-            self._p = self.grid_sys._device_problem(cost=cost, dtype=self.dtype, device=self.device,
-                                                    flags=(_native.FLAG_HARD_INF if self.HARD_INF else 0)
-                                                    | (_native.FLAG_F32_FEEDBACK if self.F32_FEEDBACK else 0))
+            flags = (_native.FLAG_HARD_INF if self.HARD_INF else 0) | (_native.FLAG_F32_FEEDBACK if self.F32_FEEDBACK else 0)
+            if self.INTERNAL_ORDER == "swapped":
+                from pyro_amd.planning import permuted
+                if not permuted.swap_applies(self.sys, dd, self.dtype):
+                    raise NotImplementedError("internal_order='swapped' is the stock cart-pole's closed form in float32 (%s, %s)"
+                                              % (type(self.sys).__name__, self.dtype))
+                kw = self.grid_sys._problem_kwargs(cost, self.dtype, device=self.device, flags=flags)
+                self._p = permuted.SwappedProblem(_native.Problem(**permuted.swap_problem_kwargs(kw)), self.grid_sys.x_grid_dim)
+            else:
+                self._p = self.grid_sys._device_problem(cost=cost, dtype=self.dtype, device=self.device, flags=flags)
         else:
+            if self.INTERNAL_ORDER == "swapped":
+                raise NotImplementedError("internal_order='swapped': the fused tier only (this problem runs on the table tier)")
             if self.F32_FEEDBACK:
                 raise NotImplementedError("f32_feedback: the fused tier only (this problem runs on the table tier)")
             g, s = self.grid_sys, self.sys
