@@ -417,7 +417,8 @@ class DynamicProgramming:
         (controller.py:328-355, simulation.py:298-324).  Returns t [n], X [B,n,sys.n], U [B,n,sys.m]."""
         dt = (tf + 0.0) / (n - 1)
         t = np.linspace(0, tf, n)
-        closed_form = self.tier == "fused" and not self.sharded and self._p.dynamics_id in _native.ROLLOUT_IDS
+        closed_form = (self.tier == "fused" and not self.sharded and self._p.dynamics_id in _native.ROLLOUT_IDS
+                       and not getattr(self._p, "swapped", False))    # (a swapped engine: the host loop below, in the reference's order)
         rp = self.sys.device_rollout_params() if (closed_form and hasattr(self.sys, "device_rollout_params")) else ()
         if rp is None:
             closed_form = False                 # e.g. a quarter car with its own terrain: arbitrary Python again
