@@ -10,7 +10,6 @@ t stress 600 tests/test_gpu_stress.py -k "not 2d_float32"
 t variants 900 tests/test_gpu_parity.py -k "variants or self_check"
 t fb4 900 tests/test_gpu_parity.py -k "feedback_storage_small or two_ranks_share_one_gpu"
 t fb2 900 tests/test_gpu_parity.py -k "feedback_storage_on_2d or node_table_tier or explicit_system"
-t multi32 600 tests/test_gpu_stress.py -k "2d_float32"
 t swapped 900 tests/test_gpu_parity.py -k "swapped_internal_order"
 bash tools/run_r05_c.sh > $O/ab.log 2>&1; tail -20 $O/ab.log
 cat $O/summary.log
