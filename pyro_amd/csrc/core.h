@@ -638,6 +638,30 @@ __device__ __forceinline__ void grid_barrier_wt(unsigned* counter, unsigned targ
     __syncthreads();
 }
 
+// ... with a bound on the wait (about a second): false = the other workgroups never arrived.  For a kernel that has not yet proven
+// itself on hardware (k_sweep_leanm, written while the GPU boxes were closed): a wrong arrival count must end as an error code of
+// pvi_sweep, not as a GPU that spins until it is reset.
+__device__ __forceinline__ bool grid_barrier_wt_bounded(unsigned* counter, unsigned target) {
+    __shared__ int s_arrived;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24)) {
+                ok = 0;
+                break;
+            }
+        }
+        s_arrived = ok;
+    }
+    __syncthreads();
+    return s_arrived != 0;
+}
+
 __device__ inline void block_stats(double j, double dmax, double ndmin, unsigned long long* slot) {
     __shared__ double red[3][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
