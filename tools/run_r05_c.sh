@@ -3,7 +3,8 @@ cd /root/repo; mkdir -p gpurun_out; L=gpurun_out/r05_c.log; : > $L
 for rep in 1 2 3; do
  for w in c3 c4; do
   n=200; [ $w = c4 ] && n=40
-  for ov in "" "VMASK=0" "ORDER=swapped" "ORDER=swapped RS_CONG=1"; do
+  E="TV0=15 TV1=34"; [ $w = c4 ] && E="TV0=13 TV1=38"      # (an even tile width: RS_CONG applies)
+  for ov in "" "VMASK=0" "ORDER=swapped" "$E" "ORDER=swapped $E" "ORDER=swapped $E RS_CONG=1"; do
    echo "== $w [$ov]" >> $L
    timeout 300 python tools/tools_time.py $w $n $ov 2>&1 | grep -E "TIME" | cut -c1-120 >> $L
   done
