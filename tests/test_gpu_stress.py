@@ -145,44 +145,3 @@ def test_multi_sweep_launch_under_stress():
                 assert np.array_equal(hm.get_J(), hs_.get_J()) and np.array_equal(hm.get_pi(), hs_.get_pi()), b
     for h in multi + single:
         h.close()
-
-
-@pytest.mark.parametrize("name", ["pendulum:201,201:201:float32", "pendulum:201,201:21:float32", "pendulum:101,101:11:float32",
-                                  "pendulum:301,151:51:float32"])
-def test_multi_sweep_launch_of_the_2d_float32_sweep_is_bit_identical(name):
-    """Round 5: batches of the 2-D float32 window sweep as ONE cooperative launch (k_sweep_leanm: write-through
-    J, fence-free grid barrier, statistics records folded by every workgroup) against one launch per sweep (pvi_override MULTI=0):
-    J, pi, every sweep's statistics and the stop sweep are the same bits -- fixed counts in odd batch sizes, then a tolerance
-    stop in the middle of a batch, then a restart."""
-    from pyro_amd import _native
-    with _native.overrides(MULTI32="1"):                      # (the form of a handle's batches is decided at its first sweep)
-        m = _dp(name)._p
-        sm, nm = m.sweep(1, 1.0, -1.0)
-    with _native.overrides(MULTI="0"):
-        s = _dp(name)._p
-        ss, ns = s.sweep(1, 1.0, -1.0)
-    assert "multi=1" in m.describe() and "kernel=k_sweep_leanm<" in m.describe(), m.describe()
-    assert "multi=0" in s.describe() and "kernel=k_sweep_lean<" in s.describe(), s.describe()
-    assert np.array_equal(np.array(sm), np.array(ss))
-    for n in (1, 2, 3, 7, 40, 5, 64, 9):
-        sm, nm = m.sweep(n, 1.0, -1.0)
-        ss, ns = s.sweep(n, 1.0, -1.0)
-        assert nm == ns == n and np.array_equal(np.array(sm), np.array(ss)), n
-        assert np.array_equal(m.get_J(), s.get_J()) and np.array_equal(m.get_pi(), s.get_pi()), n
-    # a stop in the middle of a batch: a tolerance the solve meets after a few dozen more sweeps
-    probe_stats, _ = s.sweep(30, 1.0, -1.0)
-    m.sweep(30, 1.0, -1.0)
-    tol = float(np.array(probe_stats)[-1, 3]) * 0.7
-    sm, nm = m.sweep(400, 1.0, tol)
-    ss, ns = s.sweep(400, 1.0, tol)
-    assert nm == ns and 0 < nm < 400, (nm, ns, tol)
-    assert np.array_equal(np.array(sm), np.array(ss))
-    assert np.array_equal(m.get_J(), s.get_J()) and np.array_equal(m.get_pi(), s.get_pi())
-    assert np.array_equal(m.get_J(prev=True), s.get_J(prev=True))
-    for h in (m, s):
-        h.terminal_cost()
-    sm, _ = m.sweep(25, 1.0, -1.0)
-    ss, _ = s.sweep(25, 1.0, -1.0)
-    assert np.array_equal(np.array(sm), np.array(ss)) and np.array_equal(m.get_J(), s.get_J())
-    m.close()
-    s.close()

@@ -1,0 +1,241 @@
+"""
+GPU tests of code paths that were written while no MI355X was reachable (round 5) and had not executed when they were
+committed: the swapped internal order of the float32 cart-pole, error-feedback storage outside the 4-D window sweep
+(2-D grids, explicit n = 3 systems, the node-table tier).  They sit in a file that collects LAST (the driver runs
+`pytest -x`): a failure here must not hide the verified rows of tests/test_gpu_parity.py.  Same checkers, same tolerances.
+"""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dims,nact,fb", [((31, 29, 27, 25), 21, False), ((41, 41, 41, 41), 21, False), ((31, 29, 27, 25), 9, True)])
+def test_swapped_internal_order_matches_the_reference_order(dims, nact, fb):
+    """Round 5 (opt-in): DynamicProgramming(internal_order="swapped") solves the float32 cart-pole with q = (theta, x) inside the
+    engine (pyro_amd/planning/permuted.py; Dyn<PVI_DYN_CARTPOLE> with dyn_params[5] = 1) so that the lanes of the 4-D window sweep
+    run along the axis the displacement does not depend on.  Same problem: J within the float32 tolerance of the float64 solve in
+    the reference's order at every checkpoint (with error feedback: 1e-6), the policy within the float64 Q-regret rule, the
+    statistics of a sweep within 1e-5; the engine says what it is (order=swapped, the displacement table over axes 0 and 2, the
+    window kernel)."""
+    from oracle import c_oracle as CO
+    from pyro_amd import configs
+    from pyro_amd.planning import dynamicprogramming as DP
+    import bench
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg = configs.build("cartpole:%s:%d:float32" % (",".join(str(d) for d in dims), nact))
+    g, cf = cfg["grid_sys"], cfg["cf"]
+
+    def make(dt, order="reference"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            dp = DP.DynamicProgrammingWithLookUpTable(g, cf, dtype=dt, f32_feedback=fb and dt == "float32", internal_order=order)
+        dp.save_time_history = False
+        dp.verbose = False
+        return dp
+    d64, d32, dsw = make("float64"), make("float32"), make("float32", "swapped")
+    desc = dsw._p.describe()
+    assert "order=swapped" in desc and "tables=10" in desc and ("kernel=k_sweep_lean4fb<" if fb else "kernel=k_sweep_lean4<") in desc, desc
+    assert np.allclose(dsw.J, d32.J, rtol=1e-6, atol=0.0)            # the terminal cost, transposed back
+    worst = 0.0
+    for k in range(5):
+        st = {}
+        for name, dp in (("f64", d64), ("f32", d32), ("sw", dsw)):
+            stats, n = dp._p.sweep(60, 1.0, -1.0)
+            st[name] = np.array(stats[-1])
+        J64 = d64._p.get_J()
+        m = np.abs(J64).max()
+        e_sw, e_32 = np.abs(dsw._p.get_J() - J64).max() / m, np.abs(d32._p.get_J() - J64).max() / m
+        worst = max(worst, e_sw)
+        print("after %d sweeps: swapped %.3e reference order %.3e" % (60 * (k + 1), e_sw, e_32))
+        assert e_sw <= (1e-6 if fb else 1e-5), (k, e_sw, e_32)
+        assert np.allclose(st["sw"], st["f64"], rtol=1e-5, atol=1e-5 * m), (st["sw"], st["f64"])
+    c = CO.CProblem(bench.oracle_problem(cfg))
+    Jprev = d64._p.get_J(prev=True)
+    nodes = np.arange(0, g.nodes_n, 5, dtype=np.int64)
+    q, qmin = c.q_at(Jprev, nodes, dsw._p.get_pi()[nodes])
+    ok = np.isfinite(q) & np.isfinite(qmin)
+    assert np.array_equal(np.isfinite(q), np.isfinite(qmin)) and (q[ok] - qmin[ok]).max() <= 1e-5 * np.abs(Jprev).max(), (q[ok] - qmin[ok]).max()
+    assert (dsw._p.get_pi() != d32._p.get_pi()).mean() < 0.02       # (ties and float32 roundings of another summation order)
+    # a cost-to-go set through the class surface lands transposed: the next sweep of both orders agrees
+    J0 = d64._p.get_J()
+    for dp in (d32, dsw):
+        dp.J = J0
+        dp._flush()
+        dp._p.sweep(1, 1.0, -1.0)
+    assert np.abs(dsw._p.get_J() - d32._p.get_J()).max() <= 2e-6 * np.abs(J0).max()
+    rel, mism = dsw._p.self_check(1.0)                               # the window sweep against the plain-gather kernel, swapped dynamics in both
+    assert rel <= 1e-5, (rel, mism)
+    with pytest.raises(NotImplementedError):
+        make("float64", "swapped")
+    with pytest.raises(NotImplementedError):
+        dsw._p.rollout(np.zeros((1, 4)), 10, 0.1)
+    for dp in (d64, d32, dsw):
+        dp._p.close()
+
+
+@pytest.mark.parametrize("name,sweeps,every", [("pendulum:401,401:21:float32", 600, 100), ("pendulum:201,201:201:float32", 300, 100),
+                                              ("pendulum:1001,1001:51:float32", 300, 100)])
+def test_f32_error_feedback_storage_on_2d_grids(name, sweeps, every):
+    """VERDICT r4 missing #3 / next #5: error-feedback storage for the 2-D float32 sweep (k_sweep_leanfb: uniform walk and the
+    lane-split walk of grids with many actions; C2 = BASELINE configs[1] at full size).  Every checkpoint within 1e-6 of the
+    float64 iterates and no worse than plain float32 storage; the same bits from a restart; the policy within the Q-regret rule
+    of the float32 path."""
+    from pyro_amd import configs
+    from pyro_amd.planning import dynamicprogramming as DP
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg = configs.build(name)
+    g, cf = cfg["grid_sys"], cfg["cf"]
+
+    def make(dt, fb=False):
+        with contextlib.redirect_stdout(io.StringIO()):
+            dp = DP.DynamicProgrammingWithLookUpTable(g, cf, dtype=dt, f32_feedback=fb)
+        dp.save_time_history = False
+        dp.verbose = False
+        return dp
+    d64, d32, dfb = make("float64"), make("float32"), make("float32", True)
+    assert "feedback=1" in dfb._p.describe() and "feedback=0" in d32._p.describe(), dfb._p.describe()
+    worst_fb = worst_plain = 0.0
+    for k in range(sweeps // every):
+        for dp in (d64, d32, dfb):
+            dp._p.sweep(every, 1.0, -1.0)
+        J64 = d64._p.get_J()
+        m = np.abs(J64).max()
+        e_fb, e_plain = np.abs(dfb._p.get_J() - J64).max() / m, np.abs(d32._p.get_J() - J64).max() / m
+        worst_fb, worst_plain = max(worst_fb, e_fb), max(worst_plain, e_plain)
+        print("%s after %d sweeps: feedback %.3e plain %.3e" % (name, every * (k + 1), e_fb, e_plain))
+        assert e_fb <= 1e-6, (k, e_fb)
+    assert "kernel=k_sweep_leanfb<" in dfb._p.describe(), dfb._p.describe()
+    assert worst_fb <= worst_plain * 1.05 + 1e-9, (worst_fb, worst_plain)
+    # the policy: float64 Q-regret of the feedback handle's actions on the float64 J of the sweep before
+    Jprev, pi = d64._p.get_J(prev=True), dfb._p.get_pi()
+    from oracle import c_oracle as CO
+    import bench
+    c = CO.CProblem(bench.oracle_problem(cfg))
+    nodes = np.arange(0, g.nodes_n, max(1, g.nodes_n // 100000), dtype=np.int64)
+    q, qmin = c.q_at(Jprev, nodes, pi[nodes])
+    ok = np.isfinite(q) & np.isfinite(qmin)
+    assert (q[ok] - qmin[ok]).max() <= 1e-5 * np.abs(Jprev).max()
+    # a new terminal cost clears the residuals: the same bits as a fresh handle
+    dfb.evaluate_terminal_cost()
+    dfb._p.sweep(40, 1.0, -1.0)
+    fresh = make("float32", True)
+    fresh._p.sweep(40, 1.0, -1.0)
+    assert np.array_equal(dfb._p.get_J(), fresh._p.get_J()) and np.array_equal(dfb._p.get_pi(), fresh._p.get_pi())
+
+
+def test_f32_error_feedback_storage_of_an_explicit_system():
+    """... and for the n = 3 systems (k_sweep3_fast: the reference's helicopter demo on a 101 x 101 x 201 grid, obstacles and
+    domain-check cost): every checkpoint within 1e-6 of float64, no worse than plain float32 storage, a restart clears the
+    residuals."""
+    from pyro_amd import configs
+    from pyro_amd.planning import dynamicprogramming as DP
+    with contextlib.redirect_stdout(io.StringIO()):
+        s, g, cf, _ = configs._helicopter((101, 101, 201), (11,), "float32")
+
+    def make(dt, fb=False):
+        with contextlib.redirect_stdout(io.StringIO()):
+            dp = DP.DynamicProgrammingWithLookUpTable(g, cf, dtype=dt, f32_feedback=fb)
+        dp.save_time_history = False
+        dp.verbose = False
+        return dp
+    d64, d32, dfb = make("float64"), make("float32"), make("float32", True)
+    assert "path=fast3" in dfb._p.describe() and "feedback=1" in dfb._p.describe() and "feedback=0" in d32._p.describe(), dfb._p.describe()
+    worst_fb = worst_plain = 0.0
+    for k in range(4):
+        for dp in (d64, d32, dfb):
+            dp._p.sweep(100, 1.0, -1.0)
+        J64 = d64._p.get_J()
+        m = np.abs(J64).max()
+        e_fb, e_plain = np.abs(dfb._p.get_J() - J64).max() / m, np.abs(d32._p.get_J() - J64).max() / m
+        worst_fb, worst_plain = max(worst_fb, e_fb), max(worst_plain, e_plain)
+        print("helicopter after %d sweeps: feedback %.3e plain %.3e" % (100 * (k + 1), e_fb, e_plain))
+        assert e_fb <= 1e-6, (k, e_fb)
+    assert worst_fb <= worst_plain * 1.05 + 1e-9
+    dfb.evaluate_terminal_cost()
+    dfb._p.sweep(30, 1.0, -1.0)
+    fresh = make("float32", True)
+    fresh._p.sweep(30, 1.0, -1.0)
+    assert np.array_equal(dfb._p.get_J(), fresh._p.get_J())
+
+
+def test_f32_error_feedback_storage_through_the_node_table_tier():
+    """... and for a one-degree-of-freedom system of the generic mechanical tier (MountainCar: Dyn<PVI_DYN_NODE_1x1>)."""
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import mountaincar
+    from pyro_amd.planning import discretizer
+    from pyro_amd.planning import dynamicprogramming as DP
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = mountaincar.MountainCar()
+        g = discretizer.GridDynamicSystem(s, [201, 201], [11])
+        cf = costfunction.QuadraticCostFunction.from_sys(s)
+        cf.INF = 100
+        dps = {k: DP.DynamicProgrammingWithLookUpTable(g, cf, dtype=dt, f32_feedback=fb)
+               for k, dt, fb in (("f64", "float64", False), ("f32", "float32", False), ("fb", "float32", True))}
+    for dp in dps.values():
+        dp.save_time_history = False
+        dp.verbose = False
+    assert dps["fb"].tier == "fused" and "feedback=1" in dps["fb"]._p.describe()
+    for k in range(4):
+        for dp in dps.values():
+            dp._p.sweep(100, 1.0, -1.0)
+        J64 = dps["f64"]._p.get_J()
+        m = np.abs(J64).max()
+        e_fb, e_plain = (np.abs(dps[k_]._p.get_J() - J64).max() / m for k_ in ("fb", "f32"))
+        print("mountain car after %d sweeps: feedback %.3e plain %.3e" % (100 * (k + 1), e_fb, e_plain))
+        assert e_fb <= 1e-6
+
+
+def _dp(name, dtype=None, fb=False):
+    from pyro_amd import configs
+    from pyro_amd.planning import dynamicprogramming as DP
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg = configs.build(name)
+        dp = DP.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype=dtype or cfg["dtype"], f32_feedback=fb)
+    dp.save_time_history = False
+    dp.verbose = False
+    return dp
+
+
+# last of all: the one piece that could leave a GPU spinning if it were wrong (its grid barrier gives up after about a second)
+@pytest.mark.parametrize("name", ["pendulum:201,201:201:float32", "pendulum:201,201:21:float32", "pendulum:101,101:11:float32",
+                                  "pendulum:301,151:51:float32"])
+def test_multi_sweep_launch_of_the_2d_float32_sweep_is_bit_identical(name):
+    """Round 5: batches of the 2-D float32 window sweep as ONE cooperative launch (k_sweep_leanm: write-through
+    J, fence-free grid barrier, statistics records folded by every workgroup) against one launch per sweep (pvi_override MULTI=0):
+    J, pi, every sweep's statistics and the stop sweep are the same bits -- fixed counts in odd batch sizes, then a tolerance
+    stop in the middle of a batch, then a restart."""
+    from pyro_amd import _native
+    with _native.overrides(MULTI32="1"):                      # (the form of a handle's batches is decided at its first sweep)
+        m = _dp(name)._p
+        sm, nm = m.sweep(1, 1.0, -1.0)
+    with _native.overrides(MULTI="0"):
+        s = _dp(name)._p
+        ss, ns = s.sweep(1, 1.0, -1.0)
+    assert "multi=1" in m.describe() and "kernel=k_sweep_leanm<" in m.describe(), m.describe()
+    assert "multi=0" in s.describe() and "kernel=k_sweep_lean<" in s.describe(), s.describe()
+    assert np.array_equal(np.array(sm), np.array(ss))
+    for n in (1, 2, 3, 7, 40, 5, 64, 9):
+        sm, nm = m.sweep(n, 1.0, -1.0)
+        ss, ns = s.sweep(n, 1.0, -1.0)
+        assert nm == ns == n and np.array_equal(np.array(sm), np.array(ss)), n
+        assert np.array_equal(m.get_J(), s.get_J()) and np.array_equal(m.get_pi(), s.get_pi()), n
+    # a stop in the middle of a batch: a tolerance the solve meets after a few dozen more sweeps
+    probe_stats, _ = s.sweep(30, 1.0, -1.0)
+    m.sweep(30, 1.0, -1.0)
+    tol = float(np.array(probe_stats)[-1, 3]) * 0.7
+    sm, nm = m.sweep(400, 1.0, tol)
+    ss, ns = s.sweep(400, 1.0, tol)
+    assert nm == ns and 0 < nm < 400, (nm, ns, tol)
+    assert np.array_equal(np.array(sm), np.array(ss))
+    assert np.array_equal(m.get_J(), s.get_J()) and np.array_equal(m.get_pi(), s.get_pi())
+    assert np.array_equal(m.get_J(prev=True), s.get_J(prev=True))
+    for h in (m, s):
+        h.terminal_cost()
+    sm, _ = m.sweep(25, 1.0, -1.0)
+    ss, _ = s.sweep(25, 1.0, -1.0)
+    assert np.array_equal(np.array(sm), np.array(ss)) and np.array_equal(m.get_J(), s.get_J())
+    m.close()
+    s.close()
