@@ -76,14 +76,39 @@ def _stale(obj, unit):
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def _compile_jobs(tag, flags, force):
+def _compile_jobs(tag, flags, force, asm=False):
+    """The compilations that are due.  asm: next to each object the unit's device assembly (same flags, `-S
+    --offload-device-only`) -- what pyro_amd/kernel_manifest.py hashes per kernel."""
     os.makedirs(OBJ, exist_ok=True)
     jobs = []
     for unit in UNITS:
         obj = os.path.join(OBJ, "%s.%s.o" % (unit, tag))
+        src = os.path.join(CSRC, UNITS[unit][0])
         if force or _stale(obj, unit):
-            jobs.append([hipcc()] + flags + ["-c", "-o", obj, os.path.join(CSRC, UNITS[unit][0])])
+            jobs.append([hipcc()] + flags + ["-c", "-o", obj, src])
+        if asm and (force or _stale(os.path.join(OBJ, "%s.s" % unit), unit)):
+            jobs.append([hipcc()] + flags + ["-S", "--offload-device-only", "-o", os.path.join(OBJ, "%s.s" % unit), src])
     return jobs
+
+
+MANIFEST = os.path.join(PKG, "kernel_manifest.json")
+
+
+def write_manifest(verbose=True):
+    """pyro_amd/kernel_manifest.json: per device kernel of THIS build the hash of its ISA (pyro_amd/kernel_manifest.py).  It
+    travels with libpyrovi.so (git-ignored like it); bench.py and the tests read it to say which kernels are verified code
+    objects (profiles/verified_kernels.json) and which kernel a set of PMC counters was taken with."""
+    import json
+    from pyro_amd import kernel_manifest
+    sfiles = [os.path.join(OBJ, "%s.s" % u) for u in UNITS]
+    if os.path.exists(MANIFEST) and all(os.path.getmtime(f) <= os.path.getmtime(MANIFEST) for f in sfiles):
+        return MANIFEST
+    man = kernel_manifest.manifest_of(sfiles)
+    with open(MANIFEST, "w") as f:
+        json.dump(man, f, indent=0, sort_keys=True)
+    if verbose:
+        print("wrote %s (%d kernels)" % (MANIFEST, len(man)), flush=True)
+    return MANIFEST
 
 
 def _run_all(cmds, verbose):
@@ -114,7 +139,10 @@ def _make(out, tag, flags, link_flags, force, verbose):
 
 
 def build(force=False, verbose=True):
-    return _make(OUT, "o3", FLAGS, ["-shared", "-fPIC"], force, verbose)
+    _run_all(_compile_jobs("o3", FLAGS, force, asm=True), verbose)
+    out = _make(OUT, "o3", FLAGS, ["-shared", "-fPIC"], False, verbose)
+    write_manifest(verbose)
+    return out
 
 
 def build_variant(name, defines=(), extra_flags=(), force=False, verbose=True):
@@ -127,7 +155,7 @@ def build_variant(name, defines=(), extra_flags=(), force=False, verbose=True):
 
 def build_all(force=False, verbose=True):
     """Product and sanitized library: all six compilations side by side, then the two links."""
-    jobs = _compile_jobs("o3", FLAGS, force) + _compile_jobs("san", FLAGS_SAN, force)
+    jobs = _compile_jobs("o3", FLAGS, force, asm=True) + _compile_jobs("san", FLAGS_SAN, force)
     _run_all(jobs, verbose)
     build(False, verbose)
     build_sanitized(False, verbose)

@@ -16,6 +16,7 @@ DYN_TABLE, DYN_PENDULUM, DYN_CARTPOLE, DYN_TWOLINK = 0, 1, 2, 3
 DYN_NODE_1x1, DYN_NODE_2x1, DYN_NODE_2x2 = 4, 5, 6        # any MechanicalSystem through per-node tables
 DYN_HELICOPTER, DYN_KINCAR, DYN_QUARTERCAR = 7, 8, 9      # the reference's three-dimensional demo systems (n = 3)
 DYN_HOLONOMIC, DYN_LONGCAR = 10, 11                       # point robot with obstacles, longitudinal car (n = 2)
+DYN_CARTPOLE_SW = 12                                      # opt-in: the cart-pole with q = (theta, x) (float32 4-D window sweep only)
 CLOSED_FORM_IDS = (DYN_PENDULUM, DYN_CARTPOLE, DYN_TWOLINK)    # dynamics pvi_eval_f can evaluate anywhere
 # ... and pvi_rollout: the explicit systems have continuous closed forms too (their sweeps read host tables at the nodes)
 ROLLOUT_IDS = CLOSED_FORM_IDS + (DYN_HELICOPTER, DYN_KINCAR, DYN_QUARTERCAR, DYN_HOLONOMIC, DYN_LONGCAR)

@@ -53,6 +53,10 @@ def compact_line(full, full_path=None):
         out["vector_peak_frac"] = _r(fv.get("frac"))
     if full.get("counters_error"):
         out["counters_error"] = str(full["counters_error"])[:200]
+    pv = full.get("provenance")
+    if pv:       # code objects of this build that have not passed the GPU suite on hardware (pyro_amd/kernel_manifest.py)
+        out["unverified_kernels"] = pv.get("unverified_kernels")
+        out["kernel_verified"] = pv.get("kernel_verified")
     cb = full.get("cpu_baseline")
     if cb:
         out["cpu_baseline"] = {k: _r(cb.get(k)) for k in ("value", "unit", "cores", "kind", "sweeps_per_sec", "per_core_value",

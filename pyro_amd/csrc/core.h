@@ -128,21 +128,21 @@ struct Dyn<PVI_DYN_PENDULUM> {
 };
 
 // CartPole (cartpole.py:369-437).  c = [m1+m2, m2*lcg, m2*lcg^2, -m2*lcg, m2*g*lcg]
-template <>
-struct Dyn<PVI_DYN_CARTPOLE> {
+// SW (PVI_DYN_CARTPOLE_SW, opt-in): the generalised coordinates in the order q = (theta, x) -- state (theta, x, dtheta, dx).
+// Same system, same arithmetic; the two rows of inv(H) and of its product with the gravity term change places at the end of
+// init, the angle and its rate are read from the other slots.  (The float32 window sweep of 4-D grids runs its lanes along the
+// LAST axis: in this order that is dx, which the displacement does not depend on -- pyro_amd/planning/permuted.py.)  A separate
+// instantiation, so that the reference-order kernels stay the code objects that have run (tools/kernel_manifest.py).
+template <bool SW>
+struct DynCartPole {
     static constexpr int DOF = 2, M = 1;
+    static constexpr int TH = SW ? 0 : 1;   // the angle's slot among the coordinates (its rate: 2 + TH)
     double i00, i10, t0, t1, cdq0;
     // ONE_DIV: the three entries of inv(H) from one reciprocal of the determinant (an ulp off the reference's three divisions):
     // only where bit-identity with the reference is not the point -- the float64 epilogue of the float32 feedback sweep
-    // c[5] != 0: the generalised coordinates in the order q = (theta, x) -- state (theta, x, dtheta, dx).  Same system, same
-    // arithmetic; the two rows of inv(H) and of its product with the gravity term change places at the end of init, the angle
-    // and its rate are read from the other slots.  (The float32 window sweep of 4-D grids runs its lanes along the LAST axis:
-    // in this order that is dx, which the displacement does not depend on -- pyro_amd/planning/permuted.py.)
-    __device__ static bool swapped(const double* c) { return c[5] != 0.0; }
     template <bool ONE_DIV = false>
     __device__ void init(const double* c, const double* x, const double* tr) {
-        const bool sw = swapped(c);
-        const double cth = tr[0], sth = tr[1], dth = sw ? x[2] : x[3];
+        const double cth = tr[0], sth = tr[1], dth = x[2 + TH];
         const double H00 = c[0], H01 = c[1] * cth, H11 = c[2];
         const double C01 = (c[3] * sth) * dth;
         cdq0 = C01 * dth;
@@ -162,7 +162,7 @@ struct Dyn<PVI_DYN_CARTPOLE> {
         i10 = i01;
         t0 = i01 * r1;
         t1 = i11 * r1;
-        if (sw) {  // (accel and affine below then yield (ddtheta, ddx))
+        if constexpr (SW) {  // (accel and affine below then yield (ddtheta, ddx))
             const double a = i00, b = t0;
             i00 = i10;
             t0 = t1;
@@ -171,13 +171,12 @@ struct Dyn<PVI_DYN_CARTPOLE> {
         }
     }
     __device__ static void trig_from_tables(const DevP& P, const int* i, double* tr) {
-        const int k = swapped(P.c) ? i[0] : i[1];
-        tr[0] = P.trig[0][k];  // cos(theta)
-        tr[1] = P.trig[1][k];  // sin(theta)
+        tr[0] = P.trig[0][i[TH]];  // cos(theta)
+        tr[1] = P.trig[1][i[TH]];  // sin(theta)
     }
     __device__ static void trig_from_state(const double* x, double* tr) {
-        tr[0] = cos(x[1]);
-        tr[1] = sin(x[1]);
+        tr[0] = cos(x[TH]);
+        tr[1] = sin(x[TH]);
     }
     __device__ void accel(const double* u, double* a) const {
         const double r0 = u[0] - cdq0;
@@ -191,6 +190,10 @@ struct Dyn<PVI_DYN_CARTPOLE> {
         B[1][0] = i10;
     }
 };
+template <>
+struct Dyn<PVI_DYN_CARTPOLE> : DynCartPole<false> {};
+template <>
+struct Dyn<PVI_DYN_CARTPOLE_SW> : DynCartPole<true> {};
 
 // TwoLinkManipulator / DoublePendulum (manipulator.py:897-992, pendulum.py:400-493)
 // c = [k0, m2, k1, k2, I2, k3, k4, g1c, g2c, d1, d2]  (see pyro_amd/dynamic/manipulator.py)
@@ -304,19 +307,6 @@ template <>
 struct Dyn<PVI_DYN_NODE_2x1> : DynNode<2, 1> {};
 template <>
 struct Dyn<PVI_DYN_NODE_2x2> : DynNode<2, 2> {};
-
-// sin / cos of the angles from a state anywhere in the state space (rollouts, pvi_eval_f): the closed form's own, except that the
-// cart-pole's angle sits in slot 0 when its coordinates are swapped (Dyn<PVI_DYN_CARTPOLE>::swapped)
-template <int DYN>
-__device__ inline void dyn_trig_from_state(const double* c, const double* x, double* tr) {
-    Dyn<DYN>::trig_from_state(x, tr);
-}
-template <>
-__device__ inline void dyn_trig_from_state<PVI_DYN_CARTPOLE>(const double* c, const double* x, double* tr) {
-    const double th = Dyn<PVI_DYN_CARTPOLE>::swapped(c) ? x[0] : x[1];
-    tr[0] = cos(th);
-    tr[1] = sin(th);
-}
 
 // =================================================================================================
 // cost (costfunction.py:151-204): rows of M.dx first, then the outer dot, all left to right

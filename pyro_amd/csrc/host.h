@@ -66,8 +66,13 @@ struct LeanP {
     float guard;
     int lds_floats;      // floats of one window buffer
     int RS;              // LDS row pitch in dwords, 32k+1
-    float* jlo;          // [owned] PVI_FLAG_F32_FEEDBACK on a 2-D grid: rounding residual of the stored J (NULL: plain storage)
-    double alpha64;      // ... and the discount factor of the launch unrounded
+};
+
+// PVI_FLAG_F32_FEEDBACK on a 2-D grid (k_sweep_leanfb): its own kernel argument -- LeanP keeps the layout of the kernels that do
+// not read it (their code objects are the ones that have run: tools/kernel_manifest.py)
+struct LeanFb {
+    float* jlo;          // [owned] rounding residual of the stored J
+    double alpha64;      // the discount factor of the launch unrounded
 };
 
 struct Lean4P {
@@ -209,7 +214,7 @@ struct pvi_problem {
     int lean_pw1 = 2, lean_block = 256;
     dim3 lean_grid;
     size_t lean_lds = 0;
-    bool lean_lds_attr = false;
+    const void* lean_lds_attr = nullptr;  // the kernel function that last got hipFuncAttributeMaxDynamicSharedMemorySize (per function, not per handle)
     char lean_why[160] = "";
     int lean_reach = 0;       // largest |velocity displacement| of an in-box cell, grid cells
     int lean_opmag = 0;       // largest |ta| + sum |tB u| (cells): operand magnitude of the float32 displacement
@@ -225,6 +230,7 @@ struct pvi_problem {
     size_t levr_bytes = 0;
     const unsigned long long* okmask3 = nullptr;  // fast3: validity of every (node, action) cell of an explicit system
     float* jlo = nullptr;     // [owned] PVI_FLAG_F32_FEEDBACK: rounding residual of the stored float32 J of every node
+    LeanFb lean_fb = {nullptr, 0.0};  // ... as the 2-D window sweep's kernel argument (set at every launch: launch_sweep_t)
     const double* roll_params = nullptr;  // constants of the continuous closed form (pvi_set_rollout_params)
     SplineP SP;               // bicubic-spline interpolation mode (sweep_spline.inc)
     bool spline = false;

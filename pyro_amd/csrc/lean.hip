@@ -357,6 +357,7 @@ static int launch_lean4_t(pvi_problem* h, const float* Jin, float* Jout, float a
         L4G(DYN, false)
     switch (h->d.dynamics_id) {
         case PVI_DYN_CARTPOLE: L4(PVI_DYN_CARTPOLE) break;
+        case PVI_DYN_CARTPOLE_SW: L4(PVI_DYN_CARTPOLE_SW) break;
         case PVI_DYN_NODE_2x1: L4(PVI_DYN_NODE_2x1) break;
         case PVI_DYN_NODE_2x2: L4(PVI_DYN_NODE_2x2) break;
         default: L4(PVI_DYN_TWOLINK) break;
@@ -674,6 +675,7 @@ static int lean4_setup(pvi_problem* h) {
 #define L4DISPATCH(MACRO)                                  \
     switch (h->d.dynamics_id) {                            \
         case PVI_DYN_CARTPOLE: MACRO(PVI_DYN_CARTPOLE) break; \
+        case PVI_DYN_CARTPOLE_SW: MACRO(PVI_DYN_CARTPOLE_SW) break; \
         case PVI_DYN_NODE_2x1: MACRO(PVI_DYN_NODE_2x1) break; \
         case PVI_DYN_NODE_2x2: MACRO(PVI_DYN_NODE_2x2) break; \
         default: MACRO(PVI_DYN_TWOLINK) break;                \
@@ -738,7 +740,7 @@ static int lean4_setup(pvi_problem* h) {
     // input only (cartpole.py:369-437: H, C, g depend on q[1] and dq[1]; no damping term) -- axes 0 and 2 drop out.  The kernel
     // that FINDS the invariant axes (every node against the node at index 0 of each axis: 66 GB of cache traffic, 93 ms of C4's
     // create) runs for the dynamics that do not declare them, and with TABLES=2 (the variants test holds the declaration to it).
-    const int declared = h->d.dynamics_id == PVI_DYN_CARTPOLE ? (h->d.dyn_params[5] != 0.0 ? 0xA : 0x5) : -1;   // (q = (theta, x): axes 1 and 3)
+    const int declared = h->d.dynamics_id == PVI_DYN_CARTPOLE ? 0x5 : h->d.dynamics_id == PVI_DYN_CARTPOLE_SW ? 0xA : -1;   // (q = (theta, x): axes 1 and 3)
     if (want_tables && declared >= 0 && !ovr_is("TABLES", 2)) {
         inv = declared;
     } else if (want_tables) {
@@ -930,6 +932,7 @@ static int lean4_setup(pvi_problem* h) {
             snprintf(h->lean4_cands + at, sizeof(h->lean4_cands) - at, "%s%s%d/%d:%.2f", at ? "," : "", tag, c.cap, c.w, full);
     };
     int first = -1;  // the first candidate that fits: timed on a device that may still be ramping its clocks
+    bool keep_cached = false;
     for (int attempt = 0; attempt < 2 && best < 0; ++attempt) {
     if (attempt == 1) {
         // The key leaves out what decides whether a window FITS (the slab's rows, the position bounds, the dynamics constants):
@@ -937,6 +940,7 @@ static int lean4_setup(pvi_problem* h) {
         // giving the window sweep up (the handle fell to a slower kernel, PVI_FLAG_F32_FEEDBACK failed with EINVAL).
         if (!from_cache) break;
         from_cache = false;
+        keep_cached = true;   // (the entry serves the pieces it fits: this piece's winner does not evict it -- ADVICE r5)
         cands = all_cands;
         tune = !ovr_is("TUNE", 0) && cands.size() > 1;
         if (tune)
@@ -1008,7 +1012,7 @@ static int lean4_setup(pvi_problem* h) {
         HIPCHK(hipMemsetAsync(h->J[h->cur ^ 1], 0, (size_t)h->stored * 4, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
-    if (best >= 0 && !from_cache && tune) {
+    if (best >= 0 && !from_cache && tune && !keep_cached) {
         std::lock_guard<std::mutex> lk(g_lean4_choice_mu);
         g_lean4_choice[key] = cands[(size_t)best];
     }
@@ -1031,6 +1035,7 @@ int lean_setup(pvi_problem* h) {
     int rc;
     if ((rc = lean4_setup(h))) return rc;
     if (h->lean4_ok) return PVI_OK;  // 4-D grids: the paired-window kernel (sweep_lean4.inc)
+    if (h->d.dynamics_id == PVI_DYN_CARTPOLE_SW) return PVI_OK;  // (no other family is instantiated for it: pvi_create refuses the handle)
     if ((rc = dev_alloc(h, (size_t)DOF * h->owned, &L.ta))) return rc;
     if ((rc = dev_alloc(h, (size_t)DOF * M * h->owned, &L.tB))) return rc;
     if ((rc = dev_alloc(h, (size_t)h->owned, &L.gx))) return rc;
@@ -1108,7 +1113,7 @@ int lean_setup(pvi_problem* h) {
             h->lean_block = ((threads + 63) / 64) * 64;
             if (h->lean_block > 512) continue;
             h->lean_ok = true;
-            h->lean_lds_attr = false;
+            h->lean_lds_attr = nullptr;
             float ms = 0.f;
             for (int rep = 0; rep < 3 && rc == 0; ++rep) {  // one warm-up, two timed
                 if (rep == 1) HIPCHK(hipEventRecord(h->ev0, h->stream));
@@ -1150,7 +1155,7 @@ int lean_setup(pvi_problem* h) {
                 h->lean_block = ((threads + 63) / 64) * 64;
                 if (h->lean_block > (L.npt > 1 ? 256 : 512)) continue;
                 h->lean_ok = true;
-                h->lean_lds_attr = false;
+                h->lean_lds_attr = nullptr;
                 return 0;
             }
         }
@@ -1242,9 +1247,9 @@ static int launch_lean2_t(pvi_problem* h, const float* Jin, float* Jout, float a
     {                                                                                                               \
         auto kfn = k_sweep_lean<DYN, PI_T, U, NP, RSK>;                                                                  \
         set_kname(h, "k_sweep_lean", (int)DYN, tname<PI_T>(), (bool)U, (int)NP, (int)RSK);                              \
-        if (!h->lean_lds_attr && h->lean_lds > 48 * 1024) {                                                         \
+        if (h->lean_lds_attr != (const void*)kfn && h->lean_lds > 48 * 1024) {                                                        \
             HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PVI_LDS_MAX)); \
-            h->lean_lds_attr = true;                                                                                \
+            h->lean_lds_attr = (const void*)kfn;                                                                          \
         }                                                                                                           \
         hipLaunchKernelGGL(kfn, h->lean_grid, h->lean_block, h->lean_lds, st, h->P, h->LP, h->F.act, h->LP.actc, Jin, Jout, pi, al, \
                            sc);                                                                                     \
@@ -1254,15 +1259,15 @@ static int launch_lean2_t(pvi_problem* h, const float* Jin, float* Jout, float a
     {                                                                                                               \
         auto kfn = k_sweep_leanfb<DYN, PI_T, U>;                                                                    \
         set_kname(h, "k_sweep_leanfb", (int)DYN, tname<PI_T>(), (bool)U);                                           \
-        if (!h->lean_lds_attr && h->lean_lds > 48 * 1024) {                                                         \
+        if (h->lean_lds_attr != (const void*)kfn && h->lean_lds > 48 * 1024) {                                                        \
             HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PVI_LDS_MAX)); \
-            h->lean_lds_attr = true;                                                                                \
+            h->lean_lds_attr = (const void*)kfn;                                                                          \
         }                                                                                                           \
         hipLaunchKernelGGL(kfn, h->lean_grid, h->lean_block, h->lean_lds, st, h->P, h->LP, h->F.act, h->LP.actc, Jin, Jout, pi, al, \
-                           sc);                                                                                     \
+                           sc, h->lean_fb);                                                                         \
         if (sc.split_finish == 1) hipLaunchKernelGGL(k_sweep_finish, 1, STAT_SHARDS, 0, st, sc);                    \
     }
-            if (h->LP.jlo) {  // error-feedback storage (2-D grids, one input; pvi_create admits no other handle)
+            if (h->lean_fb.jlo) {  // error-feedback storage (2-D grids, one input; pvi_create admits no other handle)
                 if (h->d.dynamics_id == PVI_DYN_PENDULUM) {
                     if (h->LP.lsplit == 0)
                         LEANFB(PVI_DYN_PENDULUM, true)
@@ -1333,6 +1338,7 @@ static const void* multi32_kernel_of(pvi_problem* h) {
 bool multi32_applies(pvi_problem* h) {
     if (h->multi32 >= 0) return h->multi32 == 1 && !h->jlo && !h->force_exact;
     h->multi32 = 0;
+    if (h->d.dtype != PVI_F32) return false;   // (multi_why keeps what multi64_applies wrote)
     auto no = [&](const char* why) {
         snprintf(h->multi_why, sizeof(h->multi_why), "%s", why);
         return false;
@@ -1367,7 +1373,6 @@ int launch_multi32(pvi_problem* h, int src, double alpha, double tol, int nsweep
     const void* kfn = multi32_kernel_of(h);
     DevP P = h->P;
     LeanP LP = h->LP;
-    LP.jlo = nullptr;
     const float4* actp = h->F.act;
     const float* actc = h->LP.actc;
     float* J0 = (float*)h->J[src];

@@ -9,8 +9,8 @@ In the reference's state order (x, theta, dx, dtheta) the last axis is dtheta --
 generalised coordinates swapped, q = (theta, x), the state is (theta, x, dtheta, dx), the last axis is dx and the lanes of a tile
 row all shift together.
 
-It is the same problem: the same grid levels per physical axis, the same dynamics (Dyn<PVI_DYN_CARTPOLE> with dyn_params[5] = 1
-reads the angle and its rate from the other slots and returns (ddtheta, ddx)), the same cost (Q, S, xbar permuted).  The value
+It is the same problem: the same grid levels per physical axis, the same dynamics (Dyn<PVI_DYN_CARTPOLE_SW>, its own dynamics id:
+it reads the angle and its rate from the other slots and returns (ddtheta, ddx)), the same cost (Q, S, xbar permuted).  The value
 function is the reference's with its axes transposed: `SwappedProblem` keeps the device arrays in the internal order and
 transposes J and pi where they cross the class surface (get / set), so the caller sees the reference's node order.
 
@@ -39,10 +39,8 @@ def swap_problem_kwargs(kw):
     out["x_levels"] = [kw["x_levels"][i] for i in p]
     out["x_lb"] = np.asarray(kw["x_lb"], dtype=float)[p]
     out["x_ub"] = np.asarray(kw["x_ub"], dtype=float)[p]
-    params = [float(v) for v in kw["dyn_params"]]
-    params += [0.0] * (6 - len(params))
-    params[5] = 1.0                                  # core.h Dyn<PVI_DYN_CARTPOLE>::swapped
-    out["dyn_params"] = params
+    out["dynamics_id"] = _native.DYN_CARTPOLE_SW       # core.h DynCartPole<true>: the same five constants
+    out["dyn_params"] = [float(v) for v in kw["dyn_params"]]
     # (trig: cos / sin over the ANGLE's levels -- the same two arrays; the library reads them along axis 0 in this order)
     cost = kw.get("cost")
     if cost is not None:

@@ -5,6 +5,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 
 from conftest import ROOT
 
@@ -101,7 +102,7 @@ def test_counters_are_tied_to_the_kernel_name():
     # C5 / C5d: the sparse patch walk and the dense patch walk, not set-up's slowest candidate
     assert bench.norm_kernel(ctr["c5"]["kernel"]) == "k_sweep64<3,unsignedchar,true,true,true>"
     assert bench.norm_kernel(ctr["c5d"]["kernel"]) == "k_sweep64<3,unsignedchar,true,true,false>"
-    c = dict(ctr["c5"], kernel_path="path=exact-f64v2 mapping=patch8x8 sparse=1", csrc_hash=bench.kernel_source_hash())
+    c = dict(ctr["c5"], kernel_path="path=exact-f64v2 mapping=patch8x8 sparse=1", isa_hash=bench.kernel_isa_hash(ctr["c5"]["kernel"]))
     good = "path=exact-f64v2 kernel=k_sweep64<3,unsignedchar,true,true,true> mapping=patch8x8 off32=1 sparse=1 inbox=0.1 note="
     kept, err = bench.check_counters(c, good)
     assert kept and err is None
@@ -111,28 +112,56 @@ def test_counters_are_tied_to_the_kernel_name():
     assert not kept and "not reported" in err
 
 
-def test_counters_are_tied_to_the_kernel_sources(tmp_path, monkeypatch):
-    """a kernel BODY edited under the same template name must invalidate the committed PMC
-    passes.  The digest stores a hash of pyro_amd/csrc/* + include/pyrovi.h; check_counters recomputes it."""
-    import shutil
+def test_counters_are_tied_to_the_kernel_code_object(tmp_path, monkeypatch):
+    """PMC passes describe a CODE OBJECT.  The digest stores the kernel's ISA hash
+    (pyro_amd/kernel_manifest.py, from the device assembly of the build); check_counters compares it with the hash of the same
+    kernel in THIS build's manifest: a kernel recompiled to other instructions under the same template name invalidates the
+    counters, a comment edit under csrc/ does not, counters without a hash are dropped."""
+    import json
     bench = _bench()
     from pyro_amd import _build
-    h0 = bench.kernel_source_hash()
-    assert len(h0) == 16 and h0 == bench.kernel_source_hash()
-    desc = "path=lean kernel=k_sweep_lean4<2,unsignedchar> tile=19x51 win=1 note="
-    c = {"kernel": "void k_sweep_lean4<2, unsigned char>(DevP, Lean4P)", "kernel_path": "path=lean tile=19x51 win=1",
-         "source": "profiles/x.json", "csrc_hash": h0, "hbm_bytes_per_launch": 1.0}
+    man = {"k_sweep_lean4<2,unsignedchar,true,true>": {"exact": "aaaa000011112222", "loose": "x"}}
+    mpath = tmp_path / "kernel_manifest.json"
+    mpath.write_text(json.dumps(man))
+    lib = tmp_path / "libpyrovi.so"
+    lib.write_text("")
+    os.utime(lib, (os.path.getmtime(mpath) - 5,) * 2)
+    monkeypatch.setattr(_build, "MANIFEST", str(mpath))
+    monkeypatch.setattr(_build, "OUT", str(lib))
+    assert bench.kernel_isa_hash("void k_sweep_lean4<2, unsigned char, true, true>(DevP, Lean4P)") == "aaaa000011112222"
+    desc = "path=lean kernel=k_sweep_lean4<2,unsignedchar,true,true> tile=19x51 win=1 note="
+    c = {"kernel": "void k_sweep_lean4<2, unsigned char, true, true>(DevP, Lean4P)", "kernel_path": "path=lean tile=19x51 win=1",
+         "source": "profiles/x.json", "isa_hash": "aaaa000011112222", "hbm_bytes_per_launch": 1.0}
     kept, err = bench.check_counters(c, desc)
     assert kept and err is None
-    kept, err = bench.check_counters(dict(c, csrc_hash=None), desc)          # counters from before the hash existed
+    kept, err = bench.check_counters(dict(c, isa_hash=None), desc)           # counters from before the hash existed
     assert not kept and "not recorded" in err
-    # edit a kernel body in a copy of the tree: same kernel name, same variant tokens -- the counters must go
-    csrc = tmp_path / "csrc"
-    shutil.copytree(_build.CSRC, csrc)
-    with open(csrc / "sweep_lean4.inc", "a") as f:
-        f.write("// edited\n")
-    monkeypatch.setattr(_build, "CSRC", str(csrc))
-    h1 = bench.kernel_source_hash()
-    assert h1 != h0
+    kept, err = bench.check_counters(dict(c, isa_hash="bbbb000011112222"), desc)   # the kernel was recompiled since
+    assert not kept and "code object:" in err and "bbbb000011112222" in err and "aaaa000011112222" in err
+    # a manifest older than the library does not describe it: nothing is trusted
+    os.utime(lib, (os.path.getmtime(mpath) + 60,) * 2)
+    assert bench.kernel_isa_hash("k_sweep_lean4<2,unsignedchar,true,true>") is None
     kept, err = bench.check_counters(c, desc)
-    assert not kept and "sources:" in err and h0 in err and h1 in err
+    assert not kept and "no manifest" in err
+
+
+def test_committed_counters_name_the_code_objects_they_were_taken_on():
+    """Every entry of profiles/counters.json carries an ISA hash (or null = not attributable); the entries whose kernel this
+    build still compiles to the same instructions are exactly the ones bench.py will keep."""
+    import json
+    bench = _bench()
+    ctr = json.load(open(os.path.join(ROOT, "profiles", "counters.json")))
+    man = bench.kernel_manifest()
+    if not man:
+        pytest.skip("no kernel manifest next to the library (build with pyro_amd/_build.py)")
+    live = {}
+    for w, c in ctr.items():
+        if w.startswith("_"):
+            continue
+        assert "isa_hash" in c and "csrc_hash" not in c, w
+        k = bench.norm_kernel(c["kernel"])
+        live[w] = c["isa_hash"] is not None and man.get(k, {}).get("exact") == c["isa_hash"]
+    # round 4's passes: the float64 kernels and the n = 3 kernel are unchanged code objects; the float32 window sweeps were
+    # rewritten in round 5 (their counters are dropped until a new pass)
+    assert live["c5"] and live["c5d"] and live["c1"] and live["h3"], live
+

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("dims,nact,fb", [((31, 29, 27, 25), 21, False), ((41, 41, 41, 41), 21, False), ((31, 29, 27, 25), 9, True)])
 def test_swapped_internal_order_matches_the_reference_order(dims, nact, fb):
     """Round 5 (opt-in): DynamicProgramming(internal_order="swapped") solves the float32 cart-pole with q = (theta, x) inside the
-    engine (pyro_amd/planning/permuted.py; Dyn<PVI_DYN_CARTPOLE> with dyn_params[5] = 1) so that the lanes of the 4-D window sweep
+    engine (pyro_amd/planning/permuted.py; Dyn<PVI_DYN_CARTPOLE_SW>, a dynamics id of its own) so that the lanes of the 4-D window sweep
     run along the axis the displacement does not depend on.  Same problem: J within the float32 tolerance of the float64 solve in
     the reference's order at every checkpoint (with error feedback: 1e-6), the policy within the float64 Q-regret rule, the
     statistics of a sweep within 1e-5; the engine says what it is (order=swapped, the displacement table over axes 0 and 2, the
@@ -90,7 +90,8 @@ def test_f32_error_feedback_storage_on_2d_grids(name, sweeps, every):
     g, cf = cfg["grid_sys"], cfg["cf"]
 
     def make(dt, fb=False):
-        with contextlib.redirect_stdout(io.StringIO()):
+        from pyro_amd import _native
+        with contextlib.redirect_stdout(io.StringIO()), _native.overrides(**({"UNPROVEN": "1"} if fb else {})):
             dp = DP.DynamicProgrammingWithLookUpTable(g, cf, dtype=dt, f32_feedback=fb)
         dp.save_time_history = False
         dp.verbose = False
@@ -136,7 +137,8 @@ def test_f32_error_feedback_storage_of_an_explicit_system():
         s, g, cf, _ = configs._helicopter((101, 101, 201), (11,), "float32")
 
     def make(dt, fb=False):
-        with contextlib.redirect_stdout(io.StringIO()):
+        from pyro_amd import _native
+        with contextlib.redirect_stdout(io.StringIO()), _native.overrides(**({"UNPROVEN": "1"} if fb else {})):
             dp = DP.DynamicProgrammingWithLookUpTable(g, cf, dtype=dt, f32_feedback=fb)
         dp.save_time_history = False
         dp.verbose = False
@@ -172,8 +174,10 @@ def test_f32_error_feedback_storage_through_the_node_table_tier():
         g = discretizer.GridDynamicSystem(s, [201, 201], [11])
         cf = costfunction.QuadraticCostFunction.from_sys(s)
         cf.INF = 100
-        dps = {k: DP.DynamicProgrammingWithLookUpTable(g, cf, dtype=dt, f32_feedback=fb)
-               for k, dt, fb in (("f64", "float64", False), ("f32", "float32", False), ("fb", "float32", True))}
+        from pyro_amd import _native
+        with _native.overrides(UNPROVEN="1"):
+            dps = {k: DP.DynamicProgrammingWithLookUpTable(g, cf, dtype=dt, f32_feedback=fb)
+                   for k, dt, fb in (("f64", "float64", False), ("f32", "float32", False), ("fb", "float32", True))}
     for dp in dps.values():
         dp.save_time_history = False
         dp.verbose = False

@@ -3,7 +3,7 @@ CPU tests of the internal axis order (pyro_amd/planning/permuted.py, DynamicProg
 problem is the SAME problem -- checked on the oracle, whose table-driven sweep (oracle/vi_oracle.py sweep_lut, the reference's
 dynamicprogramming.py:564-570) runs the cart-pole with its coordinates swapped from tables built by a host restatement of that
 system, against the oracle's closed form in the reference's order -- and the wrapper hands node-ordered arrays over transposed.
-The GPU side (Dyn<PVI_DYN_CARTPOLE> with dyn_params[5] = 1) is tests/test_gpu_parity.py::test_swapped_internal_order_*.
+The GPU side (Dyn<PVI_DYN_CARTPOLE_SW>, its own dynamics id) is tests/test_gpu_zz_unproven.py::test_swapped_internal_order_*.
 """
 import contextlib
 import io
@@ -66,10 +66,10 @@ def test_swapped_problem_kwargs_describe_the_same_problem():
     kw = g._problem_kwargs(cf.device_cost(), "float32")
     assert kw["dynamics_id"] == _native.DYN_CARTPOLE
     sk = permuted.swap_problem_kwargs(kw)
-    assert [len(l) for l in sk["x_levels"]] == [9, 7, 6, 5] and sk["dyn_params"][5] == 1.0 and list(sk["dyn_params"][:5]) == list(kw["dyn_params"])
+    assert [len(l) for l in sk["x_levels"]] == [9, 7, 6, 5] and sk["dynamics_id"] == _native.DYN_CARTPOLE_SW and list(sk["dyn_params"]) == list(kw["dyn_params"])
     assert np.array_equal(sk["x_lb"], s.x_lb[[1, 0, 3, 2]]) and np.array_equal(sk["cost"]["xbar"], cf.xbar[[1, 0, 3, 2]])
     assert sk["cost"]["Q"][0, 0] == 2.0 and sk["cost"]["Q"][3, 3] == 3.0 and sk["cost"]["S"][2, 2] == 0.125
-    assert kw["dyn_params"][5:] == [] or kw["dyn_params"][5] == 0.0          # the caller's arguments are untouched
+    assert kw["dynamics_id"] == _native.DYN_CARTPOLE                         # the caller's arguments are untouched
     # reference order: the oracle's closed form
     dyn_id, params = s.device_dynamics()
     p = O.Problem(g.x_level, g.u_level, g.dt, dyn_id, np.array(params), cf.Q, cf.R, cf.S, cf.xbar, cf.ubar, float(cf.INF), float(cf.EPS),

@@ -13,7 +13,7 @@ for w in sys.argv[1:]:
     # template instantiation of the handle's last launch).  pvi_create also launches slower candidates of the same family
     # once or twice each (mappings, dense / sparse walks, tile shapes): "the k_sweep* with the most vector work" picked one
     # of THOSE for C5 / C5d in round 3.  Without a `kernel=` token: the sweep kernel with the most calls.
-    from bench import norm_kernel, kernel_source_hash
+    from bench import norm_kernel, kernel_isa_hash
     want = norm_kernel(dict(t.split("=", 1) for t in raw.get("kernel_path", "").split() if "=" in t).get("kernel"))
     sweeps = {k: v for k, v in src.items() if "k_sweep" in k and "finish" not in k and "_probe" not in k}
     named = [(k, v) for k, v in sweeps.items() if want and want != "-" and norm_kernel(k) == want]
@@ -38,8 +38,8 @@ for w in sys.argv[1:]:
         "wave_cycles_quad": sweep.get("SQ_WAVE_CYCLES"), "wait_any_quad": sweep.get("SQ_WAIT_ANY"),
         "wait_inst_any_quad": sweep.get("SQ_WAIT_INST_ANY"), "active_inst_any_quad": sweep.get("SQ_ACTIVE_INST_ANY"),
         "kernel": kname, "kernel_calls": sweep.get("calls"), "kernel_path": raw.get("kernel_path", ""),
-        # the sources the profiled library was built from (the counter pass ran on THIS tree: gpurun snapshots it)
-        "csrc_hash": raw.get("csrc_hash") or kernel_source_hash(),
+        # the code object the passes ran on (the counter pass ran on THIS tree's library: gpurun snapshots it with its manifest)
+        "isa_hash": (raw.get("isa_hashes") or {}).get(norm_kernel(kname)) or kernel_isa_hash(kname),
         "source": "profiles/%s_counters_%s.json (rocprofv3 --pmc passes of tools/tools_counters.sh), kernel %s as of commit %s"
                   % (ROUND, w, kname.split("<")[0], HEAD),
     }

@@ -52,8 +52,10 @@ except Exception as e:
 import sys
 sys.path.insert(0, '/root/repo')
 import bench
-# (the sources of the library the passes ran on: bench.py drops the counters once a kernel file changes)
-json.dump({"workload": "$W", "kernel_path": path, "csrc_hash": bench.kernel_source_hash(), "kernels": keep}, open('/root/repo/gpurun_out/counters_$W.json', 'w'), indent=1)
+# (the ISA hash of every kernel counted, from the manifest of the library the passes ran on: bench.py drops the counters once a
+#  kernel is compiled to other instructions)
+isa = {bench.norm_kernel(k): bench.kernel_isa_hash(k) for k in keep}
+json.dump({"workload": "$W", "kernel_path": path, "isa_hashes": isa, "kernels": keep}, open('/root/repo/gpurun_out/counters_$W.json', 'w'), indent=1)
 for k, v in keep.items():
     if 'sweep' in k: print(k, json.dumps(v))
 PY
