@@ -206,6 +206,8 @@ def main():
     bl.add_argument("manifest")
     bl.add_argument("--commit", required=True)
     bl.add_argument("--evidence", required=True)
+    bl.add_argument("--only", default=None, help="file with one kernel name per line (e.g. the kernels a trace saw): bless these only")
+    bl.add_argument("--file", default=VERIFIED, help="the verified list to extend (default profiles/verified_kernels.json)")
     a = ap.parse_args()
     if a.cmd == "build":
         if a.asm:
@@ -243,7 +245,13 @@ def main():
             len(cl["verified"]), len(cl["layout_only"]), len(cl["unverified"]), bad))
         sys.exit(1 if bad else 0)
     else:
-        ver = bless(json.load(open(a.manifest)), a.commit, a.evidence)
+        man = json.load(open(a.manifest))
+        if a.only:
+            seen = {short(ln.strip()) for ln in open(a.only) if ln.strip()}
+            man = {k: v for k, v in man.items() if k in seen}
+        if a.file != VERIFIED and not os.path.exists(a.file) and os.path.exists(VERIFIED):
+            shutil.copy(VERIFIED, a.file)
+        ver = bless(man, a.commit, a.evidence, a.file)
         print("%d kernels listed, %d runs" % (len(ver["kernels"]), len(ver["runs"])))
 
 
