@@ -249,6 +249,9 @@ def main():
         if a.only:
             seen = {short(ln.strip()) for ln in open(a.only) if ln.strip()}
             man = {k: v for k, v in man.items() if k in seen}
+        else:       # (library-level evidence covers what a default call can launch, not the opt-in kernels)
+            pats = optin_patterns()
+            man = {k: v for k, v in man.items() if not is_optin(k, pats)}
         if a.file != VERIFIED and not os.path.exists(a.file) and os.path.exists(VERIFIED):
             shutil.copy(VERIFIED, a.file)
         ver = bless(man, a.commit, a.evidence, a.file)
