@@ -58,6 +58,8 @@ extern "C" {
 #define PVI_ENOMEM -3
 #define PVI_ESTATE -4   /* call not valid in the handle's current state */
 #define PVI_EHALO -5    /* a gather left the stored slab: halo too small for this dynamics */
+#define PVI_ECORRUPT -6 /* pvi_sweep: the corruption detector of the error-feedback sweep fired (pvi_override("FBCHECK", "1")): the
+                           float32 action loop and the float64 epilogue disagree about the same backup beyond any rounding */
 
 /* storage / interpolation arithmetic type of J on the device */
 #define PVI_F32 0

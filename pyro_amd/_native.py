@@ -24,6 +24,7 @@ COST_TABLE, COST_QUADRATIC, COST_TIME, COST_QUADRATIC_DOMAIN, COST_REACHABILITY 
 INTERP_LINEAR, INTERP_BICUBIC_SPLINE, INTERP_NEAREST = 0, 1, 2
 CTL_TABLE, CTL_COMPUTED_TORQUE = 0, 1
 PVI_EHALO = -5
+PVI_ECORRUPT = -6      # the corruption detector of the error-feedback sweep fired (pvi_override FBCHECK=1)
 FLAG_EXT_J_SLACK = 1
 FLAG_HARD_INF = 2
 FLAG_F32_FEEDBACK = 4     # error-feedback storage of a float32 J (4-D window sweep; include/pyrovi.h)

@@ -230,6 +230,7 @@ struct pvi_problem {
     size_t levr_bytes = 0;
     const unsigned long long* okmask3 = nullptr;  // fast3: validity of every (node, action) cell of an explicit system
     float* jlo = nullptr;     // [owned] PVI_FLAG_F32_FEEDBACK: rounding residual of the stored float32 J of every node
+    bool fbcheck = false;     // ... with the corruption detector of the 4-D epilogue (pvi_override("FBCHECK", "1") at create: k_sweep_lean4fbc)
     LeanFb lean_fb = {nullptr, 0.0};  // ... as the 2-D window sweep's kernel argument (set at every launch: launch_sweep_t)
     const double* roll_params = nullptr;  // constants of the continuous closed form (pvi_set_rollout_params)
     SplineP SP;               // bicubic-spline interpolation mode (sweep_spline.inc)

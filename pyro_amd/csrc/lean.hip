@@ -334,7 +334,10 @@ static int launch_lean4_t(pvi_problem* h, const float* Jin, float* Jout, float a
                            sc, (const float*)L.ptab, (const Lean4Tile*)h->lean4_tiles);                                \
     }
 #define L4V(DYN, GXN, VM)                                                              \
-    if (L.jlo) {                                                                       \
+    if (L.jlo && h->fbcheck) {                                                         \
+        set_kname(h, "k_sweep_lean4fbc", (int)DYN, tname<PI_T>(), (bool)GXN, (bool)VM); \
+        L4K((k_sweep_lean4fbc<DYN, PI_T, GXN, VM>))                                    \
+    } else if (L.jlo) {                                                                \
         set_kname(h, "k_sweep_lean4fb", (int)DYN, tname<PI_T>(), (bool)GXN, (bool)VM); \
         L4K((k_sweep_lean4fb<DYN, PI_T, GXN, VM>))                                     \
     } else {                                                                           \

@@ -1387,6 +1387,7 @@ static const char* const OVERRIDE_KEYS[] = {
     "VMASK",       // 0: the 4-D float32 window sweep clamps and compares cell indices instead of reading set-up's validity bits
     "RS_CONG",     // 1: 4-D float32 window sweep, row pitch congruent to the widest tile's (even) width modulo 32 (bank experiments)
     "MULTI32",     // 1: batches of the 2-D float32 window sweep as one cooperative launch (k_sweep_leanm; opt-in until measured)
+    "FBCHECK",     // 1: PVI_FLAG_F32_FEEDBACK on a 4-D grid runs the epilogue with the corruption detector (k_sweep_lean4fbc; opt-in until it has run)
     "UNPROVEN",    // 1: admit kernels that have not yet passed their tests on hardware (error-feedback storage outside 4-D grids)
     "MULTI",       // 0: one launch per sweep also where a batch could run as ONE multi-sweep launch (k_sweep64m)
 };
@@ -1806,6 +1807,7 @@ extern "C" int pvi_create(const pvi_desc* d, pvi_handle* out) {
         }();
         if (rc) return bail(rc);
         jlo_of(h) = lo;
+        h->fbcheck = h->lean4_ok && ovr_is("FBCHECK", 1);
     }
     if (d->dtype == PVI_F32 && is_dyn3(d->dynamics_id) && A <= 64 && !ovr("NO_FAST")) {
         // fast3: the validity of every cell of an explicit system, once (sweep_lean.inc's idea applied to the obstacle tests)
@@ -2408,6 +2410,17 @@ extern "C" int pvi_sweep(pvi_handle h, int32_t max_sweeps, double alpha, double 
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
         ms_total += ms;
+        if (c.dbg[0] & 4) {  // k_sweep_lean4fbc: the float32 loop and the float64 epilogue disagree about the winner's backup
+            float v32, v64;
+            memcpy(&v32, &c.dbg[3], 4);
+            memcpy(&v64, &c.dbg[4], 4);
+            HIPCHK(hipMemsetAsync(h->ctrl->dbg, 0, sizeof(c.dbg), h->stream));
+            return fail(PVI_ECORRUPT, "corruption detector: node %d action %d sweep %d of the batch: the action loop computed %.9g, the epilogue %.9g for the same backup -- "
+                                      "this build's window sweep does not compute what its source says on this device (DESIGN.md 4.2d); results of this handle are not to be trusted",
+                        c.dbg[1], c.dbg[2], c.dbg[5], (double)v32, (double)v64);
+        }
+        if (c.dbg[0] && c.dbg[1] == -77)
+            return fail(PVI_EHIP, "multi-sweep launch: the grid barrier of sweep %d of the batch was never completed (k_sweep_leanm gave up after about a second)", c.dbg[2]);
         if (c.dbg[0])
             return fail(PVI_EHIP, "bounds check: idx=%d limit=%d a=%d bpw=%d vo=%d vorg=%d idxv=%d fl=%d vs=%d exact=%d pos_in=%d",
                         c.dbg[1], c.dbg[2], c.dbg[3], c.dbg[4], c.dbg[5], c.dbg[6], c.dbg[7], c.dbg[8], c.dbg[9], c.dbg[10],

@@ -203,6 +203,28 @@ def _dp(name, dtype=None, fb=False):
     return dp
 
 
+@pytest.mark.parametrize("name", ["cartpole:41,41,41,41:21:float32", "cartpole:31,33,35,37:31:float32", "twolink:21,21,21,21:5,5:float32"])
+def test_feedback_corruption_detector_is_silent_on_a_sound_build_and_changes_no_bit(name):
+    """Round 6 (VERDICT r5 next #3d): k_sweep_lean4fbc = the error-feedback sweep of 4-D grids with a detector in its epilogue -- the
+    float32 action loop's value of the winner against the float64 re-evaluation of the same backup, |diff| <= 1e-4 (1 + |J|), else
+    pvi_sweep returns PVI_ECORRUPT.  On a sound build it never fires (full-occupancy grids, a solve's worth of sweeps), J, pi, the
+    residual-driven iterates and the statistics are the bits of k_sweep_lean4fb, and the handle says which kernel it runs.  (That it
+    FIRES on the build of commit 4e5b14a: tools/r05_hunt/run_r06_detector.sh, which needs that build.)"""
+    from pyro_amd import _native
+    with _native.overrides(FBCHECK="1"):
+        c = _dp(name, fb=True)._p
+    p = _dp(name, fb=True)._p
+    for n in (1, 40, 7, 120):
+        sc, nc = c.sweep(n, 1.0, -1.0)                      # (PVI_ECORRUPT would raise NativeError here)
+        sp, npl = p.sweep(n, 1.0, -1.0)
+        assert nc == npl == n and np.array_equal(np.array(sc), np.array(sp)), n
+        assert np.array_equal(c.get_J(), p.get_J()) and np.array_equal(c.get_pi(), p.get_pi()), n
+    assert "kernel=k_sweep_lean4fbc<" in c.describe() and "kernel=k_sweep_lean4fb<" in p.describe(), c.describe()
+    assert np.isfinite(c.get_J()).all()
+    c.close()
+    p.close()
+
+
 # last of all: the one piece that could leave a GPU spinning if it were wrong (its grid barrier gives up after about a second)
 @pytest.mark.parametrize("name", ["pendulum:201,201:201:float32", "pendulum:201,201:21:float32", "pendulum:101,101:11:float32",
                                   "pendulum:301,151:51:float32"])
