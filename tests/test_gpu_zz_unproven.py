@@ -225,6 +225,73 @@ def test_feedback_corruption_detector_is_silent_on_a_sound_build_and_changes_no_
     p.close()
 
 
+@pytest.mark.parametrize("system,dims,nact,k", [("pendulum", (61, 57), 9, 2), ("pendulum", (61, 57), 9, 5), ("cartpole", (21, 19, 23, 17), 5, 3)])
+@pytest.mark.parametrize("eps", [-1.5e-6, -4e-7, 0.0, 4e-7])
+def test_float32_slabs_refuse_or_agree_when_the_reach_sits_on_a_whole_number_of_cells(system, dims, nact, k, eps):
+    """the time step is chosen so that the largest axis-0 displacement of an in-box cell is k + eps cells, eps
+    within +-1.5e-6 (the float32 kernels form x_next in float32: an ulp of a ten-cell displacement is 1e-6 cells).  With the halo
+    the host rule agrees on (parallel._rows_for_reach: floor(d + 2e-6) + 1 rows) the two slabs must reproduce the whole-grid float32
+    sweep bit for bit; with ONE ROW LESS the handle must be refused (set-up) or the sweep must end in PVI_EHALO -- never a clamped
+    gather that passes silently."""
+    from oracle import vi_oracle as O
+    from pyro_amd import _native, parallel
+    from test_gpu_parity import native_problem
+    n0 = dims[0]
+    if system == "pendulum":
+        lb, ub, dyn, consts = [-3.2, -6.0], [3.2, 6.0], O.DYN_PENDULUM, O.pendulum_consts()
+    else:
+        lb, ub, dyn, consts = [-4.0, -3.2, -5.0, -6.0], [4.0, 3.2, 5.0, 6.0], O.DYN_CARTPOLE, O.cartpole_consts()
+    n = len(dims)
+    lv = O.make_levels(np.array(lb), np.array(ub), np.array(dims))
+    ul = O.make_levels(np.array([-10.0]), np.array([10.0]), np.array([nact]))
+    step0 = (ub[0] - lb[0]) / (n0 - 1)
+    vmax = ub[n // 2]                                           # x_next_0 = x_0 + dq_0 dt: the reach is max |dq_0| dt
+    dt = (k + eps) * step0 / vmax
+    Q, R = np.eye(n), np.eye(1)
+    p = O.Problem(lv, ul, dt, dyn, consts, Q, R, np.zeros((n, n)), np.zeros(n), np.zeros(1), 1e4, 0.2)
+    need = parallel._rows_for_reach(k + eps)
+    assert need == (k + 1 if eps >= -2e-6 else k)
+    mid = n0 // 2
+    whole = native_problem(p, dtype="float32")
+    whole.terminal_cost()
+    slabs = [native_problem(p, dtype="float32", rows=(0, mid), halo=(0, need)), native_problem(p, dtype="float32", rows=(mid, n0), halo=(need, 0))]
+    for s in slabs:
+        s.terminal_cost()
+    for _ in range(3):
+        whole.sweep(1, 1.0, -1.0)
+        for s in slabs:
+            s.sweep_async(1.0)
+            s.sweep_stats()
+        parts = [s.get_J() for s in slabs]
+        assert np.array_equal(np.concatenate(parts), whole.get_J())
+        full = np.concatenate(parts).reshape(n0, -1)
+        for s in slabs:
+            r0, r1 = s.store_rows
+            s.set_J(full[r0:r1].ravel(), r0, r1 - r0)
+    for s in slabs:
+        s.close()
+    # one row less than the rule: refused at create, reported by the sweep, or -- where float32 rounding keeps every gather inside
+    # the rows that ARE stored (eps < 0) -- still the whole grid's bits; a silent difference is the failure
+    whole.terminal_cost()
+    whole.sweep(1, 1.0, -1.0)
+    try:
+        short = native_problem(p, dtype="float32", rows=(0, mid), halo=(0, need - 1))
+    except _native.NativeError as e:
+        assert "halo" in str(e).lower(), e
+        whole.close()
+        return
+    short.terminal_cost()
+    try:
+        short.sweep_async(1.0)
+        short.sweep_stats()
+    except _native.NativeError as e:
+        assert e.code == _native.PVI_EHALO, e
+    else:
+        assert eps < 0 and np.array_equal(short.get_J(), whole.get_J()[:mid * int(np.prod(dims[1:]))]), (system, k, eps, short.describe())
+    short.close()
+    whole.close()
+
+
 # last of all: the one piece that could leave a GPU spinning if it were wrong (its grid barrier gives up after about a second)
 @pytest.mark.parametrize("name", ["pendulum:201,201:201:float32", "pendulum:201,201:21:float32", "pendulum:101,101:11:float32",
                                   "pendulum:301,151:51:float32"])
