@@ -165,6 +165,20 @@ def override(key=None, value=None):
     """Pin a kernel variant for handles created from now on (pvi_override; tests and profiling).  override(key, None)
     removes the key, override() removes all."""
     check(lib().pvi_override(None if key is None else str(key).encode(), None if value is None else str(value).encode()))
+    if key is None:
+        _OVERRIDES.clear()
+    elif value is None:
+        _OVERRIDES.pop(str(key), None)
+    else:
+        _OVERRIDES[str(key)] = str(value)
+
+
+_OVERRIDES = {}          # what this process has pinned through override() (the library keeps its own copy)
+
+
+def override_value(key):
+    """The value override(key, value) pinned in this process, or None."""
+    return _OVERRIDES.get(str(key))
 
 
 class overrides:

@@ -143,10 +143,14 @@ class DynamicProgramming:
         (PVI_EINVAL)."""
         if self.dtype != np.float32:
             return False
+        # Only the 4-D form has run on hardware.  The 2-D and explicit-system forms were written while no MI355X was reachable
+        # (round 5): until tests/test_gpu_zz_unproven.py has passed they are admitted with _native.overrides(UNPROVEN="1") only --
+        # the library applies the same gate (pvi_create: PVI_EINVAL).
+        unproven = _native.override_value("UNPROVEN") == "1"
         mech = getattr(self.sys, "dof", None)
         if mech is not None:        # mechanical systems: the LDS-window sweeps
-            return self.sys.n == 4 or (self.sys.n == 2 and self.sys.m == 1)
-        return True                 # explicit systems: k_sweep3_fast (the library refuses where that sweep does not apply)
+            return self.sys.n == 4 or (unproven and self.sys.n == 2 and self.sys.m == 1)
+        return unproven             # explicit systems: k_sweep3_fast (the library refuses where that sweep does not apply)
 
     def _make_engine(self):
         self._host = {}             # cached downloads: 'J', 'pi', 'J_next'
@@ -157,8 +161,9 @@ class DynamicProgramming:
             if self.INTERPOLATION != "linear":
                 raise NotImplementedError("the spline fit couples every row of the grid: single-GPU only")
             if self.F32_FEEDBACK and not self._feedback_applies():
-                raise NotImplementedError("f32_feedback is the float32 storage mode of the LDS-window sweeps: 4-D grids, and 2-D grids "
-                                          "with one input (dtype %s, n = %d, m = %d)" % (self.dtype, self.sys.n, self.sys.m))
+                raise NotImplementedError("f32_feedback is the float32 storage mode of the 4-D LDS-window sweep (2-D grids with one input and "
+                                          "explicit systems: written, not yet run on hardware -- _native.overrides(UNPROVEN='1') admits "
+                                          "them; dtype %s, n = %d, m = %d)" % (self.dtype, self.sys.n, self.sys.m))
             self._p = self.comm.engine(self)        # (every sharded engine carries the flag to the pieces of its slabs)
             self.tier = self._p.tier
             return
@@ -174,8 +179,9 @@ class DynamicProgramming:
             # (base class: an invalid cell costs exactly INF; the same as INF + alpha*0 unless the system rejects
             #  states inside the grid box, i.e. obstacles)
             if self.F32_FEEDBACK and not self._feedback_applies():
-                raise NotImplementedError("f32_feedback is the float32 storage mode of the LDS-window sweeps: 4-D grids, and 2-D grids "
-                                          "with one input (dtype %s, n = %d, m = %d)" % (self.dtype, self.sys.n, self.sys.m))
+                raise NotImplementedError("f32_feedback is the float32 storage mode of the 4-D LDS-window sweep (2-D grids with one input and "
+                                          "explicit systems: written, not yet run on hardware -- _native.overrides(UNPROVEN='1') admits "
+                                          "them; dtype %s, n = %d, m = %d)" % (self.dtype, self.sys.n, self.sys.m))
             flags = (_native.FLAG_HARD_INF if self.HARD_INF else 0) | (_native.FLAG_F32_FEEDBACK if self.F32_FEEDBACK else 0)
             if self.INTERNAL_ORDER == "swapped":
                 from pyro_amd.planning import permuted

@@ -412,13 +412,10 @@ def test_f32_kernel_variants_agree(name, variants):
                      # round 4: other bands of the launch order (the persistent and quad-window kernels of this round were
                      # measured, lost and removed: DESIGN.md 4.2b)
                      ("lean_bands2", {"PVI_WIN": "1", "PVI_BANDS": "2"}),
-                     # round 5: the invariant axes of the displacement FOUND by the kernel instead of declared by the closed form
-                     # (TABLES=2), cell validity by clamp-and-compare instead of set-up's bit per action (VMASK=0)
-                     ("lean_tab2", {"PVI_WIN": "1", "PVI_TABLES": "2"}), ("lean_clamp", {"PVI_WIN": "1", "PVI_VMASK": "0"}),
                      ("fast", {"PVI_NO_LEAN": "1"}),
                      ("exact32", {"PVI_NO_FAST": "1"})]:
         for k in ("PVI_LSPLIT", "PVI_NO_LEAN", "PVI_NO_FAST", "PVI_NPT", "PVI_WIN", "PVI_TABLES", "PVI_NO_XCD", "PVI_TV0", "PVI_TV1",
-                  "PVI_BANDS", "PVI_VMASK"):
+                  "PVI_BANDS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -433,7 +430,7 @@ def test_f32_kernel_variants_agree(name, variants):
         tok = dict(t.split("=", 1) for t in outs["lean"][2].split() if "=" in t)
         assert tok.get("choice", "-") != "-", outs["lean"][2]
         for k in ("PVI_LSPLIT", "PVI_NO_LEAN", "PVI_NO_FAST", "PVI_NPT", "PVI_WIN", "PVI_TABLES", "PVI_NO_XCD", "PVI_TV0", "PVI_TV1",
-                  "PVI_BANDS", "PVI_VMASK"):
+                  "PVI_BANDS"):
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setenv("PVI_L4PIN", tok["choice"])
         h = native_problem(p, dtype="float32")
@@ -467,13 +464,10 @@ def test_f32_kernel_variants_agree(name, variants):
     if four_d:
         # ... while the round-3 kernel splits every operand into integer + fraction in float64 at set-up and takes the arm too.
         # Whatever the coefficient tables, the launch order or the tile shape: the same bits.
-        for tag in ("lean", "lean_win1", "lean_tab0", "lean_tab1", "lean_noxcd", "lean_shape", "lean_bands2", "lean_tab2", "lean_clamp"):
+        for tag in ("lean", "lean_win1", "lean_tab0", "lean_tab1", "lean_noxcd", "lean_shape", "lean_bands2"):
             assert path_of(outs[tag][2]) == "path=lean" and "win=1" in outs[tag][2], (tag, outs[tag][2])
             assert np.array_equal(outs[tag][0], outs["lean_win1"][0]) and np.array_equal(outs[tag][1], outs["lean_win1"][1]), (tag, outs[tag][2])
         assert "tables=0" in outs["lean_tab0"][2] and "gx=node" in outs["lean_tab0"][2], outs["lean_tab0"][2]
-        tabs = lambda d: dict(t.split("=", 1) for t in d.split() if "=" in t)["tables"]
-        assert tabs(outs["lean_tab2"][2]) == tabs(outs["lean"][2]), (outs["lean_tab2"][2], outs["lean"][2])   # declared == found
-        assert "vmask=1" in outs["lean"][2] and "vmask=0" in outs["lean_clamp"][2], (outs["lean"][2], outs["lean_clamp"][2])
         assert "tile=3x" in outs["lean_shape"][2], outs["lean_shape"][2]       # (columns are evened out over the tiles)
         assert "kernel=k_sweep_lean4<" in outs["lean"][2], outs["lean"][2]
         # its split displacement is the more accurate float32 form: at least as close to the float64 oracle as the others
@@ -922,19 +916,15 @@ def test_f32_error_feedback_storage_small():
     dfb._p.sweep(20, 1.0, -1.0)
     d32b._p.sweep(20, 1.0, -1.0)
     assert np.array_equal(dfb._p.get_J(), d32b._p.get_J())
-    # (v) refusals: float64 and the table tier (class surface), and the library itself on a handle without a float32 production
-    #     sweep (the n = 3 helicopter with its mask sweep switched off: the plain float64-dynamics kernel)
+    # (v) refusals: float64, a 2-D grid (class surface), and the library itself on a handle without the 4-D window sweep
     with pytest.raises(NotImplementedError):
         make("float64", True)
-    import table_case
     with contextlib.redirect_stdout(io.StringIO()):
-        tc = table_case.table_case()
-        h3 = configs.build("h3s")
+        c2 = configs.build("pendulum:41,41:5:float32")
     with pytest.raises(NotImplementedError):
-        DP.DynamicProgrammingWithLookUpTable(tc["grid_sys"], tc["cf"], dtype="float32", f32_feedback=True)
-    with _native.overrides(NO_FAST="1"):
-        with pytest.raises(_native.NativeError) as ei:
-            h3["grid_sys"]._device_problem(cost=DP.device_cost_of(h3["cf"], h3["sys"]), dtype="float32", flags=_native.FLAG_F32_FEEDBACK)
+        DP.DynamicProgrammingWithLookUpTable(c2["grid_sys"], c2["cf"], dtype="float32", f32_feedback=True)
+    with pytest.raises(_native.NativeError) as ei:
+        c2["grid_sys"]._device_problem(cost=DP.device_cost_of(c2["cf"], c2["sys"]), dtype="float32", flags=_native.FLAG_F32_FEEDBACK)
     assert "PVI_FLAG_F32_FEEDBACK" in str(ei.value)
 
 
@@ -1274,7 +1264,7 @@ rank, out = int(sys.argv[1]), sys.argv[2]
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d", rank=rank, world_size=%d)
 with contextlib.redirect_stdout(io.StringIO()):
     cfg = configs.build("%s")
-vi = parallel.ShardedValueIteration(cfg["grid_sys"], cfg["cf"], dist, dtype="float32", device=0, overlap=%s, f32_feedback=%s)
+vi = parallel.ShardedValueIteration(cfg["grid_sys"], cfg["cf"], dist, dtype="float32", device=0, overlap=%s)
 stats = [vi.sweep(1.0) for _ in range(4)]
 last = vi.run(3, 1.0, -1.0)
 J, pi = vi.gather()
@@ -1286,14 +1276,11 @@ print("WORLD2-OK", rank)
 """
 
 
-@pytest.mark.parametrize("case,world,overlap,fb", [("cartpole:21,21,21,21:7:float32", 2, True, False),
-                                                   ("cartpole:21,21,21,21:7:float32", 2, False, False),
-                                                   ("pendulum:101,101:11:float32", 2, True, False),
-                                                   ("cartpole:21,21,21,21:7:float32", 3, True, False),
-                                                   # round 5: error-feedback storage over the Python-driven slabs (every piece keeps the
-                                                   # residuals of its rows; nothing about them is exchanged)
-                                                   ("cartpole:21,21,21,21:7:float32", 3, True, True)])
-def test_two_ranks_share_one_gpu(tmp_path, case, world, overlap, fb):
+@pytest.mark.parametrize("case,world,overlap", [("cartpole:21,21,21,21:7:float32", 2, True),
+                                                ("cartpole:21,21,21,21:7:float32", 2, False),
+                                                ("pendulum:101,101:11:float32", 2, True),
+                                                ("cartpole:21,21,21,21:7:float32", 3, True)])
+def test_two_ranks_share_one_gpu(tmp_path, case, world, overlap):
     """The sharded driver with the product HipSlab on real hardware: two processes (both on GPU 0), halo rows moved
     by a gloo process group through host staging, statistics all-reduced -- must equal the single-handle result
     bit for bit (same kernels, same arithmetic per node).  overlap=True is the boundary-first schedule: separate
@@ -1307,7 +1294,7 @@ def test_two_ranks_share_one_gpu(tmp_path, case, world, overlap, fb):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "res.npz")
-    code = _WORLD2 % (ROOT, port, world, case, overlap, fb)
+    code = _WORLD2 % (ROOT, port, world, case, overlap)
     procs = [subprocess.Popen([sys.executable, "-c", code, str(r), out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
     logs = [p.communicate(timeout=900)[0] for p in procs]
@@ -1317,7 +1304,7 @@ def test_two_ranks_share_one_gpu(tmp_path, case, world, overlap, fb):
     from pyro_amd.planning import dynamicprogramming
     with contextlib.redirect_stdout(io.StringIO()):
         cfg = configs.build(case)
-        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype="float32", f32_feedback=fb)
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype="float32")
     stats, _ = dp._p.sweep(7, 1.0, -1.0)
     assert np.array_equal(r["J"], dp._p.get_J()) and np.array_equal(r["pi"], dp._p.get_pi())
     np.testing.assert_allclose(r["stats"][:4], stats[:4], rtol=1e-12)

@@ -13,6 +13,87 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("name", ["cartpole_11p4x5", "twolink_11p4x3x3", "doublependulum_13x11x13x11x3x3"])
+def test_declared_invariance_and_clamped_validity_variants_agree(name):
+    """Host logic of round 5 that tests/test_gpu_parity.py::test_f32_kernel_variants_agree does not cover in its last-run form: the
+    4-D window sweep with the invariant axes of the displacement FOUND by k_lean4_invariance (TABLES=2) instead of declared by the
+    cart-pole's closed form, and with cell validity by clamp-and-compare (VMASK=0) instead of set-up's bit per action -- the same
+    bits as the default; the declared axes are the found ones; the handle says which form it runs."""
+    from pyro_amd import _native
+    from test_gpu_parity import CASES, load, native_problem, oracle_problem
+    g = load(name)
+    p = oracle_problem(g, *CASES[name])
+    alpha = float(g["alpha"]) if "alpha" in g.files else 1.0
+    outs = {}
+    for tag, kv in (("lean", {"WIN": "1"}), ("tab2", {"WIN": "1", "TABLES": "2"}), ("clamp", {"WIN": "1", "VMASK": "0"})):
+        with _native.overrides(**kv):
+            h = native_problem(p, dtype="float32")
+        h.terminal_cost()
+        h.sweep(6, alpha, -1.0)
+        outs[tag] = (h.get_J(), h.get_pi(), h.describe())
+        h.close()
+    tok = {t: dict(x.split("=", 1) for x in outs[t][2].split() if "=" in x) for t in outs}
+    for t in ("tab2", "clamp"):
+        assert outs[t][2].split()[0] == "path=lean" and tok[t]["win"] == "1", outs[t][2]
+        assert np.array_equal(outs[t][0], outs["lean"][0]) and np.array_equal(outs[t][1], outs["lean"][1]), (t, outs[t][2])
+    assert tok["tab2"]["tables"] == tok["lean"]["tables"], (outs["tab2"][2], outs["lean"][2])          # declared == found
+    assert tok["lean"]["vmask"] == "1" and tok["clamp"]["vmask"] == "0", (outs["lean"][2], outs["clamp"][2])
+
+
+def test_feedback_refusals_and_the_unproven_gate():
+    """PVI_FLAG_F32_FEEDBACK where it is not offered: the table tier (class surface), an explicit system whose mask sweep is
+    switched off (library), and -- until their tests have run on hardware -- 2-D grids and explicit systems without
+    pvi_override("UNPROVEN", "1") (class surface: NotImplementedError; library: PVI_EINVAL naming the override)."""
+    import table_case
+    from pyro_amd import configs, _native
+    from pyro_amd.planning import dynamicprogramming as DP
+    with contextlib.redirect_stdout(io.StringIO()):
+        tc = table_case.table_case()
+        h3 = configs.build("h3s")
+        c2 = configs.build("pendulum:41,41:5:float32")
+    with pytest.raises(NotImplementedError):
+        DP.DynamicProgrammingWithLookUpTable(tc["grid_sys"], tc["cf"], dtype="float32", f32_feedback=True)
+    for cfg in (c2, h3):
+        with pytest.raises(NotImplementedError):
+            DP.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype="float32", f32_feedback=True)
+        with pytest.raises(_native.NativeError) as ei:
+            cfg["grid_sys"]._device_problem(cost=DP.device_cost_of(cfg["cf"], cfg["sys"]), dtype="float32", flags=_native.FLAG_F32_FEEDBACK)
+        assert "UNPROVEN" in str(ei.value) and "PVI_FLAG_F32_FEEDBACK" in str(ei.value), ei.value
+    with _native.overrides(NO_FAST="1", UNPROVEN="1"):
+        with pytest.raises(_native.NativeError) as ei:
+            h3["grid_sys"]._device_problem(cost=DP.device_cost_of(h3["cf"], h3["sys"]), dtype="float32", flags=_native.FLAG_F32_FEEDBACK)
+    assert "PVI_FLAG_F32_FEEDBACK" in str(ei.value) and "UNPROVEN" not in str(ei.value), ei.value
+
+
+def test_error_feedback_over_python_driven_slabs(tmp_path):
+    """Round 5: error-feedback storage over the Python-driven slabs (three ranks on one GPU, every piece keeps the residuals of its
+    rows, nothing about them is exchanged): the bits of the one-handle feedback solve."""
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from pyro_amd import configs
+    from pyro_amd.planning import dynamicprogramming
+    import test_gpu_parity as T
+    case, world = "cartpole:21,21,21,21:7:float32", 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "res.npz")
+    code = T._WORLD2.replace('overlap=%s)', 'overlap=%s, f32_feedback=True)') % (ROOT, port, world, case, True)
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    logs = [pr.communicate(timeout=900)[0] for pr in procs]
+    assert all("WORLD2-OK" in lg for lg in logs), "\n".join(logs)
+    r = np.load(out)
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg = configs.build(case)
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(cfg["grid_sys"], cfg["cf"], dtype="float32", f32_feedback=True)
+    stats, _ = dp._p.sweep(7, 1.0, -1.0)
+    assert np.array_equal(r["J"], dp._p.get_J()) and np.array_equal(r["pi"], dp._p.get_pi())
+    np.testing.assert_allclose(r["stats"][:4], stats[:4], rtol=1e-12)
+
+
 @pytest.mark.parametrize("dims,nact,fb", [((31, 29, 27, 25), 21, False), ((41, 41, 41, 41), 21, False), ((31, 29, 27, 25), 9, True)])
 def test_swapped_internal_order_matches_the_reference_order(dims, nact, fb):
     """Round 5 (opt-in): DynamicProgramming(internal_order="swapped") solves the float32 cart-pole with q = (theta, x) inside the
