@@ -213,14 +213,19 @@ def norm_kernel(name):
 def kernel_manifest():
     """{kernel: {"exact": ISA hash, ...}} of the library this process loads: pyro_amd/kernel_manifest.json, written by
     pyro_amd/_build.py next to libpyrovi.so from the device assembly of the same compilation (it travels to the GPU box with the
-    .so).  {} when it is missing or older than the library (a library built by other means)."""
-    from pyro_amd import _build
+    .so).  {} when it is missing or names another library file (its "_library" sha256)."""
+    from pyro_amd import _build, kernel_manifest as KM
+    global _MANIFEST_CACHE
     try:
-        if os.path.getmtime(_build.MANIFEST) + 1.0 < os.path.getmtime(_build.OUT):
-            return {}
-        return json.load(open(_build.MANIFEST))
+        key = (_build.MANIFEST, _build.OUT, os.path.getmtime(_build.MANIFEST), os.path.getmtime(_build.OUT))
+        if _MANIFEST_CACHE is None or _MANIFEST_CACHE[0] != key:
+            _MANIFEST_CACHE = (key, KM.load_manifest(_build.MANIFEST, library=_build.OUT))      # ({} unless written for THIS .so)
+        return _MANIFEST_CACHE[1]
     except (OSError, ValueError):
         return {}
+
+
+_MANIFEST_CACHE = None
 
 
 def kernel_isa_hash(kernel):
@@ -237,7 +242,7 @@ def provenance(kernel=None):
     from pyro_amd import kernel_manifest as KM
     man = kernel_manifest()
     if not man:
-        return {"unverified_kernels": None, "note": "pyro_amd/kernel_manifest.json missing or older than libpyrovi.so"}
+        return {"unverified_kernels": None, "note": "pyro_amd/kernel_manifest.json missing or written for another libpyrovi.so"}
     cl = KM.classify(man)
     pats = KM.optin_patterns()
     bad = [k for k in cl["layout_only"] + cl["unverified"] if not KM.is_optin(k, pats)]

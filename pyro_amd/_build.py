@@ -101,13 +101,14 @@ def write_manifest(verbose=True):
     import json
     from pyro_amd import kernel_manifest
     sfiles = [os.path.join(OBJ, "%s.s" % u) for u in UNITS]
-    if os.path.exists(MANIFEST) and all(os.path.getmtime(f) <= os.path.getmtime(MANIFEST) for f in sfiles):
+    if os.path.exists(MANIFEST) and all(os.path.getmtime(f) <= os.path.getmtime(MANIFEST) for f in sfiles + [OUT]):
         return MANIFEST
     man = kernel_manifest.manifest_of(sfiles)
+    man["_library"] = kernel_manifest.file_id(OUT)        # (the library this manifest describes: bench.py checks it)
     with open(MANIFEST, "w") as f:
         json.dump(man, f, indent=0, sort_keys=True)
     if verbose:
-        print("wrote %s (%d kernels)" % (MANIFEST, len(man)), flush=True)
+        print("wrote %s (%d kernels)" % (MANIFEST, len(man) - 1), flush=True)
     return MANIFEST
 
 

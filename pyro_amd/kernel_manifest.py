@@ -145,6 +145,26 @@ def manifest_of(sfiles):
     return man
 
 
+def file_id(path):
+    """{"sha256", "bytes"} of a file: the manifest written next to libpyrovi.so names the library it describes."""
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return {"sha256": h.hexdigest(), "bytes": os.path.getsize(path)}
+
+
+def load_manifest(path, library=None):
+    """The kernels of a manifest file (keys starting with "_" are metadata).  With `library`: {} unless the manifest was written
+    for exactly that file ("_library": its sha256) -- file times do not survive every way a tree is copied to a GPU box."""
+    man = json.load(open(path))
+    meta = man.pop("_library", None)
+    man = {k: v for k, v in man.items() if not k.startswith("_")}
+    if library is not None and (meta is None or meta.get("sha256") != file_id(library)["sha256"]):
+        return {}
+    return man
+
+
 def build(tree=ROOT, outdir=None, extra=()):
     outdir = outdir or os.path.join("/tmp", "pvi_kernel_manifest_%d" % os.getpid())
     return manifest_of(compile_units(tree, outdir, extra))
@@ -221,7 +241,7 @@ def main():
         if not a.out:
             print(text)
     elif a.cmd == "diff":
-        A, B = json.load(open(a.a)), json.load(open(a.b))
+        A, B = load_manifest(a.a), load_manifest(a.b)
         ch, lay, new, gone = diff(A, B)
         for tag, ks in (("CHANGED", ch), ("LAYOUT-ONLY", lay), ("NEW", new), ("GONE", gone)):
             for k in ks:
@@ -232,7 +252,7 @@ def main():
         print("%d identical, %d changed, %d layout-only, %d new, %d gone" % (
             len([k for k in B if k in A and A[k]["exact"] == B[k]["exact"]]), len(ch), len(lay), len(new), len(gone)))
     elif a.cmd == "check":
-        man = json.load(open(a.manifest)) if a.manifest else build()
+        man = load_manifest(a.manifest) if a.manifest else build()
         cl = classify(man)
         optin = optin_patterns(a.opt_in)
         bad = 0
@@ -245,7 +265,7 @@ def main():
             len(cl["verified"]), len(cl["layout_only"]), len(cl["unverified"]), bad))
         sys.exit(1 if bad else 0)
     else:
-        man = json.load(open(a.manifest))
+        man = load_manifest(a.manifest)
         if a.only:
             seen = {short(ln.strip()) for ln in open(a.only) if ln.strip()}
             man = {k: v for k, v in man.items() if k in seen}

@@ -120,12 +120,12 @@ def test_counters_are_tied_to_the_kernel_code_object(tmp_path, monkeypatch):
     import json
     bench = _bench()
     from pyro_amd import _build
-    man = {"k_sweep_lean4<2,unsignedchar,true,true>": {"exact": "aaaa000011112222", "loose": "x"}}
+    from pyro_amd import kernel_manifest as KM
+    lib = tmp_path / "libpyrovi.so"
+    lib.write_text("a library")
+    man = {"k_sweep_lean4<2,unsignedchar,true,true>": {"exact": "aaaa000011112222", "loose": "x"}, "_library": KM.file_id(str(lib))}
     mpath = tmp_path / "kernel_manifest.json"
     mpath.write_text(json.dumps(man))
-    lib = tmp_path / "libpyrovi.so"
-    lib.write_text("")
-    os.utime(lib, (os.path.getmtime(mpath) - 5,) * 2)
     monkeypatch.setattr(_build, "MANIFEST", str(mpath))
     monkeypatch.setattr(_build, "OUT", str(lib))
     assert bench.kernel_isa_hash("void k_sweep_lean4<2, unsigned char, true, true>(DevP, Lean4P)") == "aaaa000011112222"
@@ -138,8 +138,9 @@ def test_counters_are_tied_to_the_kernel_code_object(tmp_path, monkeypatch):
     assert not kept and "not recorded" in err
     kept, err = bench.check_counters(dict(c, isa_hash="bbbb000011112222"), desc)   # the kernel was recompiled since
     assert not kept and "code object:" in err and "bbbb000011112222" in err and "aaaa000011112222" in err
-    # a manifest older than the library does not describe it: nothing is trusted
-    os.utime(lib, (os.path.getmtime(mpath) + 60,) * 2)
+    # a manifest written for another library file does not describe this one: nothing is trusted
+    lib.write_text("another library")
+    os.utime(lib, (os.path.getmtime(lib) + 5,) * 2)
     assert bench.kernel_isa_hash("k_sweep_lean4<2,unsignedchar,true,true>") is None
     kept, err = bench.check_counters(c, desc)
     assert not kept and "no manifest" in err
