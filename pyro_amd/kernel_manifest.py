@@ -199,11 +199,13 @@ def bless(man, commit, evidence, path=VERIFIED):
     run = len(ver["runs"])
     ver["runs"].append({"commit": commit, "evidence": evidence, "kernels": len(man)})
     for k, v in man.items():
-        e = ver["kernels"].setdefault(k, {"exact": [], "loose": [], "runs": []})
+        e = ver["kernels"].setdefault(k, {"exact": [], "loose": [], "runs": []})     # runs[i]: the runs hash i was part of
         if v["exact"] not in e["exact"]:
             e["exact"].append(v["exact"])
             e["loose"].append(v["loose"])
-            e["runs"].append(run)
+            e["runs"].append([run])
+        else:
+            e["runs"][e["exact"].index(v["exact"])].append(run)
     json.dump(ver, open(path, "w"), indent=0, sort_keys=True)
     return ver
 

@@ -121,4 +121,4 @@ def test_verified_list_names_its_evidence():
     ver = KM.load_verified()
     assert ver["runs"] and all(r["commit"] and r["evidence"] for r in ver["runs"])
     for k, e in list(ver["kernels"].items())[:50]:
-        assert len(e["exact"]) == len(e["loose"]) == len(e["runs"]) and all(0 <= r < len(ver["runs"]) for r in e["runs"]), k
+        assert len(e["exact"]) == len(e["loose"]) == len(e["runs"]) and all(0 <= r < len(ver["runs"]) for rs in e["runs"] for r in rs), k
