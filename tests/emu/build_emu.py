@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""
+TEST INFRASTRUCTURE.  Builds tests/emu/_build/libpyrovi_emu.so: the SOURCES of libpyrovi (pyro_amd/csrc/*, include/pyrovi.h)
+compiled as ordinary C++ for the host against the HIP emulation of tests/emu/include/hip/hip_runtime.h + tests/emu/emu_runtime.cpp.
+The product sources are not touched and carry no emulation switch: a copy is transformed textually --
+
+  * `asm volatile(...)` statements (GCN wait counts, register-class constraints that keep a value live) are dropped;
+  * `extern __shared__ ... T name[];` becomes a pointer to the workgroup's emulated dynamic LDS;
+  * `__attribute__((address_space(N)))` is dropped (LDS addresses are host pointers below 4 GiB in the emulation);
+
+-- and everything else (builtins, vector types, the runtime API, launches) is supplied by the header.  Nothing in pyro_amd/ loads
+this library; tests/test_emu_cpu.py points PYROVI_LIB at it in subprocesses.
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "pyro_amd", "csrc")
+BUILD = os.path.join(HERE, "_build")
+OUT = os.path.join(BUILD, "libpyrovi_emu.so")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+UNITS = ["pyrovi.hip", "f64.hip", "lean.hip"]
+
+
+def transform(text):
+    # asm statements: whole statement up to the terminating ");"
+    text = re.sub(r'asm\s+volatile\s*\((?:[^;"]|"[^"]*")*\)\s*;', "/* asm */ ;", text)
+    # dynamic LDS declarations
+    text = re.sub(r'extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_][\w ]*?)\s+(\w+)\[\];',
+                  r'\1* \2 = (\1*)emu::g_blk->dyn_lds;', text)
+    text = re.sub(r'__attribute__\(\(address_space\(\d+\)\)\)', "", text)
+    return text
+
+
+def sources():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(ROOT, "include", "pyrovi.h"),
+                                                                      os.path.join(HERE, "emu_runtime.cpp"),
+                                                                      os.path.join(HERE, "include", "hip", "hip_runtime.h"), __file__]
+
+
+def up_to_date():
+    return os.path.exists(OUT) and all(os.path.getmtime(p) <= os.path.getmtime(OUT) for p in sources())
+
+
+def build(force=False, verbose=False, opt="-O1"):
+    if up_to_date() and not force:
+        return OUT
+    src = os.path.join(BUILD, "pyro_amd", "csrc")
+    os.makedirs(src, exist_ok=True)
+    os.makedirs(os.path.join(BUILD, "include"), exist_ok=True)
+    shutil.copy(os.path.join(ROOT, "include", "pyrovi.h"), os.path.join(BUILD, "include", "pyrovi.h"))
+    for f in os.listdir(CSRC):
+        with open(os.path.join(CSRC, f)) as fi, open(os.path.join(src, f.replace(".hip", ".cpp")), "w") as fo:
+            fo.write(transform(fi.read()))
+    flags = [opt, "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-strict-aliasing", "-fno-omit-frame-pointer", "-mno-omit-leaf-frame-pointer", "-pthread",
+             "-I" + os.path.join(HERE, "include"), "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-Wno-unused-value",
+             "-Wno-deprecated-declarations", "-DPVI_EMU_BUILD=1"]
+    objs, procs = [], []
+    for u in UNITS + ["emu_runtime.cpp"]:
+        s = os.path.join(src, u.replace(".hip", ".cpp")) if u != "emu_runtime.cpp" else os.path.join(HERE, u)
+        o = os.path.join(BUILD, os.path.basename(s) + ".o")
+        objs.append(o)
+        cmd = [CLANG] + flags + ["-c", "-o", o, s]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd, cwd=src, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = False
+    for cmd, p in procs:
+        out = p.communicate()[0]
+        if p.returncode:
+            failed = True
+            sys.stderr.write(out[-6000:] if not verbose else out)
+    if failed:
+        raise RuntimeError("emulated build failed")
+    cmd = [CLANG, "-shared", "-fPIC", "-pthread", "-o", OUT] + objs
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
