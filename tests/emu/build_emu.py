@@ -6,7 +6,8 @@ The product sources are not touched and carry no emulation switch: a copy is tra
 
   * `asm volatile(...)` statements (GCN wait counts, register-class constraints that keep a value live) are dropped;
   * `extern __shared__ ... T name[];` becomes a pointer to the workgroup's emulated dynamic LDS;
-  * `__attribute__((address_space(N)))` is dropped (LDS addresses are host pointers below 4 GiB in the emulation);
+  * `__attribute__((address_space(N)))` is dropped (LDS addresses are host pointers below 16 MiB in the emulation);
+  * `(const void*)kernel<...>` (a kernel taken as an untyped pointer for a cooperative launch) becomes emu::coop_thunk(&kernel<...>);
 
 -- and everything else (builtins, vector types, the runtime API, launches) is supplied by the header.  Nothing in pyro_amd/ loads
 this library; tests/test_emu_cpu.py points PYROVI_LIB at it in subprocesses.
@@ -33,6 +34,8 @@ def transform(text):
     text = re.sub(r'extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_][\w ]*?)\s+(\w+)\[\];',
                   r'\1* \2 = (\1*)emu::g_blk->dyn_lds;', text)
     text = re.sub(r'__attribute__\(\(address_space\(\d+\)\)\)', "", text)
+    # kernels taken as untyped function pointers (cooperative launches): record how to call them
+    text = re.sub(r'\(const void\*\)(k_\w+<[^<>;]*>)', r'emu::coop_thunk(&\1)', text)
     return text
 
 

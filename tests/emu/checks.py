@@ -347,6 +347,67 @@ def check_table_tier_spline_rollout():
         print(fn.__name__, args, "ok")
 
 
+def check_multi_sweep_launches():
+    """Batches as ONE cooperative launch with grid barriers between the sweeps: k_sweep64m (float64; verified on hardware) and
+    k_sweep_leanm (the 2-D float32 window sweep; MULTI32=1, never run on hardware) against one launch per sweep -- J, pi, every
+    sweep's statistics and the stop sweep are the same bits; odd batch sizes, a tolerance stop inside a batch, a restart."""
+    import test_gpu_parity as T
+    g = T.load("config1_pendulum_101x101x11")
+    p = T.oracle_problem(g, O.DYN_PENDULUM, O.pendulum_consts())
+    m = T.native_problem(p)
+    m.terminal_cost()
+    sm, nm = m.sweep(5000, 1.0, 0.1)
+    with _native.overrides(MULTI="0"):          # (the form of a handle's batches is decided at its first sweep)
+        s1 = T.native_problem(p)
+        s1.terminal_cost()
+        ss, ns = s1.sweep(5000, 1.0, 0.1)
+    print("k_sweep64m:", m.describe()[:150])
+    assert "multi=1" in m.describe() and "kernel=k_sweep64m<" in m.describe() and "multi=0" in s1.describe()
+    assert nm == ns == int(g["sweeps"]) == 618
+    assert np.array_equal(np.array(sm), np.array(ss)) and np.array_equal(m.get_J(), s1.get_J()) and np.array_equal(m.get_pi(), s1.get_pi())
+    assert rel(m.get_J(), g["J"].ravel()) < 1e-12
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.dynamic import mountaincar
+    from pyro_amd.planning import discretizer
+    with quiet():
+        mc = mountaincar.MountainCar()
+        gm = discretizer.GridDynamicSystem(mc, [51, 41], [5])
+        cfm = costfunction.QuadraticCostFunction.from_sys(mc)
+        cfm.INF = 100
+    for name, extra in (("pendulum:61,61:9:float32", {}), ("pendulum:61,61:9:float32", {"LSPLIT": "0"}), ("pendulum:101,101:11:float32", {}),
+                        ("pendulum:45,75:101:float32", {}), ("mountaincar", {}), ("mountaincar", {"LSPLIT": "0"})):
+        cfg = {"grid_sys": gm, "cf": cfm} if name == "mountaincar" else build(name)
+        with _native.overrides(MULTI32="1", **extra):
+            a = make(cfg, "float32")._p
+            sa, na = a.sweep(1, 1.0, -1.0)
+        with _native.overrides(MULTI="0", **extra):
+            b = make(cfg, "float32")._p
+            sb, nb = b.sweep(1, 1.0, -1.0)
+        print("k_sweep_leanm:", name, a.describe()[:170])
+        assert "multi=1" in a.describe() and "kernel=k_sweep_leanm<" in a.describe(), a.describe()
+        assert "multi=0" in b.describe() and "kernel=k_sweep_lean<" in b.describe(), b.describe()
+        assert np.array_equal(np.array(sa), np.array(sb))
+        for n in (1, 2, 3, 7, 20, 5):
+            sa, na = a.sweep(n, 1.0, -1.0)
+            sb, nb = b.sweep(n, 1.0, -1.0)
+            assert na == nb == n and np.array_equal(np.array(sa), np.array(sb)), (name, n)
+            assert np.array_equal(a.get_J(), b.get_J()) and np.array_equal(a.get_pi(), b.get_pi()), (name, n)
+        probe, _ = b.sweep(20, 1.0, -1.0)
+        a.sweep(20, 1.0, -1.0)
+        tol = float(np.array(probe)[-1, 3]) * 0.7
+        sa, na = a.sweep(300, 1.0, tol)
+        sb, nb = b.sweep(300, 1.0, tol)
+        assert na == nb and 0 < na < 300, (name, na, nb, tol)
+        assert np.array_equal(np.array(sa), np.array(sb)) and np.array_equal(a.get_J(), b.get_J()) and np.array_equal(a.get_pi(), b.get_pi())
+        assert np.array_equal(a.get_J(prev=True), b.get_J(prev=True))
+        for h in (a, b):
+            h.terminal_cost()
+        sa, _ = a.sweep(15, 1.0, -1.0)
+        sb, _ = b.sweep(15, 1.0, -1.0)
+        assert np.array_equal(np.array(sa), np.array(sb)) and np.array_equal(a.get_J(), b.get_J())
+        print("   stop sweep %d of 300 at tol %.4g: identical" % (na, tol))
+
+
 CHECKS = {k[6:]: v for k, v in globals().items() if k.startswith("check_")}
 
 if __name__ == "__main__":

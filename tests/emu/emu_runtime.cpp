@@ -52,7 +52,8 @@ struct Fiber {
     unsigned long long val = 0, aux = 0, res = 0;
     unsigned p[4] = {0, 0, 0, 0};
 };
-static constexpr size_t STACK_BYTES = 256 * 1024, MAX_THREADS = 1024, LDS_BYTES = 512 * 1024, GUARD = 256 * 1024;
+static constexpr uintptr_t COOP_BASE = 0x900000, COOP_END = 0xFF0000;   // LDS arenas of cooperative launches
+static constexpr size_t STACK_BYTES = 256 * 1024, MAX_THREADS = 1024, LDS_BYTES = 256 * 1024, GUARD = 128 * 1024;   // (a workgroup's LDS is at most 160 KiB)
 struct Worker {                 // per host thread: fiber stacks, LDS arena, the workgroup being run
     char* stacks = nullptr;
     char* lds = nullptr;
@@ -81,10 +82,10 @@ static Worker* worker() {
     // on that for cells whose value it discards (a masked cell's address can lie a few slots outside the window).  Here the arena
     // sits between two read-only zero pages ranges of GUARD bytes: such reads see zeros, an out-of-range WRITE faults (a bug).
     void* p = MAP_FAILED;
-    for (int tries = 0; tries < 15 && p == MAP_FAILED; ++tries) {
+    for (int tries = 0; tries < 16 && p == MAP_FAILED; ++tries) {
         const int slot = g_arena_slot.fetch_add(1);
         char* want = (char*)(uintptr_t)(0x100000ull + (unsigned long long)slot * (LDS_BYTES + 2 * GUARD));
-        if ((uintptr_t)want + LDS_BYTES + 2 * GUARD > (1ull << 24)) break;
+        if ((uintptr_t)want + LDS_BYTES + 2 * GUARD > COOP_BASE) break;
         p = mmap(want, LDS_BYTES + 2 * GUARD, PROT_READ, MAP_PRIVATE | MAP_ANONYMOUS | MAP_FIXED_NOREPLACE, -1, 0);
         if (p != MAP_FAILED && p != (void*)want) {
             munmap(p, LDS_BYTES + 2 * GUARD);
@@ -96,7 +97,7 @@ static Worker* worker() {
         }
     }
     if (p == MAP_FAILED) {
-        fprintf(stderr, "emu: cannot map an LDS arena below 16 MiB (vm.mmap_min_addr? more than 15 host threads?)\n");
+        fprintf(stderr, "emu: cannot map an LDS arena below 16 MiB (vm.mmap_min_addr? more than 16 host threads?)\n");
         abort();
     }
     w->lds = (char*)p;
@@ -402,6 +403,60 @@ void launch(dim3 grid, dim3 block, size_t lds, const std::function<void()>& body
         p->wait();
     }
 }
+// ---- cooperative launches: every workgroup resident at once, one host thread each (grid barriers spin on atomics) -------------------
+static std::mutex g_reg_mu;
+static std::vector<std::pair<const void*, Invoker>> g_reg;
+void register_kernel(const void* fn, Invoker inv) {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    for (auto& e : g_reg)
+        if (e.first == fn) return;
+    g_reg.emplace_back(fn, inv);
+}
+static Invoker find_kernel(const void* fn) {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    for (auto& e : g_reg)
+        if (e.first == fn) return e.second;
+    return nullptr;
+}
+static int launch_coop(const void* fn, dim3 grid, dim3 block, void** args, size_t lds) {
+    Invoker inv = find_kernel(fn);
+    if (!inv) return 1;
+    const unsigned long long nb = (unsigned long long)grid.x * grid.y * grid.z;
+    const size_t T = (size_t)block.x * block.y * block.z;
+    size_t stride = 16 * 1024;
+    while (stride < lds + 8192) stride *= 2;       // (the arena + a zero page on either side)
+    if (nb == 0 || nb > 512 || T > MAX_THREADS || nb * stride > COOP_END - COOP_BASE) {
+        fprintf(stderr, "emu: cooperative launch of %llu workgroups x %zu work-items x %zu LDS bytes is beyond the emulation\n", nb, T, lds);
+        return 1;
+    }
+    void* region = mmap((void*)COOP_BASE, nb * stride, PROT_READ, MAP_PRIVATE | MAP_ANONYMOUS | MAP_FIXED_NOREPLACE, -1, 0);
+    if (region != (void*)COOP_BASE) {
+        fprintf(stderr, "emu: cannot map the LDS region of a cooperative launch\n");
+        return 1;
+    }
+    g_launches.fetch_add(1);
+    const std::function<void()> body = [=]() { inv(fn, args); };
+    const Idx3 bdim{block.x, block.y, block.z}, gdim{grid.x, grid.y, grid.z};
+    std::vector<std::thread> th;
+    for (unsigned long long b = 0; b < nb; ++b)
+        th.emplace_back([&, b]() {
+            Worker w;     // a worker of its own: `static thread_local` (= __shared__) objects are per workgroup this way
+            w.stacks = (char*)mmap(nullptr, STACK_BYTES * T, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+            if (w.stacks == MAP_FAILED) abort();
+            w.lds = (char*)COOP_BASE + b * stride + 4096;
+            mprotect(w.lds, stride - 8192, PROT_READ | PROT_WRITE);
+            w.f.resize(T);
+            Worker* keep = g_w;
+            g_w = &w;
+            const Idx3 bid{(unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((unsigned long long)grid.x * grid.y))};
+            run_block(&w, bid, bdim, gdim, lds, body, "cooperative kernel");
+            g_w = keep;
+            munmap(w.stacks, STACK_BYTES * T);
+        });
+    for (auto& t : th) t.join();
+    munmap(region, nb * stride);
+    return 0;
+}
 }  // namespace emu
 
 extern "C" unsigned long long emu_inactive_lane_reads() { return emu::g_inactive_reads.load(); }
@@ -467,9 +522,11 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
 hipError_t hipGetLastError() { return hipSuccess; }
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : e == hipErrorOutOfMemory ? "out of memory" : "invalid value"; }
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) {
-    *v = a == hipDeviceAttributeMultiprocessorCount ? 256 : 0;   // no cooperative launches: the multi-sweep kernels are not modelled
+    *v = a == hipDeviceAttributeMultiprocessorCount ? 256 : 1;   // (cooperative launches: emu::launch_coop)
     return hipSuccess;
 }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 1; return hipSuccess; }
-hipError_t hipLaunchCooperativeKernel(const void*, dim3, dim3, void**, unsigned, hipStream_t) { return hipErrorInvalidValue; }
+hipError_t hipLaunchCooperativeKernel(const void* fn, dim3 grid, dim3 block, void** args, unsigned lds, hipStream_t) {
+    return emu::launch_coop(fn, grid, block, args, lds) ? hipErrorInvalidValue : hipSuccess;
+}

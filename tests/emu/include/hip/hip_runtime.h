@@ -22,6 +22,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <type_traits>
+#include <utility>
 
 #define PVI_EMU 1
 #define __global__
@@ -80,6 +82,21 @@ unsigned long long collective(Op op, unsigned long long val, unsigned long long 
 void barrier();
 void launch(dim3 grid, dim3 block, size_t dyn_lds_bytes, const std::function<void()>& body, const char* name);
 void yield_host();
+// Cooperative launches go through a function POINTER and an array of argument addresses: build_emu.py rewrites every
+// `(const void*)kernel<...>` of the sources into emu::coop_thunk(&kernel<...>), which records how to call that kernel.
+typedef void (*Invoker)(const void* fn, void** args);
+void register_kernel(const void* fn, Invoker inv);
+template <class... A>
+struct Thunk {
+    template <size_t... I>
+    static void go(void (*fn)(A...), void** args, std::index_sequence<I...>) { fn(*(typename std::remove_reference<A>::type*)args[I]...); }
+    static void call(const void* fn, void** args) { go((void (*)(A...))fn, args, std::index_sequence_for<A...>{}); }
+};
+template <class... A>
+static inline const void* coop_thunk(void (*fn)(A...)) {
+    register_kernel((const void*)fn, &Thunk<A...>::call);
+    return (const void*)fn;
+}
 }  // namespace emu
 
 #define threadIdx (emu::g_me->tid)

@@ -66,6 +66,12 @@ def test_emulated_feedback_outside_4d_grids(emu_lib):
     run_check(emu_lib, "feedback_2d_explicit_node")
 
 
+def test_emulated_multi_sweep_launches(emu_lib):
+    """Cooperative launches: every workgroup a host thread of its own, the grid barriers spin on real atomics."""
+    out = run_check(emu_lib, "multi_sweep_launches")
+    assert "kernel=k_sweep_leanm<1,unsignedchar,true>" in out and "kernel=k_sweep_leanm<4,unsignedchar" in out and "kernel=k_sweep64m<" in out
+
+
 def test_emulated_slabs_and_the_halo_rule(emu_lib):
     out = run_check(emu_lib, "slabs_and_halo")
     assert "refused (PVI_EHALO)" in out
