@@ -81,6 +81,29 @@ def test_emulated_tiers_on_the_reference_goldens(emu_lib):
     run_check(emu_lib, "table_tier_spline_rollout")
 
 
+def test_driver_entry_points_end_to_end_on_the_emulated_library(emu_lib):
+    """What the driver runs on the GPU box at round end -- __graft_entry__.smoke() and bench.py's line -- end to end against the
+    emulated library (a tiny custom workload): the code paths exist, the JSON line carries every contract key, and a line that
+    does not come from pyro_amd/libpyrovi.so says so (`invalid`)."""
+    import json
+    env = dict(os.environ, PYROVI_LIB=emu_lib, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "pendulum:41,41:7:float32", "--steps", "3", "--warmup", "1", "--cpu-budget", "1"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().split("\n")[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"]) and line["roofline"]["bound"] == "hbm"
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"]) and line["cpu_baseline"]["kind"] == "port"
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["dtype"] == "f32" and line["vs_baseline"] is None
+    assert line["unverified_kernels"] == 0 and line["kernel_verified"] is True          # (this build's manifest against the verified list)
+    assert "not the product library" in line["invalid"]
+    assert line["step_rel_err_vs_cpu"] <= 1e-5
+
+
 def test_the_product_never_loads_the_emulated_library():
     """grep: nothing under pyro_amd/, bench.py or __graft_entry__.py names tests/emu or libpyrovi_emu."""
     bad = []
