@@ -591,8 +591,8 @@ def run_single(args):
         print("bench.py: ACCURACY CHECK FAILED: " + "; ".join(failures), file=sys.stderr)
     from pyro_amd import _native, _build
     if os.path.realpath(_native.LIB_PATH) != os.path.realpath(_build.OUT):
-        # PYROVI_LIB points somewhere else (a sanitizer or experiment build, the emulated library of tests/emu): the figures
-        # of this line are not the product's
+        # PYROVI_LIB points somewhere else (a sanitizer or experiment build, a test build): the figures of this line are not
+        # the product's
         out["invalid"] = "PYROVI_LIB=%s: not the product library pyro_amd/libpyrovi.so" % _native.LIB_PATH
     emit(out)
 
