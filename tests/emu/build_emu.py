@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "pyro_amd", "csrc")
 BUILD = os.path.join(HERE, "_build")
 OUT = os.path.join(BUILD, "libpyrovi_emu.so")
+RCCL = os.path.join(BUILD, "librccl_emu.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 UNITS = ["pyrovi.hip", "f64.hip", "lean.hip"]
 
@@ -41,12 +42,12 @@ def transform(text):
 
 def sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(ROOT, "include", "pyrovi.h"),
-                                                                      os.path.join(HERE, "emu_runtime.cpp"),
+                                                                      os.path.join(HERE, "emu_runtime.cpp"), os.path.join(HERE, "rccl_emu.cpp"),
                                                                       os.path.join(HERE, "include", "hip", "hip_runtime.h"), __file__]
 
 
 def up_to_date():
-    return os.path.exists(OUT) and all(os.path.getmtime(p) <= os.path.getmtime(OUT) for p in sources())
+    return os.path.exists(OUT) and os.path.exists(RCCL) and all(os.path.getmtime(p) <= os.path.getmtime(OUT) for p in sources())
 
 
 def build(force=False, verbose=False, opt="-O1"):
@@ -81,6 +82,9 @@ def build(force=False, verbose=False, opt="-O1"):
         raise RuntimeError("emulated build failed")
     cmd = [CLANG, "-shared", "-fPIC", "-pthread", "-o", OUT] + objs
     subprocess.run(cmd, check=True)
+    # the stand-in for librccl.so (PVI_RCCL_LIB): rank processes of one machine over a shared-memory segment
+    subprocess.run([CLANG, "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(HERE, "include"), "-o", RCCL,
+                    os.path.join(HERE, "rccl_emu.cpp"), "-lrt"], check=True)
     return OUT
 
 

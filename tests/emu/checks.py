@@ -408,6 +408,47 @@ def check_multi_sweep_launches():
         print("   stop sweep %d of 300 at tol %.4g: identical" % (na, tol))
 
 
+def check_rccl_shards():
+    """The in-library multi-GPU path (pvi_shard_*: axis-0 slabs, halo exchange by ncclSend / ncclRecv in one group, all-gather by
+    broadcasts, three-double all-reduce, boundary-first overlap schedule) with 1, 2 and 3 rank PROCESSES over the stand-in for
+    librccl (tests/emu/rccl_emu.cpp: shared memory) -- on hardware two ranks have never shared the test box's one GPU (RCCL
+    refuses), so this is the first time the exchange code runs with a neighbour: the concatenated slabs equal the whole-grid
+    handle bit for bit, statistics and stop sweep included."""
+    import subprocess
+    import tempfile
+    import test_gpu_parity as T
+    rccl = os.path.join(os.path.dirname(_native.LIB_PATH), "librccl_emu.so")
+    assert os.path.exists(rccl), rccl
+    env = dict(os.environ, PVI_RCCL_LIB=rccl, PVI_EMU_THREADS="3")
+    for case, world, overlap, tol in (("pendulum:61,61:9:float64", 1, False, 8.0), ("pendulum:61,61:9:float64", 2, False, 8.0),
+                                      ("cartpole:11,12,9,10:5:float32", 2, True, 60.0), ("cartpole:11,12,9,10:5:float32", 3, True, 60.0),
+                                      ("cartpole:11,12,9,10:5:float32", 3, False, 60.0)):
+        with tempfile.TemporaryDirectory() as tmp:
+            script = os.path.join(tmp, "rccl_rank.py")
+            open(script, "w").write(T._RCCL_RANK % dict(root=ROOT))
+            idfile = os.path.join(tmp, "comm.id")
+            procs = [subprocess.Popen([sys.executable, script, str(r), str(world), case, idfile, os.path.join(tmp, "r%d.npz" % r), str(int(overlap)), repr(tol)],
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
+            outs = [(p.wait(timeout=600), p.stdout.read()) for p in procs]
+            assert all(rc == 0 and ("RCCL-RANK-OK %d" % r) in o for r, (rc, o) in enumerate(outs)), "\n".join(o[-1500:] for _, o in outs)
+            parts = [np.load(os.path.join(tmp, "r%d.npz" % r)) for r in range(world)]
+        cfg = build(case)
+        with quiet():
+            h = cfg["grid_sys"]._device_problem(cost=cfg["cf"].device_cost(), dtype=cfg["dtype"])
+        h.terminal_cost()
+        st5, _ = h.sweep(5, 1.0, -1.0)
+        st, n = h.sweep(400, 1.0, tol)
+        desc = str(parts[0]["desc"])
+        print("%s world %d overlap %s: stop after %d sweeps; %s" % (case, world, overlap, n, desc[:110]))
+        assert "comm=rccl" in desc and ("rank=0/%d" % world) in desc, desc
+        assert 0 < n < 400 and all(int(p["n"]) == n for p in parts), (n, [int(p["n"]) for p in parts])
+        assert np.array_equal(np.concatenate([p["J"] for p in parts]), h.get_J())
+        assert np.array_equal(np.concatenate([p["pi"] for p in parts]), h.get_pi())
+        for p in parts:
+            assert np.allclose(p["st5"], st5[-1], rtol=1e-12) and np.allclose(p["st"], st[-1], rtol=1e-12)
+        h.close()
+
+
 CHECKS = {k[6:]: v for k, v in globals().items() if k.startswith("check_")}
 
 if __name__ == "__main__":

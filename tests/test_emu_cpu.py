@@ -72,6 +72,13 @@ def test_emulated_multi_sweep_launches(emu_lib):
     assert "kernel=k_sweep_leanm<1,unsignedchar,true>" in out and "kernel=k_sweep_leanm<4,unsignedchar" in out and "kernel=k_sweep64m<" in out
 
 
+def test_emulated_in_library_rccl_path_with_two_and_three_rank_processes(emu_lib):
+    """pvi_shard_* over a stand-in for librccl (shared memory between rank processes): the exchange code with a NEIGHBOUR, which the
+    one-GPU test box has never allowed (RCCL refuses two ranks on one device)."""
+    out = run_check(emu_lib, "rccl_shards")
+    assert "rccl_ranks=3" in out and "send/recv+overlap pieces=2" in out
+
+
 def test_emulated_slabs_and_the_halo_rule(emu_lib):
     out = run_check(emu_lib, "slabs_and_halo")
     assert "refused (PVI_EHALO)" in out
