@@ -646,6 +646,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-secondary", action="store_true", help="headline workload only")
     ap.add_argument("--no-selftest", action="store_true", help="N > 1: skip the sharded-against-one-rank check of a small grid")
+    ap.add_argument("--selftest-grid", default=None, help="N > 1: another grid for that check (default cartpole:41,13,17,15:7:float32)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--converged", action="store_true", default=None,
                     help="solve the workload to tol 0.1 in float32 and float64 and report the J* difference "

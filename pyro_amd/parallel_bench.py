@@ -232,7 +232,9 @@ def run(args):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    torch.cuda.set_device(local)
+    has_cuda = torch.cuda.is_available()      # (False only in the CPU tests of this harness: tests/test_emu_cpu.py)
+    if has_cuda:
+        torch.cuda.set_device(local)
     # gloo and RCCL print banners on stdout from C: the ONE JSON line goes to the real stdout, everything else to stderr
     import sys
     sys.stdout.flush()
@@ -243,7 +245,7 @@ def run(args):
     # (pvi_shard_*).  The process group also carries an nccl backend for device tensors; it is only ever initialised when
     # PVI_TORCH_COLLECTIVES=1 selects the Python-driven schedule, or when the in-library communicator fails to start.
     via_torch = bool(int(os.environ.get("PVI_TORCH_COLLECTIVES", "0")))
-    dist.init_process_group("cpu:gloo,cuda:nccl" if world > 1 else "gloo", rank=rank, world_size=world)
+    dist.init_process_group("cpu:gloo,cuda:nccl" if world > 1 and has_cuda else "gloo", rank=rank, world_size=world)
     steps = args.steps if args.steps is not None else 20
     warmup = args.warmup if args.warmup is not None else 2
     headline = args.workload or "c3w"
@@ -257,7 +259,8 @@ def run(args):
             ref = _one_gpu_rate(ref_cfg, local, ref_sweeps)
         t0 = time.perf_counter()
         drv = _Driver(cfg, dist, torch, rank, world, local, via_torch)
-        torch.cuda.synchronize()
+        if has_cuda:
+            torch.cuda.synchronize()
         setup_s = time.perf_counter() - t0
         elapsed, batches, st = _timed(drv, dist, torch, steps, warmup)
         per_rank = _rank_timing(drv, dist, world)
@@ -272,7 +275,8 @@ def run(args):
     if not getattr(args, "no_selftest", False):
         err = None
         try:
-            selftest = _selftest(dist, torch, rank, world, local, via_torch)
+            grid = getattr(args, "selftest_grid", None)
+            selftest = _selftest(dist, torch, rank, world, local, via_torch, **({"name": grid} if grid else {}))
         except Exception as e:                            # noqa: BLE001
             err = "%s: %s" % (type(e).__name__, e)
         errs = [None] * world
@@ -319,7 +323,9 @@ def run(args):
                 frag["strong_scaling_speedup"] = frag["value"] / ref if ref else None
                 out["secondary"] = {"c4": frag}
     if rank == 0:
-        from pyro_amd import benchline
+        from pyro_amd import _build, _native, benchline
+        if os.path.realpath(_native.LIB_PATH) != os.path.realpath(_build.OUT):     # (a sanitizer, experiment or test build)
+            out["invalid"] = "PYROVI_LIB=%s: not the product library pyro_amd/libpyrovi.so" % _native.LIB_PATH
         benchline.emit(out, fd=real_stdout)       # compact headline on stdout, the full record on stderr / gpurun_out
     _barrier(dist, torch)
     dist.destroy_process_group()

@@ -465,8 +465,16 @@ extern "C" unsigned long long emu_launch_count() { return emu::g_launches.load()
 // ---- runtime API ------------------------------------------------------------------------------------------------------------------
 struct emu_stream { int unused; };
 struct emu_event { std::chrono::steady_clock::time_point t; };
-hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
+static int emu_devices() {   // PVI_EMU_DEVICES: how many "devices" a process sees (all of them are this host; default 1)
+    static const int n = [] {
+        const char* e = getenv("PVI_EMU_DEVICES");
+        const int v = e ? atoi(e) : 1;
+        return v < 1 ? 1 : v > 64 ? 64 : v;
+    }();
+    return n;
+}
+hipError_t hipGetDeviceCount(int* n) { *n = emu_devices(); return hipSuccess; }
+hipError_t hipSetDevice(int d) { return d >= 0 && d < emu_devices() ? hipSuccess : hipErrorInvalidValue; }
 // live "device" allocations, for tests that inspect or poison device memory (emu_alloc_count / emu_alloc_get)
 static std::mutex g_alloc_mu;
 static std::vector<std::pair<void*, size_t>> g_allocs;

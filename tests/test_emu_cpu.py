@@ -111,6 +111,31 @@ def test_driver_entry_points_end_to_end_on_the_emulated_library(emu_lib):
     assert line["step_rel_err_vs_cpu"] <= 1e-5
 
 
+def test_multi_gpu_bench_harness_end_to_end_on_the_emulated_library(emu_lib):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` -- the command the driver uses for the scaling runs,
+    which has never run with N > 1 on hardware -- against the emulated library and the librccl stand-in: two rank processes,
+    the in-library RCCL path (not the torch fall-back), the self-test of a sharded solve against one rank's, ONE JSON line."""
+    import json
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYROVI_LIB=emu_lib, PVI_RCCL_LIB=os.path.join(os.path.dirname(emu_lib), "librccl_emu.so"), PVI_EMU_DEVICES="8",
+               PVI_EMU_THREADS="3", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "bench.py", "--gpus", "2", "--workload", "cartpole:11,12,9,10:5:float32", "--steps", "3",
+                        "--warmup", "1", "--no-cpu", "--selftest-grid", "cartpole:9,7,8,9:5:float32"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["rccl_ranks"] == 2 and line["selftest"]["ok"] is True
+    assert "RCCL inside libpyrovi" in line["config"]["parallelism"] and "p2p send/recv" in line["config"]["parallelism"]
+    assert line["value"] > 0 and line["scaling"] == "strong" and "not the product library" in line["invalid"]
+    assert len(line["per_rank"]["sweep_ms"]) == 2
+
+
 def test_the_product_never_loads_the_emulated_library():
     """grep: nothing under pyro_amd/, bench.py or __graft_entry__.py names tests/emu or libpyrovi_emu."""
     bad = []
