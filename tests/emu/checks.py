@@ -110,10 +110,13 @@ def check_f32_paths():
         n = 6
         J, pi, Jprev, c = oracle_sweeps(cfg, n)
         outs = {}
+        full = name.startswith("cartpole")          # (every variant on the cart-pole; the launch-order ones once is enough)
         for tag, ov in (("default", {}), ("win1", {"WIN": "1"}), ("tab0", {"WIN": "1", "TABLES": "0"}), ("tab1", {"WIN": "1", "TABLES": "1"}),
                         ("tab2", {"WIN": "1", "TABLES": "2"}), ("clamp", {"WIN": "1", "VMASK": "0"}), ("noxcd", {"WIN": "1", "NO_XCD": "1"}),
                         ("bands2", {"WIN": "1", "BANDS": "2"}), ("shape", {"WIN": "1", "TV0": "3", "TV1": "7"}),
                         ("win0", {"WIN": "0"}), ("fast", {"NO_LEAN": "1"}), ("exact32", {"NO_FAST": "1"})):
+            if not full and tag in ("tab1", "noxcd", "bands2", "shape", "win0"):
+                continue
             dp = make(cfg, "float32", **ov)
             dp._p.sweep(n, 1.0, -1.0)
             outs[tag] = (dp._p.get_J(), dp._p.get_pi(), dp._p.describe())
@@ -122,6 +125,8 @@ def check_f32_paths():
             assert e <= 2e-6, (name, tag, e)
             dp._p.close()
         for tag in ("win1", "tab0", "tab1", "tab2", "clamp", "noxcd", "bands2", "shape"):   # the 4-D window sweep: the same bits whatever the variant
+            if tag not in outs:
+                continue
             assert "win=1" in outs[tag][2] and "kernel=k_sweep_lean4<" in outs[tag][2], (tag, outs[tag][2])
             assert np.array_equal(outs[tag][0], outs["win1"][0]) and np.array_equal(outs[tag][1], outs["win1"][1]), tag
         assert tokens(outs["tab2"][2])["tables"] == tokens(outs["win1"][2])["tables"]             # declared == found

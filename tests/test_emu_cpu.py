@@ -34,10 +34,21 @@ def emu_lib():
     return build_emu.build()
 
 
+def _all_cpus():
+    """(preexec) The C oracle's OpenMP settings (OMP_PROC_BIND / OMP_PLACES, set by oracle/c_oracle.py earlier in the same pytest
+    session) leave THIS process bound to one core, and children inherit that: give the emulator's host threads the machine back."""
+    os.sched_setaffinity(0, range(os.cpu_count() or 1))
+
+
+def _env(lib, **extra):
+    env = {k: v for k, v in os.environ.items() if not k.startswith("OMP_")}
+    env.update(PYROVI_LIB=lib, PYTHONPATH=ROOT, **extra)
+    return env
+
+
 def run_check(lib, *names, timeout=900):
-    env = dict(os.environ, PYROVI_LIB=lib, PYTHONPATH=ROOT)
-    r = subprocess.run([sys.executable, os.path.join(EMU, "checks.py")] + list(names), env=env, cwd=ROOT, capture_output=True, text=True,
-                       timeout=timeout)
+    r = subprocess.run([sys.executable, os.path.join(EMU, "checks.py")] + list(names), env=_env(lib), cwd=ROOT, capture_output=True, text=True,
+                       timeout=timeout, preexec_fn=_all_cpus)
     sys.stdout.write(r.stdout[-4000:])
     assert r.returncode == 0, (r.stdout[-3000:] + "\n" + r.stderr[-3000:])
     for n in names:
@@ -93,11 +104,12 @@ def test_driver_entry_points_end_to_end_on_the_emulated_library(emu_lib):
     emulated library (a tiny custom workload): the code paths exist, the JSON line carries every contract key, and a line that
     does not come from pyro_amd/libpyrovi.so says so (`invalid`)."""
     import json
-    env = dict(os.environ, PYROVI_LIB=emu_lib, PYTHONPATH=ROOT)
-    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    env = _env(emu_lib)
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600,
+                       preexec_fn=_all_cpus)
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     r = subprocess.run([sys.executable, "bench.py", "--workload", "pendulum:41,41:7:float32", "--steps", "3", "--warmup", "1", "--cpu-budget", "1"],
-                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=600, preexec_fn=_all_cpus)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().split("\n")[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
@@ -120,12 +132,11 @@ def test_multi_gpu_bench_harness_end_to_end_on_the_emulated_library(emu_lib):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, PYROVI_LIB=emu_lib, PVI_RCCL_LIB=os.path.join(os.path.dirname(emu_lib), "librccl_emu.so"), PVI_EMU_DEVICES="8",
-               PVI_EMU_THREADS="3", PYTHONPATH=ROOT)
+    env = _env(emu_lib, PVI_RCCL_LIB=os.path.join(os.path.dirname(emu_lib), "librccl_emu.so"), PVI_EMU_DEVICES="8", PVI_EMU_THREADS="3")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), "bench.py", "--gpus", "2", "--workload", "cartpole:11,12,9,10:5:float32", "--steps", "3",
                         "--warmup", "1", "--no-cpu", "--selftest-grid", "cartpole:9,7,8,9:5:float32"],
-                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900, preexec_fn=_all_cpus)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
