@@ -309,16 +309,19 @@ def check_slabs_and_halo():
                 s.set_J(full[r0:r1].ravel(), r0, r1 - r0)
         print(name, dtype, "slabs == whole grid", slabs[0].describe()[:80])
     # the reach sits on a whole number of cells (+- 1e-6): the rule's halo agrees, one row less is refused / reported
-    dims, k = (31, 29), 2
-    lb, ub = [-3.2, -6.0], [3.2, 6.0]
-    lv = O.make_levels(np.array(lb), np.array(ub), np.array(dims))
-    ul = O.make_levels(np.array([-10.0]), np.array([10.0]), np.array([7]))
-    step0 = (ub[0] - lb[0]) / (dims[0] - 1)
-    for eps in (-1.5e-6, -4e-7, 0.0, 4e-7):
-        dt = (k + eps) * step0 / ub[1]
-        p = O.Problem(lv, ul, dt, O.DYN_PENDULUM, O.pendulum_consts(), np.eye(2), np.eye(1), np.zeros((2, 2)), np.zeros(2), np.zeros(1), 1e4, 0.2)
+    for system, dims, k, lb, ub in (("pendulum", (31, 29), 2, [-3.2, -6.0], [3.2, 6.0]),
+                                    ("cartpole", (13, 9, 11, 10), 2, [-4.0, -3.2, -5.0, -6.0], [4.0, 3.2, 5.0, 6.0])):
+      n = len(dims)
+      lv = O.make_levels(np.array(lb), np.array(ub), np.array(dims))
+      ul = O.make_levels(np.array([-10.0]), np.array([10.0]), np.array([7 if n == 2 else 5]))
+      step0 = (ub[0] - lb[0]) / (dims[0] - 1)
+      dyn, consts = (O.DYN_PENDULUM, O.pendulum_consts()) if n == 2 else (O.DYN_CARTPOLE, O.cartpole_consts())
+      for eps in (-1.5e-6, -4e-7, 0.0, 4e-7):
+        dt = (k + eps) * step0 / ub[n // 2]
+        p = O.Problem(lv, ul, dt, dyn, consts, np.eye(n), np.eye(1), np.zeros((n, n)), np.zeros(n), np.zeros(1), 1e4, 0.2)
         need = parallel._rows_for_reach(k + eps)
         mid = dims[0] // 2
+        plane = int(np.prod(dims[1:]))
         whole = T.native_problem(p, dtype="float32")
         whole.terminal_cost()
         whole.sweep(1, 1.0, -1.0)
@@ -326,7 +329,7 @@ def check_slabs_and_halo():
         ok.terminal_cost()
         ok.sweep_async(1.0)
         ok.sweep_stats()
-        assert np.array_equal(ok.get_J(), whole.get_J()[:mid * dims[1]]), eps
+        assert np.array_equal(ok.get_J(), whole.get_J()[:mid * plane]), eps
         outcome = "agrees"
         try:
             short = T.native_problem(p, dtype="float32", rows=(0, mid), halo=(0, need - 1))
@@ -335,10 +338,10 @@ def check_slabs_and_halo():
             short.sweep_stats()
             # (not refused and not reported: then every gather stayed inside the stored rows -- x_next exactly on a level takes the
             #  cell below it, whose upper corner is the last stored row -- and the result must be the whole grid's, bit for bit)
-            assert np.array_equal(short.get_J(), whole.get_J()[:mid * dims[1]]), (eps, short.describe())
+            assert np.array_equal(short.get_J(), whole.get_J()[:mid * plane]), (eps, short.describe())
         except _native.NativeError as e:
             outcome = "refused (%s)" % ("PVI_EHALO" if e.code == _native.PVI_EHALO else str(e)[:60])
-        print("reach %d%+.1e cells: halo %d ok; halo %d %s" % (k, eps, need, need - 1, outcome))
+        print("%s reach %d%+.1e cells: halo %d ok (%s); halo %d %s" % (system, k, eps, need, ok.describe().split()[0], need - 1, outcome))
 
 
 def check_table_tier_spline_rollout():
