@@ -50,8 +50,21 @@ def up_to_date():
     return os.path.exists(OUT) and os.path.exists(RCCL) and all(os.path.getmtime(p) <= os.path.getmtime(OUT) for p in sources())
 
 
-def build(force=False, verbose=False, opt="-O1"):
-    if up_to_date() and not force:
+def asan_runtime():
+    return subprocess.run([CLANG, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True, check=True).stdout.strip()
+
+
+def build(force=False, verbose=False, opt="-O1", asan=False):
+    """asan=True: the same library under AddressSanitizer (_build/libpyrovi_emu_asan.so; LD_PRELOAD asan_runtime() under python):
+    "device" memory is the sanitizer's heap, so a kernel that reads or writes one element beyond an allocation is reported with
+    the kernel's source line.  (ROCm's own ASan runtime cannot be preloaded on the GPU boxes: DESIGN.md 4.7.)"""
+    if asan:
+        return _build(os.path.join(BUILD, "libpyrovi_emu_asan.so"), "asan", ["-fsanitize=address", "-shared-libasan"], force, verbose, opt)
+    return _build(OUT, "", [], force, verbose, opt)
+
+
+def _build(OUT, tag, extra, force, verbose, opt):
+    if os.path.exists(OUT) and os.path.exists(RCCL) and all(os.path.getmtime(p) <= os.path.getmtime(OUT) for p in sources()) and not force:
         return OUT
     src = os.path.join(BUILD, "pyro_amd", "csrc")
     os.makedirs(src, exist_ok=True)
@@ -62,11 +75,11 @@ def build(force=False, verbose=False, opt="-O1"):
             fo.write(transform(fi.read()))
     flags = [opt, "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-strict-aliasing", "-fno-omit-frame-pointer", "-mno-omit-leaf-frame-pointer", "-pthread",
              "-I" + os.path.join(HERE, "include"), "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-Wno-unused-value",
-             "-Wno-deprecated-declarations", "-DPVI_EMU_BUILD=1"]
+             "-Wno-deprecated-declarations", "-DPVI_EMU_BUILD=1"] + extra
     objs, procs = [], []
     for u in UNITS + ["emu_runtime.cpp"]:
         s = os.path.join(src, u.replace(".hip", ".cpp")) if u != "emu_runtime.cpp" else os.path.join(HERE, u)
-        o = os.path.join(BUILD, os.path.basename(s) + ".o")
+        o = os.path.join(BUILD, os.path.basename(s) + tag + ".o")
         objs.append(o)
         cmd = [CLANG] + flags + ["-c", "-o", o, s]
         if verbose:
@@ -80,7 +93,7 @@ def build(force=False, verbose=False, opt="-O1"):
             sys.stderr.write(out[-6000:] if not verbose else out)
     if failed:
         raise RuntimeError("emulated build failed")
-    cmd = [CLANG, "-shared", "-fPIC", "-pthread", "-o", OUT] + objs
+    cmd = [CLANG, "-shared", "-fPIC", "-pthread", "-o", OUT] + extra + objs
     subprocess.run(cmd, check=True)
     # the stand-in for librccl.so (PVI_RCCL_LIB): rank processes of one machine over a shared-memory segment
     subprocess.run([CLANG, "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(HERE, "include"), "-o", RCCL,
@@ -89,4 +102,4 @@ def build(force=False, verbose=False, opt="-O1"):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, asan="--asan" in sys.argv))

@@ -36,6 +36,17 @@ emu_switch:
     .size emu_switch, .-emu_switch
 )");
 
+// AddressSanitizer build (build_emu.py --asan): every stack switch is announced, so that the sanitizer knows which stack it is on
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#include <sanitizer/common_interface_defs.h>
+#define EMU_ASAN 1
+#endif
+#endif
+#ifndef EMU_ASAN
+#define EMU_ASAN 0
+#endif
+
 namespace emu {
 thread_local FiberPub* g_me = nullptr;
 thread_local BlockCtx* g_blk = nullptr;
@@ -51,6 +62,7 @@ struct Fiber {
     int npcs = 0;
     unsigned long long val = 0, aux = 0, res = 0;
     unsigned p[4] = {0, 0, 0, 0};
+    void* asan_fake = nullptr;
 };
 static constexpr uintptr_t COOP_BASE = 0x900000, COOP_END = 0xFF0000;   // LDS arenas of cooperative launches
 static constexpr size_t STACK_BYTES = 256 * 1024, MAX_THREADS = 1024, LDS_BYTES = 256 * 1024, GUARD = 128 * 1024;   // (a workgroup's LDS is at most 160 KiB)
@@ -63,6 +75,8 @@ struct Worker {                 // per host thread: fiber stacks, LDS arena, the
     BlockCtx ctx;
     int cur = -1;
     const char* kname = "";
+    const void* sched_stack = nullptr;   // (ASan: the scheduler's stack, learnt by the first fiber that starts)
+    size_t sched_size = 0;
 };
 static thread_local Worker* g_w = nullptr;
 static std::atomic<int> g_arena_slot{0};
@@ -109,9 +123,15 @@ static Worker* worker() {
 static void fiber_entry() {
     Worker* w = g_w;
     Fiber& me = w->f[(size_t)w->cur];
+#if EMU_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &w->sched_stack, &w->sched_size);
+#endif
     (*w->body)();
     me.state = ST_DONE;
     void* dummy;
+#if EMU_ASAN
+    __sanitizer_start_switch_fiber(nullptr, w->sched_stack, w->sched_size);   // (nullptr: this fiber's stack is done with)
+#endif
     emu_switch(&dummy, w->sched_sp);
     abort();  // a finished fiber is never resumed
 }
@@ -120,7 +140,13 @@ static inline void park(State s) {
     Worker* w = g_w;
     Fiber& me = w->f[(size_t)w->cur];
     me.state = s;
+#if EMU_ASAN
+    __sanitizer_start_switch_fiber(&me.asan_fake, w->sched_stack, w->sched_size);
+#endif
     emu_switch(&me.sp, w->sched_sp);
+#if EMU_ASAN
+    __sanitizer_finish_switch_fiber(me.asan_fake, &w->sched_stack, &w->sched_size);
+#endif
 }
 
 // Program position of a parked lane: the chain of return addresses from the kernel's outermost frame down to the collective
@@ -167,7 +193,14 @@ void yield_host() { sched_yield(); }
 static inline void resume(Worker* w, int i) {
     w->cur = i;
     g_me = &w->f[(size_t)i].pub;
+#if EMU_ASAN
+    void* fake = nullptr;
+    __sanitizer_start_switch_fiber(&fake, w->f[(size_t)i].stack, STACK_BYTES);
+#endif
     emu_switch(&w->sched_sp, w->f[(size_t)i].sp);
+#if EMU_ASAN
+    __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#endif
 }
 
 // one group of lanes of a wave (the same operation at the same call site) completes its collective operation
@@ -418,14 +451,22 @@ static Invoker find_kernel(const void* fn) {
         if (e.first == fn) return e.second;
     return nullptr;
 }
+static size_t coop_stride(size_t lds) {
+    size_t stride = 16 * 1024;
+    while (stride < lds + 8192) stride *= 2;       // (the arena + a zero page on either side)
+    return stride;
+}
+int coop_capacity(size_t lds) {   // workgroups of a cooperative launch the LDS region below 16 MiB has room for
+    const size_t n = (COOP_END - COOP_BASE) / coop_stride(lds);
+    return (int)(n > 512 ? 512 : n);
+}
 static int launch_coop(const void* fn, dim3 grid, dim3 block, void** args, size_t lds) {
     Invoker inv = find_kernel(fn);
     if (!inv) return 1;
     const unsigned long long nb = (unsigned long long)grid.x * grid.y * grid.z;
     const size_t T = (size_t)block.x * block.y * block.z;
-    size_t stride = 16 * 1024;
-    while (stride < lds + 8192) stride *= 2;       // (the arena + a zero page on either side)
-    if (nb == 0 || nb > 512 || T > MAX_THREADS || nb * stride > COOP_END - COOP_BASE) {
+    const size_t stride = coop_stride(lds);
+    if (nb == 0 || nb > (unsigned long long)coop_capacity(lds) || T > MAX_THREADS) {
         fprintf(stderr, "emu: cooperative launch of %llu workgroups x %zu work-items x %zu LDS bytes is beyond the emulation\n", nb, T, lds);
         return 1;
     }
@@ -530,11 +571,12 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
 hipError_t hipGetLastError() { return hipSuccess; }
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : e == hipErrorOutOfMemory ? "out of memory" : "invalid value"; }
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) {
-    *v = a == hipDeviceAttributeMultiprocessorCount ? 256 : 1;   // (cooperative launches: emu::launch_coop)
+    *v = 1;   // ONE "compute unit" (hipOccupancyMaxActiveBlocksPerMultiprocessor then is the whole device's capacity); cooperative launches: yes
     return hipSuccess;
 }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
-hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 1; return hipSuccess; }
+namespace emu { int coop_capacity(size_t lds); }
+hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t lds) { *n = emu::coop_capacity(lds); return hipSuccess; }
 hipError_t hipLaunchCooperativeKernel(const void* fn, dim3 grid, dim3 block, void** args, unsigned lds, hipStream_t) {
     return emu::launch_coop(fn, grid, block, args, lds) ? hipErrorInvalidValue : hipSuccess;
 }
