@@ -351,8 +351,8 @@ def test_float32_slabs_refuse_or_agree_when_the_reach_sits_on_a_whole_number_of_
             s.set_J(full[r0:r1].ravel(), r0, r1 - r0)
     for s in slabs:
         s.close()
-    # one row less than the rule: refused at create, reported by the sweep, or -- where float32 rounding keeps every gather inside
-    # the rows that ARE stored (eps < 0) -- still the whole grid's bits; a silent difference is the failure
+    # one row less than the rule: refused at create, reported by the sweep, or -- where every gather stays inside the rows that ARE
+    # stored -- still the whole grid's bits; a silent difference is the failure
     whole.terminal_cost()
     whole.sweep(1, 1.0, -1.0)
     try:
@@ -368,7 +368,9 @@ def test_float32_slabs_refuse_or_agree_when_the_reach_sits_on_a_whole_number_of_
     except _native.NativeError as e:
         assert e.code == _native.PVI_EHALO, e
     else:
-        assert eps < 0 and np.array_equal(short.get_J(), whole.get_J()[:mid * int(np.prod(dims[1:]))]), (system, k, eps, short.describe())
+        # neither refused nor reported: every gather stayed inside the rows that ARE stored (x_next exactly on a level takes the
+        # cell below it, whose upper corner is the last stored row) -- then the result must be the whole grid's, bit for bit
+        assert np.array_equal(short.get_J(), whole.get_J()[:mid * int(np.prod(dims[1:]))]), (system, k, eps, short.describe())
     short.close()
     whole.close()
 
