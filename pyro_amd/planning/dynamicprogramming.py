@@ -101,7 +101,7 @@ class DynamicProgramming:
     # ------------------------------------------------------------------ device engine
     # interpolants of J_k the sweeps implement (discretizer.py:570-587 hands dp.interpol_method to RegularGridInterpolator
     # every sweep; 'bicubic' is this build's name for the RectBivariateSpline subclass, dynamicprogramming.py:578-614)
-    _INTERPOLATIONS = ("linear", "nearest", "bicubic")
+    _INTERPOLATIONS = ("linear", "slinear", "nearest", "bicubic")
 
     @property
     def interpol_method(self):
@@ -112,12 +112,15 @@ class DynamicProgramming:
         """The reference passes dp.interpol_method to the interpolant of every sweep (dynamicprogramming.py:186-189,
         discretizer.py:570-587); here the interpolation is compiled into the engine, so:
           'linear'  -- every tier (default);
+          'slinear' -- RegularGridInterpolator's order-1 spline: the SAME interpolant as 'linear' evaluated by another code path of
+                       scipy (the reference's own 12-sweep solves with the two differ by 1.8e-15 of max J, identical policies:
+                       tests/golden/slinear_*.npz).  Served by the linear sweeps of every tier; no engine is rebuilt;
           'nearest' -- RegularGridInterpolator(method='nearest'): the TABLE tier implements it (the interval and fraction of
                        every cell are fixed when the tables are packed).  Assigning it rebuilds the engine on the table
                        tier from the reference's look-up tables and carries the current cost-to-go (J, J_next, pi, k) over:
                        the new interpolant applies from the next sweep on, as in the reference; a sharded engine raises;
           'bicubic' -- only as the class DynamicProgramming2DRectBivariateSpline;
-        anything else ('cubic', 'slinear', 'quintic', 'pchip') raises instead of silently computing with another interpolant."""
+        anything else ('cubic', 'quintic', 'pchip') raises instead of silently computing with another interpolant."""
         if value not in self._INTERPOLATIONS:
             raise NotImplementedError("interpol_method %r: the GPU sweeps implement %s" % (value, ", ".join(self._INTERPOLATIONS)))
         if value == "bicubic" or self.INTERPOLATION == "bicubic":
@@ -129,7 +132,8 @@ class DynamicProgramming:
             return
         old = self.__dict__.get("_interpol_method", "linear")
         self.__dict__["_interpol_method"] = value
-        if "_p" in self.__dict__ and value != old:
+        same = {"slinear": "linear"}          # (methods the same engine serves)
+        if "_p" in self.__dict__ and same.get(value, value) != same.get(old, old):
             if self.comm is not None or not hasattr(self, "_rebuild_engine"):
                 self.__dict__["_interpol_method"] = old
                 raise NotImplementedError("interpol_method %r on this engine (sharded grids and policy evaluation keep the "

@@ -358,6 +358,10 @@ def check_table_tier_spline_rollout():
         with quiet():
             fn(*args)
         print(fn.__name__, args, "ok")
+    import test_gpu_zz_unproven as Z
+    with quiet():
+        Z.test_slinear_interpolation_through_the_class_surface_matches_reference_golden()
+    print("interpol_method = 'slinear' against the reference's own slinear solves: ok")
 
 
 def check_multi_sweep_launches():

@@ -696,7 +696,36 @@ def case_nearest():
     save("nearest_cartpole_7x9x7x9x3", **out4)
 
 
-CASES = dict(nearest=case_nearest, longcar=case_longcar, car=case_car, suspension=case_suspension, floatmass=case_floatmass, acrobot=case_acrobot, mintime=case_mintime, mountaincar=case_mountaincar, spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
+def case_slinear():
+    """interpol_method = 'slinear' (the order-1 spline of RegularGridInterpolator: the same interpolant as 'linear', evaluated by
+    another code path of scipy): the LUT class on a 2-D pendulum and a 4-D cart-pole, and the same solves with 'linear' beside
+    them -- the two differ by rounding only, which is what lets the GPU build serve 'slinear' with its linear sweeps."""
+    s, g, q = _pendulum_problem((31, 21), (5,))
+    out = _meta(s, g, q)
+    with quiet():
+        for tag in ("slinear", "linear"):
+            dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, q)
+            dp.save_time_history = False
+            dp.interpol_method = tag
+            dp.compute_steps(12)
+            out["J12_" + tag] = dp.J.copy(); out["pi12_" + tag] = dp.pi.copy()
+    save("slinear_pendulum_31x21x5", **out)
+    with quiet():
+        c = cartpole.CartPole()
+        g4 = discretizer.GridDynamicSystem(c, [7, 9, 7, 9], [3])
+        q4 = costfunction.QuadraticCostFunction.from_sys(c)
+        q4.INF = 1000.0
+        out4 = _meta(c, g4, q4)
+        for tag in ("slinear", "linear"):
+            d4 = dynamicprogramming.DynamicProgrammingWithLookUpTable(g4, q4)
+            d4.save_time_history = False
+            d4.interpol_method = tag
+            d4.compute_steps(4)
+            out4["J4_" + tag] = d4.J.copy(); out4["pi4_" + tag] = d4.pi.copy()
+    save("slinear_cartpole_7x9x7x9x3", **out4)
+
+
+CASES = dict(slinear=case_slinear, nearest=case_nearest, longcar=case_longcar, car=case_car, suspension=case_suspension, floatmass=case_floatmass, acrobot=case_acrobot, mintime=case_mintime, mountaincar=case_mountaincar, spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
              policy_eval=case_policy_eval, cost_kat=case_cost_kat, grid_kat=case_grid_kat,
              pendulum_small=case_pendulum_small, config1=case_config1, lowdef=case_lowdef,
              pendulum_demo=case_pendulum_demo, cartpole_small=case_cartpole_small,
