@@ -165,6 +165,70 @@ def load_manifest(path, library=None):
     return man
 
 
+# ---- the shipped binary against the assembly the manifest was hashed from ------------------------------------------------------------
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+OBJCOPY = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
+_BRANCH = re.compile(r"^(s_branch|s_cbranch_\w+|s_call_b64|s_setpc_b64)\b")
+
+
+def _instr(line):
+    """One instruction in a form that the assembly printer and the disassembler share: no comments, single spaces, branch targets
+    dropped (a label there, an address here); None for labels and directives."""
+    line = line.split("//")[0].split(";")[0].strip()
+    if not line or line.endswith(":") or line.startswith("."):
+        return None
+    line = re.sub(r"\s+", " ", line)
+    m = _BRANCH.match(line)
+    return m.group(1) if m else line
+
+
+def code_objects(so_path, outdir):
+    """The gfx950 ELF code objects inside a host library's .hip_fatbin section (one clang offload bundle per translation unit)."""
+    import struct
+    os.makedirs(outdir, exist_ok=True)
+    fat = os.path.join(outdir, "fatbin.bin")
+    subprocess.run([OBJCOPY, "--dump-section", ".hip_fatbin=" + fat, so_path], check=True)
+    d = open(fat, "rb").read()
+    out = []
+    for i, m in enumerate(re.finditer(b"\x7fELF", d)):
+        o = m.start()
+        e_shoff = struct.unpack_from("<Q", d, o + 0x28)[0]
+        e_shentsize, e_shnum = struct.unpack_from("<HH", d, o + 0x3A)
+        path = os.path.join(outdir, "co%d.elf" % i)
+        open(path, "wb").write(d[o:o + e_shoff + e_shentsize * e_shnum])
+        out.append(path)
+    return out
+
+
+def verify_binary(so_path, sfiles, outdir=None):
+    """Is the device code inside `so_path` the code the manifest describes?  Disassembles every kernel of the library's code
+    objects and compares the instruction stream with the assembly files (`-S --offload-device-only` of the same compilation) the
+    manifest was hashed from.  Returns (kernels compared, [kernels that differ])."""
+    outdir = outdir or os.path.join("/tmp", "pvi_verify_binary_%d" % os.getpid())
+    dis = {}
+    for elf in code_objects(so_path, outdir):
+        cur = None
+        for ln in subprocess.run([OBJDUMP, "-d", elf], capture_output=True, text=True, check=True).stdout.split("\n"):
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+            if m:
+                cur = m.group(1)
+                dis[cur] = []
+            elif cur is not None:
+                x = _instr(ln)
+                if x:
+                    dis[cur].append(x)
+    bad, n = [], 0
+    for path in sfiles:
+        for name, lines in split_kernels(path).items():
+            if not any(ln.startswith(".amdhsa_kernel") for ln in lines):
+                continue
+            a = [x for x in (_instr(ln) for ln in lines if not ln.startswith((".amdhsa", ".end_amdhsa"))) if x]
+            n += 1
+            if name not in dis or dis[name][:len(a)] != a:      # (the disassembly pads a function to its alignment: cut there)
+                bad.append(name)
+    return n, bad
+
+
 def build(tree=ROOT, outdir=None, extra=()):
     outdir = outdir or os.path.join("/tmp", "pvi_kernel_manifest_%d" % os.getpid())
     return manifest_of(compile_units(tree, outdir, extra))

@@ -122,3 +122,16 @@ def test_verified_list_names_its_evidence():
     assert ver["runs"] and all(r["commit"] and r["evidence"] for r in ver["runs"])
     for k, e in list(ver["kernels"].items())[:50]:
         assert len(e["exact"]) == len(e["loose"]) == len(e["runs"]) and all(0 <= r < len(ver["runs"]) for rs in e["runs"] for r in rs), k
+
+
+def test_the_manifest_describes_the_device_code_inside_the_library():
+    """The manifest is hashed from `hipcc -S --offload-device-only`, the library is linked from `hipcc -c` of the same sources with the
+    same flags: two compilations.  This closes the loop -- the code objects are extracted from libpyrovi.so's .hip_fatbin, every
+    kernel is disassembled, and its instruction stream must be the assembly's, instruction for instruction (branch targets aside)."""
+    from pyro_amd import _build
+    _build.build(verbose=False)
+    sfiles = [os.path.join(_build.OBJ, "%s.s" % u) for u in _build.UNITS]
+    if not all(os.path.exists(f) for f in sfiles) or not os.path.exists(KM.OBJDUMP):
+        pytest.skip("no device assembly / llvm-objdump here")
+    n, bad = KM.verify_binary(_build.OUT, sfiles)
+    assert n > 400 and not bad, (n, bad[:10])
