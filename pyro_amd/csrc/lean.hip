@@ -515,6 +515,9 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
     if (ovr_is("RS_CONG", 1) && !(tv1 & 1))   // experiments: the pitch congruent to the (even) width of the widest tile modulo 32; 16-byte
         while ((rs - tv1) & 31) rs += 2;       // fill stores need an even pitch
     size_t lds = (size_t)std::max(summary[0], 1) * (size_t)rs * 8 + 256;
+    // (the swapped cart-pole order pads every window plane to whole groups of 32 slots -- sweep_lean4.inc lean4_plane_slots: at most
+    //  31 slots for each of the <= pair planes x position rows planes of a window)
+    if (h->d.dynamics_id == PVI_DYN_CARTPOLE_SW) lds += (size_t)31 * 8 * (size_t)std::max(summary[4], 1) * (size_t)std::max(summary[2], 1);
     if (narrower) {  // the widest tile whose window lets as many workgroups onto a CU as the register budget does (24 waves)
         *narrower = 0;
         const size_t room = (size_t)160 * 1024 / (size_t)std::max(1, 1536 / threads) - 512;

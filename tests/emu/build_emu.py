@@ -28,7 +28,12 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 UNITS = ["pyrovi.hip", "f64.hip", "lean.hip"]
 
 
+LDSTRACE = False     # (build(ldstrace=True): the gathers of the 4-D window sweep report their LDS addresses)
+
+
 def transform(text):
+    if LDSTRACE:     # sweep_lean4.inc lean4_gather: g.r[k] = *(lds_vpair*)(size_t)(ADDR);
+        text = re.sub(r'\*\(lds_vpair\*\)\(size_t\)\(([^;]+)\);', r'emu::lds_rd<v2f>(\1);', text)
     # asm statements: whole statement up to the terminating ");"
     text = re.sub(r'asm\s+volatile\s*\((?:[^;"]|"[^"]*")*\)\s*;', "/* asm */ ;", text)
     # dynamic LDS declarations
@@ -54,10 +59,14 @@ def asan_runtime():
     return subprocess.run([CLANG, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True, check=True).stdout.strip()
 
 
-def build(force=False, verbose=False, opt="-O1", asan=False):
+def build(force=False, verbose=False, opt="-O1", asan=False, ldstrace=False):
     """asan=True: the same library under AddressSanitizer (_build/libpyrovi_emu_asan.so; LD_PRELOAD asan_runtime() under python):
     "device" memory is the sanitizer's heap, so a kernel that reads or writes one element beyond an allocation is reported with
     the kernel's source line.  (ROCm's own ASan runtime cannot be preloaded on the GPU boxes: DESIGN.md 4.7.)"""
+    global LDSTRACE
+    LDSTRACE = bool(ldstrace)
+    if ldstrace:
+        return _build(os.path.join(BUILD, "libpyrovi_emu_ldstrace.so"), "ldstrace", [], force, verbose, opt)
     if asan:
         return _build(os.path.join(BUILD, "libpyrovi_emu_asan.so"), "asan", ["-fsanitize=address", "-shared-libasan"], force, verbose, opt)
     return _build(OUT, "", [], force, verbose, opt)
@@ -66,7 +75,7 @@ def build(force=False, verbose=False, opt="-O1", asan=False):
 def _build(OUT, tag, extra, force, verbose, opt):
     if os.path.exists(OUT) and os.path.exists(RCCL) and all(os.path.getmtime(p) <= os.path.getmtime(OUT) for p in sources()) and not force:
         return OUT
-    src = os.path.join(BUILD, "pyro_amd", "csrc")
+    src = os.path.join(BUILD, "pyro_amd" + ("_" + tag if tag else ""), "csrc")
     os.makedirs(src, exist_ok=True)
     os.makedirs(os.path.join(BUILD, "include"), exist_ok=True)
     shutil.copy(os.path.join(ROOT, "include", "pyrovi.h"), os.path.join(BUILD, "include", "pyrovi.h"))
@@ -102,4 +111,4 @@ def _build(OUT, tag, extra, force, verbose, opt):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, asan="--asan" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, asan="--asan" in sys.argv, ldstrace="--ldstrace" in sys.argv))

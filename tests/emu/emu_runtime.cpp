@@ -77,6 +77,7 @@ struct Worker {                 // per host thread: fiber stacks, LDS arena, the
     const char* kname = "";
     const void* sched_stack = nullptr;   // (ASan: the scheduler's stack, learnt by the first fiber that starts)
     size_t sched_size = 0;
+    std::vector<std::vector<unsigned>> lds_trace;   // (--ldstrace builds) per work-item: the LDS byte addresses it read, in order
 };
 static thread_local Worker* g_w = nullptr;
 static std::atomic<int> g_arena_slot{0};
@@ -188,6 +189,60 @@ __attribute__((noinline)) unsigned long long collective(Op op, unsigned long lon
     return me.res;
 }
 void barrier() { park(ST_BAR); }
+
+// ---- LDS trace --------------------------------------------------------------------------------------------------------------------
+static std::atomic<unsigned long long> g_lds_reads{0}, g_lds_cycles{0}, g_lds_ideal{0};
+void lds_note(unsigned byte_adr) {
+    Worker* w = g_w;
+    if ((int)w->lds_trace.size() <= w->cur) w->lds_trace.resize(MAX_THREADS);
+    w->lds_trace[(size_t)w->cur].push_back(byte_adr);
+}
+// The k-th traced read of every lane of a wave is one ds_read_b64 of the wave (the lanes of a wave run the same action loop).
+// gfx950 serves it in two groups of 32 lanes; a group takes one LDS cycle when no two DISTINCT 8-byte slots fall on the same pair
+// of banks (slot mod 32), N cycles for N of them (tools/lds_conflict_model4.py, calibrated on tools/ldsbank.hip in round 4).
+static void lds_account(Worker* w, int T) {
+    if (w->lds_trace.empty()) return;
+    unsigned long long reads = 0, cycles = 0, ideal = 0;
+    for (int base = 0; base < T; base += 64) {
+        const int nl = std::min(64, T - base);
+        size_t len = 0;
+        for (int l = 0; l < nl; ++l) len = std::max(len, w->lds_trace[(size_t)(base + l)].size());
+        static const int dump = getenv("PVI_EMU_LDSDUMP") ? atoi(getenv("PVI_EMU_LDSDUMP")) : 0;
+        static std::atomic<int> dumped{0};
+        for (size_t k = 0; k < len; ++k) {
+            ++reads;
+            if (dump && base == 0 && k >= 16 && k < 20 && dumped.fetch_add(1) < dump) {
+                fprintf(stderr, "LDSDUMP block (%u) read %zu:", w->ctx.bid.x, k);
+                for (int l = 0; l < nl; ++l) {
+                    const auto& t = w->lds_trace[(size_t)(base + l)];
+                    fprintf(stderr, " %d", k < t.size() ? (int)(t[k] >> 3) - (int)((uintptr_t)w->lds >> 3) : -1);
+                }
+                fprintf(stderr, "\n");
+            }
+            for (int g = 0; g < 64; g += 32) {
+                unsigned slots[32];
+                int n = 0;
+                for (int l = g; l < std::min(g + 32, nl); ++l) {
+                    const auto& t = w->lds_trace[(size_t)(base + l)];
+                    if (k >= t.size()) continue;
+                    const unsigned s = t[k] >> 3;
+                    bool dup = false;
+                    for (int i = 0; i < n && !dup; ++i) dup = slots[i] == s;
+                    if (!dup) slots[n++] = s;
+                }
+                if (!n) continue;
+                int cnt[32] = {0}, mx = 0;
+                for (int i = 0; i < n; ++i) mx = std::max(mx, ++cnt[slots[i] & 31u]);
+                cycles += (unsigned long long)mx;
+                ++ideal;
+            }
+        }
+    }
+    for (int i = 0; i < T; ++i) w->lds_trace[(size_t)i].clear();
+    g_lds_reads.fetch_add(reads);
+    g_lds_cycles.fetch_add(cycles);
+    g_lds_ideal.fetch_add(ideal);
+}
 void yield_host() { sched_yield(); }
 
 static inline void resume(Worker* w, int i) {
@@ -357,6 +412,7 @@ static void run_block(Worker* w, Idx3 bid, Idx3 bdim, Idx3 gdim, size_t lds, con
             }
         if (!any) break;  // every work-item has ended
     }
+    lds_account(w, T);
     g_me = nullptr;
 }
 
@@ -500,6 +556,16 @@ static int launch_coop(const void* fn, dim3 grid, dim3 block, void** args, size_
 }
 }  // namespace emu
 
+extern "C" void emu_lds_stats(unsigned long long* out3, int reset) {   // {wave-level reads, LDS cycles, cycles without any conflict}
+    out3[0] = emu::g_lds_reads.load();
+    out3[1] = emu::g_lds_cycles.load();
+    out3[2] = emu::g_lds_ideal.load();
+    if (reset) {
+        emu::g_lds_reads.store(0);
+        emu::g_lds_cycles.store(0);
+        emu::g_lds_ideal.store(0);
+    }
+}
 extern "C" unsigned long long emu_inactive_lane_reads() { return emu::g_inactive_reads.load(); }
 extern "C" unsigned long long emu_launch_count() { return emu::g_launches.load(); }
 

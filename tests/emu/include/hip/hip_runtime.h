@@ -82,6 +82,14 @@ unsigned long long collective(Op op, unsigned long long val, unsigned long long 
 void barrier();
 void launch(dim3 grid, dim3 block, size_t dyn_lds_bytes, const std::function<void()>& body, const char* name);
 void yield_host();
+// LDS access trace (build_emu.py --ldstrace rewrites the gathers of the 4-D window sweep into emu::lds_rd): bank-conflict counts
+// of the production kernel's own addresses under the bank model of tools/lds_conflict_model4.py
+void lds_note(unsigned byte_adr);
+template <class T>
+static inline T lds_rd(unsigned byte_adr) {
+    lds_note(byte_adr);
+    return *(const T*)(size_t)byte_adr;
+}
 // Cooperative launches go through a function POINTER and an array of argument addresses: build_emu.py rewrites every
 // `(const void*)kernel<...>` of the sources into emu::coop_thunk(&kernel<...>), which records how to call that kernel.
 typedef void (*Invoker)(const void* fn, void** args);
