@@ -514,6 +514,10 @@ static int lean4_try(pvi_problem* h, const std::vector<int2>& pt0, int cap, int 
     int rs = std::max(4, (summary[1] + 3) & ~3);
     if (ovr_is("RS_CONG", 1) && !(tv1 & 1))   // experiments: the pitch congruent to the (even) width of the widest tile modulo 32; 16-byte
         while ((rs - tv1) & 31) rs += 2;       // fill stores need an even pitch
+    if (const char* e = ovr("RS4")) {          // experiments: the pitch itself (even, not below the longest window row)
+        const int want = atoi(e);
+        if (want >= rs && !(want & 1)) rs = want;
+    }
     size_t lds = (size_t)std::max(summary[0], 1) * (size_t)rs * 8 + 256;
     // (the swapped cart-pole order pads every window plane to whole groups of 32 slots -- sweep_lean4.inc lean4_plane_slots: at most
     //  31 slots for each of the <= pair planes x position rows planes of a window)

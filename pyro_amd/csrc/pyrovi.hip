@@ -1385,6 +1385,7 @@ static const char* const OVERRIDE_KEYS[] = {
     "JWIN",        // 0: the register-table sweeps gather J from memory instead of the workgroup's LDS window
     "REGTAB",      // 0: the multi-sweep launch of 2-D grids recomputes the per-action cells every sweep (fence-based barrier)
     "VMASK",       // 0: the 4-D float32 window sweep clamps and compares cell indices instead of reading set-up's validity bits
+    "RS4",         // 4-D float32 window sweep: the row pitch in 8-byte slots (even, at least the longest window row; bank experiments)
     "RS_CONG",     // 1: 4-D float32 window sweep, row pitch congruent to the widest tile's (even) width modulo 32 (bank experiments)
     "MULTI32",     // 1: batches of the 2-D float32 window sweep as one cooperative launch (k_sweep_leanm; opt-in until measured)
     "FBCHECK",     // 1: PVI_FLAG_F32_FEEDBACK on a 4-D grid runs the epilogue with the corruption detector (k_sweep_lean4fbc; opt-in until it has run)
