@@ -153,7 +153,7 @@ def test_swapped_internal_order_matches_the_reference_order(dims, nact, fb):
         return dp
     d64, d32, dsw = make("float64"), make("float32"), make("float32", "swapped")
     desc = dsw._p.describe()
-    assert "order=swapped" in desc and "tables=10" in desc and ("kernel=k_sweep_lean4fb<" if fb else "kernel=k_sweep_lean4<") in desc, desc
+    assert "order=swapped" in desc and "tables=10" in desc and "win=1" in desc, desc      # (`kernel=` names the LAST launch: checked below)
     assert np.allclose(dsw.J, d32.J, rtol=1e-6, atol=0.0)            # the terminal cost, transposed back
     worst = 0.0
     for k in range(5):
@@ -168,6 +168,7 @@ def test_swapped_internal_order_matches_the_reference_order(dims, nact, fb):
         print("after %d sweeps: swapped %.3e reference order %.3e" % (60 * (k + 1), e_sw, e_32))
         assert e_sw <= (1e-6 if fb else 1e-5), (k, e_sw, e_32)
         assert np.allclose(st["sw"], st["f64"], rtol=1e-5, atol=1e-5 * m), (st["sw"], st["f64"])
+    assert ("kernel=k_sweep_lean4fb<12," if fb else "kernel=k_sweep_lean4<12,") in dsw._p.describe(), dsw._p.describe()
     c = CO.CProblem(bench.oracle_problem(cfg))
     Jprev = d64._p.get_J(prev=True)
     nodes = np.arange(0, g.nodes_n, 5, dtype=np.int64)
