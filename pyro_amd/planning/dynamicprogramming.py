@@ -101,7 +101,8 @@ class DynamicProgramming:
     # ------------------------------------------------------------------ device engine
     # interpolants of J_k the sweeps implement (discretizer.py:570-587 hands dp.interpol_method to RegularGridInterpolator
     # every sweep; 'bicubic' is this build's name for the RectBivariateSpline subclass, dynamicprogramming.py:578-614)
-    _INTERPOLATIONS = ("linear", "slinear", "nearest", "bicubic")
+    _INTERPOLATIONS = ("linear", "slinear", "nearest", "cubic", "cubic_legacy", "bicubic")
+    _SAME_ENGINE = {"slinear": "linear", "cubic_legacy": "cubic"}          # (methods the same engine serves)
 
     @property
     def interpol_method(self):
@@ -119,10 +120,22 @@ class DynamicProgramming:
                        every cell are fixed when the tables are packed).  Assigning it rebuilds the engine on the table
                        tier from the reference's look-up tables and carries the current cost-to-go (J, J_next, pi, k) over:
                        the new interpolant applies from the next sweep on, as in the reference; a sharded engine raises;
-          'bicubic' -- only as the class DynamicProgramming2DRectBivariateSpline;
-        anything else ('cubic', 'quintic', 'pchip') raises instead of silently computing with another interpolant."""
+          'cubic', 'cubic_legacy' -- 2-D grids: RegularGridInterpolator's order-3 spline, i.e. the interpolating tensor spline with
+                       not-a-knot ends (the spline of RectBivariateSpline(kx=ky=3): SciPy's 'cubic_legacy' agrees with it to 3e-15)
+                       inside the grid box and 0 outside.  Served by the spline sweep of the TABLE tier (refit every sweep) with the
+                       in-box mask of x_next as its validity table; the engine is rebuilt like for 'nearest'.  SciPy >= 1.13 fits
+                       'cubic' with an iterative solver at its default tolerance and is itself some 1e-5 of max|J| away from the
+                       spline it approximates (tests/golden/cubic_pendulum.npz records both): this build returns the exact fit
+                       for either name.  Grids of other dimensions raise;
+          'bicubic' -- only as the class DynamicProgramming2DRectBivariateSpline (the same spline, CLAMPED outside the box);
+        anything else ('quintic', 'pchip') raises instead of silently computing with another interpolant."""
         if value not in self._INTERPOLATIONS:
             raise NotImplementedError("interpol_method %r: the GPU sweeps implement %s" % (value, ", ".join(self._INTERPOLATIONS)))
+        if self._SAME_ENGINE.get(value, value) == "cubic":
+            if self.sys.n != 2:
+                raise NotImplementedError("interpol_method %r: the spline sweep is 2-D (this grid has %d axes)" % (value, self.sys.n))
+            if self.INTERNAL_ORDER == "swapped" or self.F32_FEEDBACK:
+                raise NotImplementedError("interpol_method %r runs on the table tier: no internal_order / f32_feedback" % (value,))
         if value == "bicubic" or self.INTERPOLATION == "bicubic":
             if "_p" in self.__dict__ and value != self.INTERPOLATION:
                 raise NotImplementedError("interpol_method %r on a %s engine: use %s" % (
@@ -132,7 +145,7 @@ class DynamicProgramming:
             return
         old = self.__dict__.get("_interpol_method", "linear")
         self.__dict__["_interpol_method"] = value
-        same = {"slinear": "linear"}          # (methods the same engine serves)
+        same = self._SAME_ENGINE
         if "_p" in self.__dict__ and same.get(value, value) != same.get(old, old):
             if self.comm is not None or not hasattr(self, "_rebuild_engine"):
                 self.__dict__["_interpol_method"] = old
@@ -177,8 +190,11 @@ class DynamicProgramming:
         if self.INTERPOLATION != "linear" and dd is not None and dd[0] != _native.DYN_PENDULUM:
             self.tier = "table"         # the spline sweep has in-kernel dynamics for the pendulum family only
         nearest = self.__dict__.get("_interpol_method", "linear") == "nearest"
-        if nearest:
-            self.tier = "table"         # nearest-neighbour interpolation: packed into the table tier's records
+        method = self.__dict__.get("_interpol_method", "linear")
+        cubic = self._SAME_ENGINE.get(method, method) == "cubic"
+        if nearest or cubic:
+            self.tier = "table"         # nearest-neighbour interpolation: packed into the table tier's records;
+                                        # 'cubic': the spline sweep over the raw tables with the in-box mask
         if self.tier == "fused":
             # (base class: an invalid cell costs exactly INF; the same as INF + alpha*0 unless the system rejects
             #  states inside the grid box, i.e. obstacles)
@@ -209,7 +225,17 @@ class DynamicProgramming:
                 self._p.set_interpolation(self.INTERPOLATION)       # before the tables: the spline sweep reads them raw
             elif nearest:
                 self._p.set_interpolation("nearest")                # before the tables: fractions are snapped when they are packed
+            elif cubic:
+                self._p.set_interpolation("bicubic")
             ok = (g.action_isok & g.x_next_isok) if self.HARD_INF else None
+            if cubic and ok is None:
+                # RegularGridInterpolator(bounds_error=False, fill_value=0): a cell outside the box of the grid LEVELS takes
+                # J = 0, so Q = G + alpha * 0 = INF exactly (G is INF there: x_next_isok is false outside the box) -- the
+                # kernel's validity table does that; inside the box the look-up-table class adds the spline even where G = INF
+                xn = g.x_next_table
+                ok = np.ones(xn.shape[:2], dtype=bool)
+                for d in range(s.n):
+                    ok &= ~(xn[:, :, d] < g.x_level[d][0]) & ~(xn[:, :, d] > g.x_level[d][-1])
             self._p.set_tables(g.x_next_table, self._host_cost_table(), ok)
         if self.tier == "fused" and self.INTERPOLATION != "linear":
             self._p.set_interpolation(self.INTERPOLATION)

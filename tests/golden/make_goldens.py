@@ -725,7 +725,44 @@ def case_slinear():
     save("slinear_cartpole_7x9x7x9x3", **out4)
 
 
-CASES = dict(slinear=case_slinear, nearest=case_nearest, longcar=case_longcar, car=case_car, suspension=case_suspension, floatmass=case_floatmass, acrobot=case_acrobot, mintime=case_mintime, mountaincar=case_mountaincar, spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
+def case_cubic():
+    """interpol_method = 'cubic' / 'cubic_legacy' on 2-D grids (RegularGridInterpolator's order-3 spline: the not-a-knot tensor
+    spline through J_k, ZERO outside the grid box -- bounds_error=False, fill_value=0 -- where
+    DynamicProgramming2DRectBivariateSpline clamps).  SciPy >= 1.13 fits 'cubic' with an ITERATIVE sparse solver (gcrotmk at its
+    default tolerance: the interpolant it returns is some 1e-5 of max|J| away from the interpolating spline) and keeps the exact
+    fit (successive 1-D make_interp_spline) as 'cubic_legacy'; the reference forwards either string.  Recorded: the LUT class with
+    'cubic_legacy' on two pendulum grids (J / pi / margin of the argmin after sweeps 1, 2, 8), the same solves with 'cubic' (J after
+    2 and 8: the solver's tolerance, measured), and the cell-by-cell base class with 'cubic_legacy' for 2 sweeps on the small grid."""
+    out = {}
+    for tag, (xd, ud, dt) in dict(a=((31, 21), (5,), 0.05), b=((41, 31), (7,), 0.1)).items():
+        s, g, q = _pendulum_problem(xd, ud, dt=dt)
+        for k_, v_ in _meta(s, g, q).items():
+            out[tag + "_" + k_] = v_
+        with quiet():
+            for method, sfx in (("cubic_legacy", ""), ("cubic", "_iter")):
+                dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, q)
+                dp.save_time_history = False
+                dp.interpol_method = method
+                for k in range(1, 9):
+                    dp.initialize_backward_step()
+                    dp.compute_backward_step()
+                    dp.finalize_backward_step()
+                    if k in (1, 2, 8) and not sfx:
+                        out["%s_J_%d" % (tag, k)] = dp.J.copy(); out["%s_pi_%d" % (tag, k)] = dp.pi.copy()
+                        Q = np.sort(dp.Q, axis=1)
+                        out["%s_gap_%d" % (tag, k)] = Q[:, 1] - Q[:, 0]
+                    elif k in (2, 8):
+                        out["%s_J_%d%s" % (tag, k, sfx)] = dp.J.copy()
+            if tag == "a":
+                db = dynamicprogramming.DynamicProgramming(g, q)
+                db.save_time_history = False
+                db.interpol_method = "cubic_legacy"
+                db.compute_steps(2)
+                out["a_base_J_2"] = db.J.copy(); out["a_base_pi_2"] = db.pi.copy()
+    save("cubic_pendulum", **out)
+
+
+CASES = dict(cubic=case_cubic, slinear=case_slinear, nearest=case_nearest, longcar=case_longcar, car=case_car, suspension=case_suspension, floatmass=case_floatmass, acrobot=case_acrobot, mintime=case_mintime, mountaincar=case_mountaincar, spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
              policy_eval=case_policy_eval, cost_kat=case_cost_kat, grid_kat=case_grid_kat,
              pendulum_small=case_pendulum_small, config1=case_config1, lowdef=case_lowdef,
              pendulum_demo=case_pendulum_demo, cartpole_small=case_cartpole_small,

@@ -349,6 +349,49 @@ def test_spline_value_iteration_golden():
             J = Jn
 
 
+def test_cubic_interpolation_golden():
+    """dp.interpol_method = 'cubic' / 'cubic_legacy' on 2-D grids, run by the reference (dynamicprogramming.py:186-189 ->
+    discretizer.py:570-587 -> RegularGridInterpolator(method, bounds_error=False, fill_value=0)): the interpolating tensor spline of
+    RectBivariateSpline(kx=ky=3) inside the grid box and ZERO outside.  'cubic_legacy' is SciPy's exact fit: 1e-11 after sweeps 1,
+    2, 8 of the LUT class on two grids and 2 sweeps of the cell-by-cell base class.  'cubic' is the same spline fitted by an
+    iterative solver at its default tolerance (SciPy >= 1.13): the reference's own two solves differ by more than 1e-7 of max J,
+    and the exact spline is as close to 'cubic' as 'cubic_legacy' is."""
+    g = load("cubic_pendulum")
+    for tag in ("a", "b"):
+        xd, ud, dt = tuple(int(d) for d in g[tag + "_dims"]), tuple(int(d) for d in g[tag + "_udims"]), float(g[tag + "_dt"])
+        lv = O.make_levels(g[tag + "_x_lb"], g[tag + "_x_ub"], xd)
+        ul = O.make_levels(g[tag + "_u_lb"], g[tag + "_u_ub"], ud)
+        p = O.Problem(lv, ul, dt, O.DYN_PENDULUM, O.pendulum_consts(), g[tag + "_Q"], g[tag + "_R"], g[tag + "_S"], g[tag + "_xbar"],
+                      g[tag + "_ubar"], float(g[tag + "_INF"]), float(g[tag + "_EPS"]))
+        xn, x_ok, a_ok, G = O.cells(p, np.arange(p.nodes_n))
+        assert np.array_equal(O.box_mask(lv, xn), x_ok)       # (a stock system: the grid box IS the valid set)
+        J = O.terminal_cost(p)
+        Jb = J.copy()
+        for k in range(1, 9):
+            Jn, pi, _ = O.sweep_lut(lv, xn, G, J, method="cubic")
+            if k in (1, 2, 8):
+                Jg = g["%s_J_%d" % (tag, k)]
+                assert np.abs(Jn - Jg).max() <= 1e-11 * np.abs(Jg).max(), (tag, k)
+                clear = g["%s_gap_%d" % (tag, k)] > 1e-8
+                assert np.array_equal(pi[clear], g["%s_pi_%d" % (tag, k)][clear])
+                assert (pi != g["%s_pi_%d" % (tag, k)]).mean() < 0.02
+            if k in (2, 8):     # SciPy's iterative fit: a tolerance of the reference's environment, not of the restatement
+                Ji, Jg = g["%s_J_%d_iter" % (tag, k)], g["%s_J_%d" % (tag, k)]
+                tol_scipy = np.abs(Ji - Jg).max()
+                assert 1e-7 * np.abs(Jg).max() < tol_scipy < 1e-3 * np.abs(Jg).max()
+                assert np.abs(Jn - Ji).max() <= 1.0001 * tol_scipy + 1e-11 * np.abs(Jg).max()
+            J = Jn
+            if tag == "a" and k <= 2:
+                Jb, pib, _ = O.sweep_base_cubic(lv, xn, G, x_ok & a_ok, Jb, float(g["a_INF"]))
+        if tag == "a":
+            assert np.abs(Jb - g["a_base_J_2"]).max() <= 1e-11 * np.abs(Jb).max()
+            assert (pib != g["a_base_pi_2"]).mean() < 0.02
+    # it is NOT the clamped spline of the RectBivariateSpline class, nor the linear interpolant
+    Q2 = g["b_J_2"]
+    Qc, Ql, Qq = O.sweep_spline(lv, xn, G, Q2)[2], O.sweep_lut(lv, xn, G, Q2)[2], O.sweep_lut(lv, xn, G, Q2, method="cubic")[2]
+    assert np.abs(Qq - Qc).max() > 1e-3 and np.abs(Qq - Ql).max() > 1e-3
+
+
 # --------------------------------------------------------------- three-dimensional systems (SURVEY 8 f3 remainder)
 from cases3d import CASES3D, case3d  # noqa: E402
 

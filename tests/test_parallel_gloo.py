@@ -298,9 +298,22 @@ def test_interpol_method_is_not_silently_ignored():
     dp = Probe(cfg["grid_sys"], cfg["cf"])
     assert dp.interpol_method == "linear"
     dp.interpol_method = "linear"
-    for kind in ("cubic", "quintic", "pchip"):
+    for kind in ("quintic", "pchip", "quintic_legacy"):
         with pytest.raises(NotImplementedError):
             dp.interpol_method = kind
+    # 'cubic' / 'cubic_legacy' (round 6): the spline sweep of the table tier on 2-D grids -- sharded engines and grids of other
+    # dimensions keep raising, and a refused assignment leaves the attribute as it was
+    cfg4 = _build("cartpole:5,5,5,5:3:float64")
+    dp4 = Probe(cfg4["grid_sys"], cfg4["cf"])
+    for kind in ("cubic", "cubic_legacy"):
+        with pytest.raises(NotImplementedError, match="2-D"):
+            dp4.interpol_method = kind
+        assert dp4.interpol_method == "linear"
+    dp.comm = object()
+    with pytest.raises(NotImplementedError):
+        dp.interpol_method = "cubic"
+    assert dp.interpol_method == "linear"
+    dp.comm = None
     # 'slinear' (scipy's order-1 spline) IS the linear interpolant: served by the same engine, nothing is rebuilt (round 6;
     # tests/golden/slinear_*.npz: the reference's own solves with the two methods agree to 2e-15)
     engine = dp._p
