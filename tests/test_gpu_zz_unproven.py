@@ -137,6 +137,13 @@ def test_cubic_interpolation_through_the_class_surface_matches_reference_golden(
             J8 = dp.J.copy()
             dp.interpol_method = "linear"
             assert dp.tier == "fused" and np.array_equal(dp.J, J8)
+            if tag == "b":              # float32 storage of J around the same float64 fit and evaluation
+                d32 = DP.DynamicProgrammingWithLookUpTable(grid, cf, dtype="float32")
+                d32.save_time_history = False
+                d32.interpol_method = "cubic"
+                d32.compute_steps(8)
+                assert "float" in d32._p.describe().split("kernel=")[1].split()[0]
+                assert np.abs(d32.J - Jg).max() <= 1e-6 * np.abs(Jg).max()
             if tag == "a":
                 db = DP.DynamicProgramming(grid, cf)
                 db.save_time_history = False
