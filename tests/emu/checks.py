@@ -362,6 +362,9 @@ def check_table_tier_spline_rollout():
     with quiet():
         Z.test_slinear_interpolation_through_the_class_surface_matches_reference_golden()
     print("interpol_method = 'slinear' against the reference's own slinear solves: ok")
+    with quiet():
+        Z.test_cubic_interpolation_through_the_class_surface_matches_reference_golden()
+    print("interpol_method = 'cubic' / 'cubic_legacy' (2-D) against the reference's own cubic_legacy solves: ok")
 
 
 def check_multi_sweep_launches():
