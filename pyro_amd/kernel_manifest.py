@@ -187,7 +187,11 @@ def code_objects(so_path, outdir):
     import struct
     os.makedirs(outdir, exist_ok=True)
     fat = os.path.join(outdir, "fatbin.bin")
-    subprocess.run([OBJCOPY, "--dump-section", ".hip_fatbin=" + fat, so_path], check=True)
+    # (objcopy with ONE file name rewrites that file in place: always name an output, and throw it away -- round 6 found the
+    #  product library re-laid-out by its own provenance test, its sha256 no longer the manifest's)
+    discard = os.path.join(outdir, "discard.so")
+    subprocess.run([OBJCOPY, "--dump-section", ".hip_fatbin=" + fat, so_path, discard], check=True)
+    os.remove(discard)
     d = open(fat, "rb").read()
     out = []
     for i, m in enumerate(re.finditer(b"\x7fELF", d)):
