@@ -8,7 +8,8 @@ C=${1:-unknown}; BUDGET=$(( ${2:-25} * 60 )); T0=$(date +%s)
 cd /root/repo; O=gpurun_out/r06; mkdir -p $O; : > $O/summary.log
 say() { echo "$@" | tee -a $O/summary.log; }
 left() { local l=$(( BUDGET - ($(date +%s) - T0) )); [ $l -lt 0 ] && l=0; echo $l; }
-cap() { local want=$1 l=$(left); [ $want -gt $l ] && want=$l; echo $want; }      # a stage's timeout: what it wants, at most what is left
+# a stage's timeout: what it wants, at most what is left -- never 0 (`timeout 0` means NO limit): a spent budget gives every later stage one second
+cap() { local want=$1 l=$(left); [ $want -gt $l ] && want=$l; [ $want -lt 1 ] && want=1; echo $want; }
 say "commit $C  $(date -u +%FT%TZ)  budget ${BUDGET}s  $(python tools/kernel_manifest.py check pyro_amd/kernel_manifest.json | tail -1)"
 timeout $(cap 300) python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; say "smoke rc=$? :: $(tail -1 $O/smoke.log | cut -c1-200)"
 timeout $(cap 400) python bench.py > $O/bench_final.json 2> $O/bench_final.err; say "bench rc=$? :: $(tail -c 400 $O/bench_final.json)"
