@@ -27,6 +27,16 @@ class CostFunction:
         """dict(Q,R,S,xbar,ubar,EPS,INF,ontarget_check) when libpyrovi can evaluate g/h, else None."""
         return None
 
+    def trajectory_evaluation(self, traj):
+        """A copy of `traj` with dJ[i] = g(x[i], u[i], t[i]) and J = its cumulative trapezoidal integral over t, J[0] = 0
+        (costfunction.py:56-94)."""
+        import copy
+        from scipy.integrate import cumulative_trapezoid
+        dJ = np.array([self.g(traj.x[i], traj.u[i], traj.t[i]) for i in range(traj.time_steps)], dtype=float)
+        out = copy.copy(traj)
+        out.J, out.dJ = cumulative_trapezoid(y=dJ, x=traj.t, initial=0), dJ
+        return out
+
 
 def _quad(M, v):
     return float(v @ (np.asarray(M) @ v))

@@ -31,6 +31,29 @@ class StaticController:
     def __add__(self, sys):
         return ClosedLoopSystem(sys, self)
 
+    def plot_control_law(self, i=0, j=1, k=0, t=0, n=10, sys=None):
+        """Input k of the law over the (x_i, x_j) plane through sys.xbar, n x n samples (controller.py:104-170; static state
+        feedback: y = x)."""
+        import matplotlib.pyplot as plt
+        if sys is None:
+            raise ValueError("plot_control_law needs the system (its bounds and labels)")
+        xs, ys = np.linspace(sys.x_lb[i], sys.x_ub[i], n), np.linspace(sys.x_lb[j], sys.x_ub[j], n)
+        Z = np.zeros((n, n))
+        for a in range(n):
+            for b in range(n):
+                x = np.array(sys.xbar, dtype=float)
+                x[i], x[j] = xs[a], ys[b]
+                Z[a, b] = np.atleast_1d(self.c(x, self.t2r(t), t))[k]
+        fig, ax = plt.subplots(figsize=(4, 3), dpi=200)
+        im = ax.pcolormesh(xs, ys, Z.T, shading="gouraud")
+        ax.set_xlabel("%s %s" % (sys.state_label[i], sys.state_units[i]), fontsize=5)
+        ax.set_ylabel("%s %s" % (sys.state_label[j], sys.state_units[j]), fontsize=5)
+        ax.tick_params(labelsize=5)
+        fig.colorbar(im, ax=ax).ax.tick_params(labelsize=5)
+        fig.tight_layout()
+        plt.show()
+        return fig, ax
+
 
 class ClosedLoopSystem(system.ContinuousDynamicSystem):
     """dx = plant.f(x, controller.c(plant.h(x, ubar, t), r, t), t)  (controller.py:328-355)."""
@@ -48,6 +71,7 @@ class ClosedLoopSystem(system.ContinuousDynamicSystem):
         self.u_ub, self.u_lb = controller.r_ub, controller.r_lb
         self.xbar, self.ubar = plant.xbar, controller.rbar
         self.x0 = plant.x0
+        self._xbar_init, self._ubar_init = self.xbar, self.ubar      # (controller.py:324: the cost function is made here)
 
     def f(self, x, u, t=0):
         y = self.plant.h(x, self.plant.ubar, t)
@@ -55,3 +79,44 @@ class ClosedLoopSystem(system.ContinuousDynamicSystem):
 
     def h(self, x, u, t=0):
         return self.plant.h(x, self.plant.ubar, t)
+
+    def t2u(self, t):
+        """The combined system's input is the controller's reference signal (controller.py:357-372)."""
+        return self.controller.t2r(t)
+
+    def compute_trajectory(self, tf=10, n=10001, solver="solve_ivt"):
+        """Closed-loop trajectory with the plant's inputs and cost (controller.py:517-530 -> simulation.CLosedLoopSimulator).
+
+        The case the value-iteration scripts end with -- the policy of a solve, `(dp.get_lookup_table_controller() + sys)
+        .compute_trajectory(tf, n, 'euler')` -- is one row of the batched rollout kernel (dp.simulate_closed_loop ->
+        pvi_rollout: policy gather, f, Euler step on the GPU) when the controller still is the solve's (same policy, linear
+        interpolation, constant reference) and the engine has the plant's closed form; everything else is the host loop."""
+        from pyro_amd.analysis import simulation
+        traj = self._device_euler(tf, n) if solver == "euler" else None
+        if traj is None:
+            traj = simulation.CLosedLoopSimulator(self, tf, n, solver).compute()
+        self.traj = traj
+        return self.traj
+
+    def _device_euler(self, tf, n):
+        from pyro_amd.analysis import simulation
+        ctl = self.controller
+        dp = getattr(ctl, "_dp", None)
+        if dp is None or dp.sys is not self.plant or n is None or int(n) < 2:
+            return None
+        if type(ctl).__name__ != "LookUpTableController" or not type(ctl).__module__.endswith("planning.dynamicprogramming") \
+                or "c" in ctl.__dict__ or "t2r" in ctl.__dict__:
+            return None                                # (a subclass or a patched instance: arbitrary Python again)
+        if any(m != "linear" for m in ctl.interpol_method) or not np.array_equal(np.asarray(ctl.pi), np.asarray(dp.pi)):
+            return None                                # (the controller was edited after the solve: its own tables rule)
+        if type(self.plant).h is not system.ContinuousDynamicSystem.h:
+            return None                                # (static state feedback on y = x only)
+        try:
+            t, X, U = dp.simulate_closed_loop(np.asarray(self.x0, dtype=float)[None, :], tf, int(n), device_only=True)
+        except NotImplementedError:
+            return None
+        x, u = X[0], U[0]
+        dx = np.asarray(self.plant.f_batch(x, u), dtype=float)
+        dx[-1] = 0.0                                   # (the reference's Euler loop leaves the last derivative at zero)
+        r = np.tile(np.atleast_1d(np.asarray(ctl.rbar, dtype=float)), (t.size, 1))
+        return simulation.finish_closed_loop(self, simulation.Trajectory(x=x, u=r, t=t, dx=dx, y=x.copy()), u)

@@ -32,13 +32,18 @@ class ContinuousDynamicSystem:
         self.tbar = 0
         self.x0 = np.zeros(n)
         self.traj = None
+        self._xbar_init, self._ubar_init = self.xbar, self.ubar      # (what the default cost function is built around)
 
-    # the cost function the reference attaches in __init__ (system.py:121), built on first use
+    # the cost function the reference attaches in __init__ (system.py:121), built on first use -- around the xbar / ubar ARRAYS
+    # the system had at the end of ContinuousDynamicSystem.__init__, as there (costfunction.py:139-147 keeps the objects: a
+    # subclass or a script that REBINDS sys.xbar / sys.ubar later does not move the default cost's target, an in-place edit does)
     @property
     def cost_function(self):
         if getattr(self, "_cost_function", None) is None:
             from pyro_amd.analysis import costfunction
-            self._cost_function = costfunction.QuadraticCostFunction.from_sys(self)
+            cf = costfunction.QuadraticCostFunction.from_sys(self)
+            cf.xbar, cf.ubar = self.__dict__.get("_xbar_init", cf.xbar), self.__dict__.get("_ubar_init", cf.ubar)
+            self._cost_function = cf
         return self._cost_function
 
     @cost_function.setter
@@ -78,6 +83,41 @@ class ContinuousDynamicSystem:
         for _ in range(steps):
             x = self.f(x, u, t) * dt + x
         return x
+
+    # ---- after a solve: trajectories (system.py:392-470; pyro_amd/analysis/simulation.py) -----------------
+    def compute_trajectory(self, tf=10, n=10001, solver="solve_ivt", **solver_args):
+        """Time evolution from self.x0 under the input signal t2u; kept in self.traj (system.py:392-405)."""
+        from pyro_amd.analysis import simulation
+        self.traj = simulation.Simulator(self, tf, n, solver).compute(**solver_args)
+        return self.traj
+
+    def plot_trajectory(self, plot="x", **kwargs):
+        """(system.py:408-422; computes the default trajectory when there is none)"""
+        from pyro_amd.analysis import simulation
+        if self.traj is None:
+            self.compute_trajectory()
+        return simulation.plot_trajectory(self, self.traj, plot, **kwargs)
+
+    def plot_phase_plane_trajectory(self, x_axis=0, y_axis=1):
+        """(system.py:446-459)"""
+        from pyro_amd.analysis import simulation
+        if self.traj is None:
+            self.compute_trajectory()
+        return simulation.plot_phase_plane_trajectory(self, self.traj, x_axis, y_axis)
+
+    def animate_simulation(self, **kwargs):
+        """The reference draws the system's kinematic sketch along self.traj (system.py:521-560, graphical.Animator).  Graphics
+        are outside this build's scope: the trajectory is computed like there, nothing is drawn, and that is said."""
+        if self.traj is None:
+            self.compute_trajectory()
+        print("pyro_amd: animate_simulation() -- animations are not part of this build; the trajectory is in .traj "
+              "(%d points over %.3g s)" % (self.traj.time_steps, self.traj.time_final))
+        return None
+
+    def show(self, q=None, **kwargs):
+        """(system.py:484-497: a still of the kinematic sketch) -- not part of this build, see animate_simulation."""
+        print("pyro_amd: show() -- kinematic sketches are not part of this build")
+        return None
 
     # ---- device path -------------------------------------------------------------------------------
     def device_dynamics(self):

@@ -445,9 +445,11 @@ class DynamicProgramming:
         self.J, self.pi = J, pi
 
     def get_lookup_table_controller(self):
-        return LookUpTableController(self.grid_sys, self.pi)
+        ctl = LookUpTableController(self.grid_sys, self.pi)
+        ctl._dp = self      # (lets `ctl + sys` hand an Euler trajectory to the rollout kernel: ClosedLoopSystem.compute_trajectory)
+        return ctl
 
-    def simulate_closed_loop(self, X0, tf=10.0, n=10001):
+    def simulate_closed_loop(self, X0, tf=10.0, n=10001, device_only=False):
         """(not in the reference) B closed-loop Euler trajectories of the current policy on the GPU: what
         `(dp.get_lookup_table_controller() + sys).compute_trajectory(tf, n, 'euler')` does for one x0
         (controller.py:328-355, simulation.py:298-324).  Returns t [n], X [B,n,sys.n], U [B,n,sys.m]."""
@@ -464,6 +466,8 @@ class DynamicProgramming:
             self._p.set_pi(self.pi)             # the host policy may have been edited (clean_infeasible_set)
             X, U = self._p.rollout(X0, n, dt)
             return t, X, U
+        if device_only:
+            raise NotImplementedError("no rollout kernel for this engine")
         # systems whose f is arbitrary Python (table tier, per-node tables of generic mechanical systems): the reference's loop --
         # u = ctl.c(x, t), x <- x + f(x, u, t) dt (controller.py:328-355, simulation.py:298-324) -- on the host
         ctl = self.get_lookup_table_controller()

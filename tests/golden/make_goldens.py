@@ -762,7 +762,37 @@ def case_cubic():
     save("cubic_pendulum", **out)
 
 
-CASES = dict(cubic=case_cubic, slinear=case_slinear, nearest=case_nearest, longcar=case_longcar, car=case_car, suspension=case_suspension, floatmass=case_floatmass, acrobot=case_acrobot, mintime=case_mintime, mountaincar=case_mountaincar, spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
+def case_trajectory():
+    """What the reference's scripts do with a solve's policy: `cl = ctl + sys; cl.x0 = ...; cl.compute_trajectory(tf, n, 'euler')`
+    (controller.py:517-530 -> simulation.CLosedLoopSimulator, :391-447) -- every field of the Trajectory (x, u, t, dx, y, r, J, dJ)
+    for two initial states on the pendulum 21x21x5 policy of case_rollout; and an OPEN-loop pendulum under a constant torque
+    with the default solver (`sys.compute_trajectory(2.0, 41)`: solve_ivp, simulation.py:259-292)."""
+    s, g, q = _pendulum_problem((21, 21), (5,))
+    out = _meta(s, g, q)
+    with quiet():
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(g, q)
+        dp.save_time_history = False
+        dp.compute_steps(40)
+        dp.clean_infeasible_set()
+        ctl = dp.get_lookup_table_controller()
+        cl = ctl + s
+        out["pi"] = dp.pi.astype(np.int16)
+        for k, x0 in enumerate(([-3.0, 0.5], [0.0, 0.0])):
+            cl.x0 = np.array(x0)
+            tr = cl.compute_trajectory(3.0, 121, "euler")
+            for name in ("x", "u", "t", "dx", "y", "r", "J", "dJ"):
+                out["cl%d_%s" % (k, name)] = np.asarray(getattr(tr, name))
+            out["cl%d_x0" % k] = np.array(x0)
+        s2 = pendulum.SinglePendulum()
+        s2.ubar = np.array([1.5])
+        s2.x0 = np.array([0.4, -0.2])
+        tr = s2.compute_trajectory(2.0, 41)
+        for name in ("x", "u", "t", "dx", "y", "J", "dJ"):
+            out["ol_" + name] = np.asarray(getattr(tr, name))
+    save("trajectory_pendulum_21x21x5", **out)
+
+
+CASES = dict(trajectory=case_trajectory, cubic=case_cubic, slinear=case_slinear, nearest=case_nearest, longcar=case_longcar, car=case_car, suspension=case_suspension, floatmass=case_floatmass, acrobot=case_acrobot, mintime=case_mintime, mountaincar=case_mountaincar, spline=case_spline, f_kat=case_f_kat, rollout=case_rollout, obstacles=case_obstacles, helicopter=case_helicopter, reachability=case_reachability,
              policy_eval=case_policy_eval, cost_kat=case_cost_kat, grid_kat=case_grid_kat,
              pendulum_small=case_pendulum_small, config1=case_config1, lowdef=case_lowdef,
              pendulum_demo=case_pendulum_demo, cartpole_small=case_cartpole_small,

@@ -94,6 +94,56 @@ def test_error_feedback_over_python_driven_slabs(tmp_path):
     np.testing.assert_allclose(r["stats"][:4], stats[:4], rtol=1e-12)
 
 
+def test_closed_loop_trajectory_of_a_solve_matches_the_reference():
+    """Round 6 (SURVEY 8f.2, the caller after the path): what the reference's scripts end with -- `cl = ctl + sys; cl.x0 = ...;
+    cl.compute_trajectory(3.0, 121, 'euler')` with ctl = dp.get_lookup_table_controller() -- is ONE row of the rollout kernel
+    (pvi_rollout; the code object of dp.simulate_closed_loop) plus the host bookkeeping of simulation.CLosedLoopSimulator: every
+    field of the reference's Trajectory (tests/golden/trajectory_pendulum_21x21x5.npz).  A controller edited after the solve
+    falls back to the host loop and gives the same numbers."""
+    from conftest import GOLDEN
+    import os
+    from pyro_amd.analysis import costfunction
+    from pyro_amd.control import controller
+    from pyro_amd.dynamic import pendulum
+    from pyro_amd.planning import discretizer, dynamicprogramming
+    g = np.load(os.path.join(GOLDEN, "trajectory_pendulum_21x21x5.npz"))
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = pendulum.SinglePendulum()
+        grid = discretizer.GridDynamicSystem(s, [21, 21], [5])
+        q = costfunction.QuadraticCostFunction.from_sys(s)
+        q.xbar, q.INF = np.array([-3.14, 0.0]), 300
+        dp = dynamicprogramming.DynamicProgrammingWithLookUpTable(grid, q)
+        dp.save_time_history = False
+        dp.compute_steps(40)
+        dp.clean_infeasible_set()
+    assert np.array_equal(dp.pi, g["pi"])
+    ctl = dp.get_lookup_table_controller()
+    cl = ctl + s
+    assert isinstance(cl, controller.ClosedLoopSystem)
+    calls = []
+    real = dp.simulate_closed_loop
+    dp.simulate_closed_loop = lambda *a, **k: (calls.append(k.get("device_only")), real(*a, **k))[1]
+    for k in (0, 1):
+        cl.x0 = g["cl%d_x0" % k]
+        tr = cl.compute_trajectory(3.0, 121, "euler")
+        assert tr is cl.traj and calls[-1] is True                      # (the rollout kernel computed x and u)
+        for name in ("t", "x", "u", "y", "r"):
+            np.testing.assert_allclose(getattr(tr, name), g["cl%d_%s" % (k, name)], rtol=1e-8, atol=1e-8, err_msg=name)
+        np.testing.assert_allclose(tr.dx, g["cl%d_dx" % k], rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(tr.dJ, g["cl%d_dJ" % k], rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(tr.J, g["cl%d_J" % k], rtol=1e-7, atol=1e-7)
+    # a controller that is no longer the solve's: the host loop (the reference's own), the same trajectory
+    n_dev = len(calls)
+    ctl2 = dp.get_lookup_table_controller()
+    ctl2._dp = None
+    cl2 = controller.ClosedLoopSystem(s, ctl2)
+    cl2.x0 = g["cl0_x0"]
+    th = cl2.compute_trajectory(3.0, 121, "euler")
+    assert len(calls) == n_dev
+    for name in ("x", "u", "dx", "y", "r", "J", "dJ"):
+        np.testing.assert_allclose(getattr(th, name), g["cl0_" + name], rtol=1e-10, atol=1e-10, err_msg=name)
+
+
 def test_cubic_interpolation_through_the_class_surface_matches_reference_golden():
     """Round 6 (VERDICT r5 missing #5): dp.interpol_method = 'cubic' / 'cubic_legacy' on 2-D grids -- RegularGridInterpolator's
     order-3 spline, zero outside the box -- served by the spline sweep of the table tier (the code objects of

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Drop-in check in the BUILD CONTAINER only (it reads /root/reference at run time; nothing of it is copied or shipped): the
+reference's own dynamic-programming demo scripts, examples/demos_by_tool/dynamicprogramming/*.py, executed UNMODIFIED with
+`import pyro...` resolved to this package -- `pyro.X` -> `pyro_amd.X` by an import hook -- matplotlib on the Agg backend.
+A script passes when it runs to its last line.  Under emulation today (PYROVI_LIB=tests/emu/_build/libpyrovi_emu.so), on a GPU box
+it would need the reference tree, which does not travel: this is a builder's tool, its log goes to profiles/.
+
+    PYROVI_LIB=tests/emu/_build/libpyrovi_emu.so python tools/run_reference_demos.py [script.py ...]
+"""
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMOS = os.path.join(os.environ.get("PYRO_REFERENCE", "/root/reference"), "examples", "demos_by_tool", "dynamicprogramming")
+
+BOOT = r"""
+import importlib, importlib.abc, importlib.util, runpy, sys, time
+sys.path.insert(0, %(root)r)
+import matplotlib
+matplotlib.use("Agg")
+import matplotlib.pyplot as plt
+plt.show = lambda *a, **k: None
+
+
+class _Alias(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    # `pyro` and `pyro.anything` ARE `pyro_amd` and `pyro_amd.anything`
+    def find_spec(self, name, path=None, target=None):
+        if name == "pyro" or name.startswith("pyro."):
+            return importlib.util.spec_from_loader(name, self)
+        return None
+
+    def create_module(self, spec):
+        return importlib.import_module("pyro_amd" + spec.name[4:])
+
+    def exec_module(self, module):
+        pass
+
+
+sys.meta_path.insert(0, _Alias())
+t0 = time.time()
+ns = runpy.run_path(%(script)r, run_name="__main__")
+dp = ns.get("dp")
+if dp is not None and hasattr(dp, "_p"):
+    print("DEMO-ENGINE tier=%%s k=%%s %%s" %% (getattr(dp, "tier", "?"), getattr(dp, "k", "?"), dp._p.describe()[:140]))
+print("DEMO-OK %%.1f s" %% (time.time() - t0))
+"""
+
+
+def main():
+    names = sys.argv[1:] or sorted(f for f in os.listdir(DEMOS) if f.endswith(".py"))
+    limit = int(os.environ.get("DEMO_TIMEOUT", "1500"))
+    ok = 0
+    for n in names:
+        script = os.path.join(DEMOS, n)
+        t0 = time.time()
+        try:
+            r = subprocess.run([sys.executable, "-c", BOOT % dict(root=ROOT, script=script)], capture_output=True, text=True, timeout=limit,
+                               cwd="/tmp", env=dict(os.environ, MPLBACKEND="Agg", PYTHONDONTWRITEBYTECODE="1"))
+            out, rc = r.stdout + r.stderr, r.returncode
+        except subprocess.TimeoutExpired as e:
+            out, rc = ((e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or "")) + "\nTIMEOUT", -9
+        good = rc == 0 and "DEMO-OK" in out
+        ok += good
+        eng = [l for l in out.splitlines() if l.startswith("DEMO-ENGINE")]
+        last = [l for l in out.strip().splitlines() if l.strip()][-3:]
+        print("%-52s %s  %6.1f s  %s" % (n, "ok  " if good else "FAIL", time.time() - t0, eng[0][12:] if eng else ""), flush=True)
+        if not good:
+            print("      " + "\n      ".join(l[:220] for l in last), flush=True)
+    print("reference demo scripts that run unmodified: %d / %d" % (ok, len(names)))
+    return 0 if ok == len(names) else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
