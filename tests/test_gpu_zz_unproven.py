@@ -539,6 +539,11 @@ def test_multi_sweep_launch_of_the_2d_float32_sweep_is_bit_identical(name):
     with _native.overrides(MULTI="0"):
         s = _dp(name)._p
         ss, ns = s.sweep(1, 1.0, -1.0)
+    tok = dict(t.split("=", 1) for t in m.describe().split() if "=" in t)
+    if "multi=0" in m.describe() and int(tok["grid"].split("x")[0]) > 512:
+        # the timed choice of set-up took a tiling of more than MULTI_MAX_WG workgroups: the multi-sweep launch does not apply to
+        # this handle (multi32_applies, lean.hip) and one launch per sweep is what runs -- nothing to compare
+        pytest.skip("tiling of %s workgroups: the multi-sweep launch does not apply (%s)" % (tok["grid"], m.describe()[:120]))
     assert "multi=1" in m.describe() and "kernel=k_sweep_leanm<" in m.describe(), m.describe()
     assert "multi=0" in s.describe() and "kernel=k_sweep_lean<" in s.describe(), s.describe()
     assert np.array_equal(np.array(sm), np.array(ss))
@@ -547,13 +552,17 @@ def test_multi_sweep_launch_of_the_2d_float32_sweep_is_bit_identical(name):
         ss, ns = s.sweep(n, 1.0, -1.0)
         assert nm == ns == n and np.array_equal(np.array(sm), np.array(ss)), n
         assert np.array_equal(m.get_J(), s.get_J()) and np.array_equal(m.get_pi(), s.get_pi()), n
-    # a stop in the middle of a batch: a tolerance the solve meets after a few dozen more sweeps
-    probe_stats, _ = s.sweep(30, 1.0, -1.0)
-    m.sweep(30, 1.0, -1.0)
-    tol = float(np.array(probe_stats)[-1, 3]) * 0.7
+    # a stop in the middle of a batch: the tolerance is the delta a scout run of the one-launch-per-sweep handle reaches 45 sweeps
+    # from here (round 6, found under emulation: "0.7 x the current delta" is never met within 400 sweeps on the 101 x 101 grid,
+    # whose delta sits on a plateau for hundreds of sweeps -- BASELINE configs[0] needs 618)
+    J_here = s.get_J()
+    assert np.array_equal(J_here, m.get_J())
+    scout, _ = s.sweep(45, 1.0, -1.0)
+    tol = float(np.array(scout)[-1, 3]) * 1.0000001
+    s.set_J(J_here)
     sm, nm = m.sweep(400, 1.0, tol)
     ss, ns = s.sweep(400, 1.0, tol)
-    assert nm == ns and 0 < nm < 400, (nm, ns, tol)
+    assert nm == ns and 0 < nm <= 45, (nm, ns, tol)
     assert np.array_equal(np.array(sm), np.array(ss))
     assert np.array_equal(m.get_J(), s.get_J()) and np.array_equal(m.get_pi(), s.get_pi())
     assert np.array_equal(m.get_J(prev=True), s.get_J(prev=True))
