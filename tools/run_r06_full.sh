@@ -35,6 +35,7 @@ fi
 t zz_swapped 600 tests/test_gpu_zz_unproven.py -k swapped
 t zz_fb2d 900 tests/test_gpu_zz_unproven.py -k "feedback_storage_on_2d"
 t zz_fbexp 600 tests/test_gpu_zz_unproven.py -k "explicit_system or node_table_tier"
+t zz_rest 900 tests/test_gpu_zz_unproven.py -k "declared_invariance or refusals or python_driven or closed_loop or cubic or slinear or corruption_detector or whole_number"
 [ $RC -eq 0 ] || { say "SUITE NOT GREEN: no profiles"; exit 1; }
 # 3. the round's evidence: per-workload kernel-trace stats + four PMC passes, counters.json keyed on the ISA hash, default bench
 PVI_ROUND=r06 timeout 2700 bash tools/tools_profile.sh > $O/profile.out 2>&1; say "profiles: $(tail -1 $O/profile.out | cut -c1-200)"

@@ -24,7 +24,7 @@ timeout $(cap 1500) python -m pytest tests/test_gpu_parity.py tests/test_gpu_str
 say "suite rc=$RC :: $(grep -E 'passed|failed|error' $O/suite.log | tail -1)"
 # (no bless here: blessing needs the list of kernels that really executed -- the traced second run of tools/run_r06_full.sh)
 [ $RC -eq 0 ] && PVI_ROUND=r06 PVI_HEAD=$C python tools/make_counters_json.py c3 >> $O/summary.log 2>&1
-for g in "swapped" "feedback_storage_on_2d" "explicit_system or node_table_tier" "cubic or slinear or refus or halo or detector" "2d_float32"; do
+for g in "swapped" "feedback_storage_on_2d" "explicit_system or node_table_tier" "declared_invariance or refusals or python_driven or closed_loop or cubic or slinear or corruption_detector or whole_number" "2d_float32"; do
   n=zz_$(echo "$g" | cut -d' ' -f1); l=$(cap 420); [ $l -lt 30 ] && { say "$n: no time left"; continue; }
   timeout $l python -m pytest tests/test_gpu_zz_unproven.py -m gpu -q -k "$g" > $O/$n.log 2>&1; say "$n rc=$? :: $(tail -1 $O/$n.log)"
 done
