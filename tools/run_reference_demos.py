@@ -5,7 +5,7 @@ reference's own dynamic-programming demo scripts, examples/demos_by_tool/dynamic
 A script passes when it runs to its last line.  Under emulation today (PYROVI_LIB=tests/emu/_build/libpyrovi_emu.so), on a GPU box
 it would need the reference tree, which does not travel: this is a builder's tool, its log goes to profiles/.
 
-    PYROVI_LIB=tests/emu/_build/libpyrovi_emu.so python tools/run_reference_demos.py [script.py ...]
+    PYROVI_LIB=tests/emu/_build/libpyrovi_emu.so python tools/run_reference_demos.py [script.py ... | more]
 """
 import os
 import subprocess
@@ -13,7 +13,19 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEMOS = os.path.join(os.environ.get("PYRO_REFERENCE", "/root/reference"), "examples", "demos_by_tool", "dynamicprogramming")
+EXAMPLES = os.path.join(os.environ.get("PYRO_REFERENCE", "/root/reference"), "examples")
+DEMOS = os.path.join(EXAMPLES, "demos_by_tool", "dynamicprogramming")
+# the value-iteration scripts elsewhere in the reference's examples that import nothing outside the mirrored modules (`more`);
+# lqr_vs_valueiteration_for_a_simple_pendulum.py and optimal_control_demo.py also need pyro.control.lqr /
+# pyro.planning.trajectoryoptimisation, the rl_* scripts stable_baselines3: other tools of the reference, out of scope
+MORE = ["courses/udes_gro860/dp_mass_min_time_policy_evaluation.py", "courses/udes_gro860/dp_mass_min_time_optimal.py",
+        "courses/udes_gro860/dp_demo_swingup.py", "demos_by_system/pendulum_simple/simple_pendulum_with_valueiteration_quadratic.py",
+        "demos_by_system/pendulum_simple/simple_pendulum_with_valueiteration_minimum_time.py",
+        "demos_by_system/holonomic_mobile_robot/holonomic_mobile_robot_with_valueiteration.py",
+        "demos_by_system/mountain_car/mountain_car_with_valueiteration_quadratic.py",
+        "demos_by_system/car_steering/car_with_valueiteration_quadratic_cost.py",
+        "demos_by_system/car_steering/car_with_valueiteration_minimum_time.py",
+        "demos_by_system/car_propulsion/longitudinal_car_braking_value_iteration.py"]
 
 BOOT = r"""
 import importlib, importlib.abc, importlib.util, runpy, sys, time
@@ -56,14 +68,16 @@ SAVE_AS = {"double_pendulum_optimal_swingup.py": "double_pendulum_51_41_51_41_5_
 
 def main():
     names = sys.argv[1:] or sorted(f for f in os.listdir(DEMOS) if f.endswith(".py"))
+    if names == ["more"]:
+        names = MORE
     limit = int(os.environ.get("DEMO_TIMEOUT", "1500"))
     ok = skipped = 0
     for n in names:
-        script = os.path.join(DEMOS, n)
+        script = os.path.join(EXAMPLES, n) if "/" in n else os.path.join(DEMOS, n)
         t0 = time.time()
         try:
             r = subprocess.run([sys.executable, "-c", BOOT % dict(root=ROOT, script=script)], capture_output=True, text=True, timeout=limit,
-                               cwd="/tmp", env=dict(os.environ, MPLBACKEND="Agg", PYTHONDONTWRITEBYTECODE="1", DEMO_SAVE=SAVE_AS.get(n, "")))
+                               cwd="/tmp", env=dict(os.environ, MPLBACKEND="Agg", PYTHONDONTWRITEBYTECODE="1", DEMO_SAVE=SAVE_AS.get(os.path.basename(n), "")))
             out, rc = r.stdout + r.stderr, r.returncode
         except subprocess.TimeoutExpired as e:
             out, rc = ((e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or "")) + "\nTIMEOUT", -9
@@ -76,7 +90,7 @@ def main():
         ok += good
         eng = [l for l in out.splitlines() if l.startswith("DEMO-ENGINE")]
         last = [l for l in out.strip().splitlines() if l.strip()][-3:]
-        print("%-52s %s  %6.1f s  %s" % (n, "ok  " if good else "FAIL", time.time() - t0, eng[0][12:] if eng else ""), flush=True)
+        print("%-52s %s  %6.1f s  %s" % (os.path.basename(n), "ok  " if good else "FAIL", time.time() - t0, eng[0][12:] if eng else ""), flush=True)
         if not good:
             print("      " + "\n      ".join(l[:220] for l in last), flush=True)
     print("reference demo scripts that run unmodified: %d / %d (%d more need a data file the reference does not ship)" % (ok, len(names) - skipped, skipped))
