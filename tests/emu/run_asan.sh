@@ -8,7 +8,7 @@ python tests/emu/build_emu.py --asan > /dev/null || exit 1
 B=$PWD/tests/emu/_build
 A=$(/opt/rocm/lib/llvm/bin/clang++ -print-file-name=libclang_rt.asan-x86_64.so)
 export LD_PRELOAD=$A ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:halt_on_error=1:detect_stack_use_after_return=0
-export PYROVI_LIB=$B/libpyrovi_emu_asan.so PVI_RCCL_LIB=$B/librccl_emu.so
+export PYROVI_LIB=$B/libpyrovi_emu_asan.so PVI_RCCL_LIB=$B/librccl_emu.so PVI_EMU_FULL=1
 L=/tmp/pvi_emu_asan.log; : > $L
 CHECKS=${*:-"f64_bit_identical f32_paths feedback_4d_and_detector swapped_order feedback_2d_explicit_node slabs_and_halo table_tier_spline_rollout multi_sweep_launches rccl_shards"}
 for c in $CHECKS; do
