@@ -525,25 +525,30 @@ def test_float32_slabs_refuse_or_agree_when_the_reach_sits_on_a_whole_number_of_
 
 
 # last of all: the one piece that could leave a GPU spinning if it were wrong (its grid barrier gives up after about a second)
-@pytest.mark.parametrize("name", ["pendulum:201,201:201:float32", "pendulum:201,201:21:float32", "pendulum:101,101:11:float32",
-                                  "pendulum:301,151:51:float32"])
-def test_multi_sweep_launch_of_the_2d_float32_sweep_is_bit_identical(name):
+@pytest.mark.parametrize("name,lsplit", [("pendulum:201,201:201:float32", "1"), ("pendulum:201,201:201:float32", "0"),
+                                         ("pendulum:201,201:21:float32", None), ("pendulum:101,101:11:float32", None),
+                                         ("pendulum:301,151:51:float32", "0")])
+def test_multi_sweep_launch_of_the_2d_float32_sweep_is_bit_identical(name, lsplit):
     """Round 5: batches of the 2-D float32 window sweep as ONE cooperative launch (k_sweep_leanm: write-through
     J, fence-free grid barrier, statistics records folded by every workgroup) against one launch per sweep (pvi_override MULTI=0):
     J, pi, every sweep's statistics and the stop sweep are the same bits -- fixed counts in odd batch sizes, then a tolerance
     stop in the middle of a batch, then a restart."""
     from pyro_amd import _native
-    with _native.overrides(MULTI32="1"):                      # (the form of a handle's batches is decided at its first sweep)
+    # `lsplit`: lanes per node = 2^lsplit.  The multi-sweep launch needs every workgroup resident and at most MULTI_MAX_WG = 512 of
+    # them (multi32_applies, lean.hip): set-up's own choice for 201 x 201 x 201 actions is 8 lanes per node -- 1 407 workgroups,
+    # the tiling of the round-4 bench line too -- which does not qualify; 2 lanes (316 workgroups) and 1 lane (158) do.
+    ls = {} if lsplit is None else {"LSPLIT": lsplit}
+    with _native.overrides(MULTI32="1", **ls):                # (the form of a handle's batches is decided at its first sweep)
         m = _dp(name)._p
         sm, nm = m.sweep(1, 1.0, -1.0)
-    with _native.overrides(MULTI="0"):
+    with _native.overrides(MULTI="0", **ls):
         s = _dp(name)._p
         ss, ns = s.sweep(1, 1.0, -1.0)
     tok = dict(t.split("=", 1) for t in m.describe().split() if "=" in t)
-    if "multi=0" in m.describe() and int(tok["grid"].split("x")[0]) > 512:
-        # the timed choice of set-up took a tiling of more than MULTI_MAX_WG workgroups: the multi-sweep launch does not apply to
-        # this handle (multi32_applies, lean.hip) and one launch per sweep is what runs -- nothing to compare
-        pytest.skip("tiling of %s workgroups: the multi-sweep launch does not apply (%s)" % (tok["grid"], m.describe()[:120]))
+    if "multi=0" in m.describe():
+        # more workgroups than MULTI_MAX_WG or than are resident at once: the multi-sweep launch does not apply to this handle and
+        # one launch per sweep is what runs -- nothing to compare (the reason is part of the skip message)
+        pytest.skip("grid of %s workgroups x %s threads: the multi-sweep launch does not apply (%s)" % (tok["grid"], tok["block"], m.describe()[:120]))
     assert "multi=1" in m.describe() and "kernel=k_sweep_leanm<" in m.describe(), m.describe()
     assert "multi=0" in s.describe() and "kernel=k_sweep_lean<" in s.describe(), s.describe()
     assert np.array_equal(np.array(sm), np.array(ss))

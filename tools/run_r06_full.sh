@@ -43,5 +43,5 @@ timeout 600 python bench.py > $O/bench_final.json 2> $O/bench_final.err; say "be
 timeout 600 bash tools/run_writecal.sh > $O/writecal.out 2>&1; say "writecal: $(tail -3 $O/writecal.out | tr '\n' ' ' | cut -c1-300)"
 timeout 600 python tools/slab_time.py c4 8 0 3 > $O/slab_times.log 2>&1; say "slabs: $(tail -2 $O/slab_times.log | tr '\n' ' ' | cut -c1-300)"
 # 4. last: the one kernel that could leave a GPU spinning if it were wrong (its barrier gives up after a second)
-t zz_multi32 300 tests/test_gpu_zz_unproven.py -k "2d_float32"
+t zz_multi32 300 tests/test_gpu_zz_unproven.py -k "2d_float32" -rs && { timeout 300 python tools/time_multi32.py > $O/time_multi32.log 2>&1; say "multi32 timing: $(grep -c us/sweep $O/time_multi32.log) lines"; }
 cat $O/summary.log
