@@ -33,3 +33,10 @@ ctl = dp.get_lookup_table_controller()
 t, X, U = dp.simulate_closed_loop(np.array([[0.0, 0.0], [1.0, 0.0], [-2.0, 1.0]]), tf=10.0, n=2001)
 for x0, xT in zip(X[:, 0], X[:, -1]):
     print("x0 = %s  ->  x(10 s) = %s   u(x0) = %+.3f" % (x0, np.round(xT, 3), ctl.c(x0, 0)[0]))
+
+# ... and what the reference's script does next, unchanged: the closed loop of the policy from one initial state, with the plant's
+# inputs and cost along it (one row of the same rollout kernel; pyro_amd/analysis/simulation.py)
+cl_sys = ctl + sys_
+cl_sys.x0 = np.array([0.0, 0.0])
+traj = cl_sys.compute_trajectory(10, 2001, "euler")
+print("closed loop from hanging at rest: x(10 s) = %s, cost along the trajectory J = %.2f" % (np.round(traj.x[-1], 3), traj.J[-1]))
