@@ -22,6 +22,9 @@ import run_reference_demos as R  # noqa: E402
 TAIL = r"""
 import numpy as _np
 _dp = ns.get("dp") or ns.get("evaluator")
+if _dp is None:        # (scripts that call their solver something else: the last object that looks like one)
+    _c = [v for v in ns.values() if all(hasattr(v, a) for a in ("J", "pi", "k", "grid_sys", "compute_steps"))]
+    _dp = _c[-1] if _c else None
 if _dp is not None:
     _np.savez(%(out)r, J=_np.asarray(_dp.J, dtype=float), pi=_np.asarray(_dp.pi).astype(int), k=int(_dp.k))
 print("DEMO-OK")
