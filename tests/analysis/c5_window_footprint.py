@@ -15,14 +15,14 @@ For sampled position nodes (i0, i1) and every velocity node and action, the cell
            mask, two cells per trip: the lanes of a trip are at different actions) against a walk over the UNION of the wave's
            masks (all lanes at one action per trip; lanes whose cell is outside sit the trip out).
 
-    python tools/c5_window_footprint.py [n_position_samples] [seed]
+    python tests/analysis/c5_window_footprint.py [n_position_samples] [seed]
 """
 import contextlib
 import io
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))      # the repository root
 import numpy as np
 
 from oracle import vi_oracle as O

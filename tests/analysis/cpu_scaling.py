@@ -1,7 +1,7 @@
 """How the oracle's C/OpenMP twin scales on this host: cells/s of a slice of a sweep at 1, 2, 4, ... threads.
 Diagnostic for bench.py's cpu_baseline (writes one JSON line)."""
 import contextlib, io, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_PROC_BIND", "spread")
 os.environ.setdefault("OMP_PLACES", "cores")
