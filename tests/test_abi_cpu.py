@@ -117,6 +117,13 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+    # ... nor do the builder's tools or the examples: scripts that use the CPU twin live under tests/analysis/
+    for sub in ("tools", "examples"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith((".py", ".sh")):
+                    txt = open(os.path.join(dirpath, f), errors="replace").read()
+                    assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(sub, f)
 
 
 @pytest.mark.parametrize("n,m", [(2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2)])
