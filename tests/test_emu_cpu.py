@@ -147,6 +147,23 @@ def test_multi_gpu_bench_harness_end_to_end_on_the_emulated_library(emu_lib):
     assert len(line["per_rank"]["sweep_ms"]) == 2
 
 
+def test_reference_scripts_solve_identically_with_the_reference_and_with_this_package(emu_lib):
+    """Where the reference tree is present (the build container; it does not travel, and nothing under -m gpu, smoke() or bench.py
+    reads it): two of the reference's own value-iteration scripts, UNMODIFIED, run twice -- with the reference itself and with
+    `pyro.*` resolved to `pyro_amd.*` on the emulated library -- leave the same solve behind: the same number of sweeps, J to 1e-9
+    of max J, the same action on 99.9 % of the nodes (tools/compare_reference_demos.py; all 22 scripts:
+    profiles/r06_reference_demos_compared.log, where every one is identical to 3.7e-15 and on every node)."""
+    ref = os.environ.get("PYRO_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "examples", "demos_by_tool", "dynamicprogramming")):
+        pytest.skip("the reference tree is not here")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "compare_reference_demos.py"), "pendulum_optimal_swingup_low_def_fast_computation.py",
+                        "demos_by_system/car_propulsion/longitudinal_car_braking_value_iteration.py"],
+                       env=_env(emu_lib, DEMO_TIMEOUT="600", PYRO_REFERENCE=ref), cwd=ROOT, capture_output=True, text=True, timeout=1500, preexec_fn=_all_cpus)
+    sys.stdout.write(r.stdout[-2000:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count(" ok  ") == 2 and "differs from the reference's (or could not be compared): 0 / 2" in r.stdout
+
+
 def test_the_product_never_loads_the_emulated_library():
     """grep: nothing under pyro_amd/, bench.py or __graft_entry__.py names tests/emu or libpyrovi_emu."""
     bad = []
